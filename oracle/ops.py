@@ -1,0 +1,131 @@
+"""numpy fp32 building blocks used by the oracle (TEST INFRASTRUCTURE).
+
+Layouts follow the reference (PyTorch): activations [B, C, T]; Conv1d weight
+[Cout, Cin, k]; ConvTranspose1d weight [Cin, Cout, k]; Linear weight [out, in].
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def conv1d(x, w, b=None, stride=1, padding=0, dilation=1):
+    """torch.nn.functional.conv1d semantics. x [B,Cin,T], w [Cout,Cin,k]."""
+    x = np.asarray(x, F32)
+    B, Cin, T = x.shape
+    Cout, Cin2, k = w.shape
+    assert Cin == Cin2
+    if padding:
+        x = np.pad(x, ((0, 0), (0, 0), (padding, padding)))
+    Tp = x.shape[2]
+    Tout = (Tp - dilation * (k - 1) - 1) // stride + 1
+    # cols[b, tap, ci, t] = x[b, ci, t*stride + tap*dilation]
+    s0, s1, s2 = x.strides
+    cols = np.lib.stride_tricks.as_strided(
+        x, shape=(B, k, Cin, Tout), strides=(s0, s2 * dilation, s1, s2 * stride), writeable=False)
+    w2 = np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(Cout, k * Cin)  # [Cout, tap*Cin+ci]
+    out = np.empty((B, Cout, Tout), F32)
+    for bi in range(B):
+        out[bi] = w2 @ np.ascontiguousarray(cols[bi]).reshape(k * Cin, Tout)
+    if b is not None:
+        out += np.asarray(b, F32)[None, :, None]
+    return out
+
+
+def conv_transpose1d(x, w, b=None, stride=1, padding=0):
+    """torch ConvTranspose1d (no output_padding, dilation 1). w [Cin,Cout,k].
+    out[b,co,t*stride + j - padding] += x[b,ci,t] * w[ci,co,j]"""
+    x = np.asarray(x, F32)
+    B, Cin, T = x.shape
+    _, Cout, k = w.shape
+    Lfull = (T - 1) * stride + k
+    full = np.zeros((B, Cout, Lfull), F32)
+    for j in range(k):
+        # contribution of tap j: [B,Cout,T] placed at positions t*stride + j
+        contrib = np.einsum("io,bit->bot", w[:, :, j], x, optimize=True).astype(F32)
+        full[:, :, j: j + (T - 1) * stride + 1: stride] += contrib
+    out = full[:, :, padding: Lfull - padding] if padding else full
+    if b is not None:
+        out = out + np.asarray(b, F32)[None, :, None]
+    return np.ascontiguousarray(out, F32)
+
+
+def linear(x, w, b=None):
+    """x [..., in], w [out, in]."""
+    y = np.asarray(x, F32) @ np.asarray(w, F32).T
+    if b is not None:
+        y = y + b
+    return y.astype(F32)
+
+
+def group_norm(x, groups, gamma, beta, eps=1e-5):
+    """torch.nn.GroupNorm on [B,C,T] (biased variance)."""
+    B, C, T = x.shape
+    xg = x.reshape(B, groups, -1).astype(np.float64)
+    mean = xg.mean(-1, keepdims=True)
+    var = xg.var(-1, keepdims=True)
+    y = ((xg - mean) / np.sqrt(var + eps)).reshape(B, C, T)
+    return (y * gamma[None, :, None] + beta[None, :, None]).astype(F32)
+
+
+def gn_groups(channels):
+    """`normalization()` group count, vqvae/utils/diff_util.py:118-133."""
+    groups = 32
+    if channels <= 16:
+        groups = 8
+    elif channels <= 64:
+        groups = 16
+    while channels % groups != 0:
+        groups = int(groups / 2)
+    assert groups > 2
+    return groups
+
+
+def layer_norm_last(x, gamma, beta, eps=1e-5):
+    x64 = x.astype(np.float64)
+    mean = x64.mean(-1, keepdims=True)
+    var = x64.var(-1, keepdims=True)
+    return (((x64 - mean) / np.sqrt(var + eps)) * gamma + beta).astype(F32)
+
+
+def layer_norm_channels(x, gamma, beta, eps=1e-5):
+    """modules.LayerNorm on [B,C,T] (vqvae/modules/modules.py:36-48)."""
+    return layer_norm_last(x.transpose(0, 2, 1), gamma, beta, eps).transpose(0, 2, 1)
+
+
+def sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
+
+
+def silu(x):
+    return (x * sigmoid(x)).astype(F32)
+
+
+def mish(x):
+    """x * tanh(softplus(x)), vqvae/modules/modules.py:497-502."""
+    x64 = x.astype(np.float64)
+    sp = np.logaddexp(0.0, x64)
+    return (x64 * np.tanh(sp)).astype(F32)
+
+
+def gelu_new(x):
+    x64 = x.astype(np.float64)
+    return (0.5 * x64 * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (x64 + 0.044715 * x64 ** 3)))).astype(F32)
+
+
+def leaky_relu(x, slope):
+    return np.where(x >= 0, x, x * F32(slope)).astype(F32)
+
+
+def softmax(x, axis=-1):
+    x64 = x.astype(np.float64)
+    m = x64.max(axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    e = np.exp(x64 - m)
+    return (e / e.sum(axis=axis, keepdims=True)).astype(F32)
+
+
+def sequence_mask(lengths, max_len):
+    """vqvae/modules/commons.py:144-148."""
+    return (np.arange(max_len)[None, :] < np.asarray(lengths)[:, None])
