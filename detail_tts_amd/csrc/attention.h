@@ -1,0 +1,37 @@
+// Attention launchers (see attention.hip).
+#pragma once
+#include "common.h"
+
+namespace dtts {
+
+struct AttnParams {
+    const float* qkv = nullptr;   // [B, rows, T]
+    long long bs = 0;             // batch stride (floats)
+    int cs = 0;                   // row (channel) stride == allocated T
+    int q_off = 0, k_off = 0, v_off = 0, head_stride = 0;   // row of (head h, dim c) = off + h*head_stride + c
+    float* out = nullptr;         // [B, H*D, T]
+    long long o_bs = 0;
+    int o_cs = 0;
+    const int* lens = nullptr;    // [B] valid length (null -> T)
+    int T = 0, B = 0, H = 0, D = 0;
+    float scale = 1.f;            // multiplies q.k
+    const float* bias_tab = nullptr;   // [H][129]: additive bias by clamp(s-t,-64,64)+64 (already scaled), or null
+    int causal = 0;
+    // VITS windowed relative-key logits (attentions.py:218-222): band[b,h,t,r], r = (s-t)+W, |s-t|<=W
+    const float* band = nullptr;
+    int band_w = 0;
+    float* ml_out = nullptr;      // optional [B,H,T,2] (running max, denominator) for the rel-value fix-up
+};
+
+void launch_flash_attention(const AttnParams& p, hipStream_t stream);
+
+// VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)
+//   relk[b,h,t,r] = scale * sum_c q[c,t] * Ek[r][c]
+void launch_vits_rel_key(const float* qkv, long long bs, int cs, int q_off, int head_stride, const float* Ek,
+                         float* relk, const int* lens, int B, int H, int D, int T, int W, float scale, hipStream_t s);
+//   out[b,h*D+c,t] += sum_r softmax(t, t+r-W) * Ev[r][c]    (uses ml from the flash kernel)
+void launch_vits_rel_value(const float* qkv, long long bs, int cs, int q_off, int k_off, int head_stride,
+                           const float* relk, const float* ml, const float* Ev, float* out, long long o_bs, int o_cs,
+                           const int* lens, int B, int H, int D, int T, int W, float scale, hipStream_t s);
+
+}  // namespace dtts

@@ -1,0 +1,133 @@
+// extern "C" surface of libdetail_hip.so (see include/detail_hip.h).
+#include <mutex>
+
+#include "model.h"
+
+using dtts::Model;
+
+struct dtts_handle {
+    std::unique_ptr<Model> m;
+    std::string err;
+};
+
+static std::string g_create_error;
+
+#define DTTS_API_BEGIN try {
+#define DTTS_API_END(h)                                   \
+    }                                                     \
+    catch (const dtts::Error& e) {                        \
+        if (h) (h)->err = e.what();                       \
+        return e.code;                                    \
+    }                                                     \
+    catch (const std::exception& e) {                     \
+        if (h) (h)->err = e.what();                       \
+        return -100;                                      \
+    }                                                     \
+    return 0;
+
+extern "C" {
+
+const char* dtts_version(void) { return "detail_hip 0.1 (gfx950)"; }
+
+void dtts_default_config(dtts_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->diff_channels = 768; c->diff_layers = 10; c->diff_heads = 16; c->mel_channels = 128; c->diff_out_channels = 256;
+    c->diff_steps = 50; c->diff_trained_steps = 4000; c->cond_free_k = 2.0f;
+    c->gpt_dim = 768; c->gpt_layers = 10; c->gpt_heads = 16; c->gpt_mel_codes = 8194; c->gpt_text_tokens = 257;
+    c->gpt_max_mel_pos = 1603; c->gpt_max_text_pos = 802;
+    c->inter_channels = 192; c->hidden_channels = 192; c->filter_channels = 512; c->enc_heads = 4; c->enc_layers = 3;
+    c->gin_channels = 768; c->upsample_initial_channel = 400; c->n_upsamples = 5;
+    const int rates[5] = {8, 4, 2, 2, 2}, kern[5] = {16, 8, 2, 2, 2};
+    for (int i = 0; i < 5; ++i) { c->upsample_rates[i] = rates[i]; c->upsample_kernels[i] = kern[i]; }
+    c->n_resblock_kernels = 3;
+    const int rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
+    for (int i = 0; i < 3; ++i) { c->resblock_kernels[i] = rk[i]; c->resblock_dilations[i] = rd[i]; }
+}
+
+int dtts_create(dtts_handle** out, const dtts_config* cfg, int device) {
+    if (!out || !cfg) return -1;
+    *out = nullptr;
+    try {
+        auto* h = new dtts_handle();
+        h->m.reset(new Model(*cfg, device));
+        *out = h;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return -2;
+    }
+    return 0;
+}
+
+int dtts_destroy(dtts_handle* h) {
+    delete h;
+    return 0;
+}
+
+const char* dtts_last_error(dtts_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dtts_bind_weights(dtts_handle* h, const void* blob, size_t nbytes, const char* const* names, const unsigned long long* offsets,
+                      const unsigned long long* numels, int n, void* stream) {
+    DTTS_API_BEGIN
+    h->m->bind_weights(blob, nbytes, names, offsets, numels, n, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_diff_conditioning(dtts_handle* h, const float* refer, const int* lens, int B, int Tmax, float* cond_out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->diff_conditioning(refer, lens, B, Tmax, cond_out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_diff_timestep_independent(dtts_handle* h, const float* latent_cm, const int* lens_n, int B, int nmax, const float* cond,
+                                   float* code_emb, void* stream) {
+    DTTS_API_BEGIN
+    h->m->diff_timestep_independent(latent_cm, lens_n, B, nmax, cond, code_emb, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_diff_forward(dtts_handle* h, const float* x, const float* code_emb, const int* lens, int B, int T, int step,
+                      int cond_free, float* out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->diff_forward(x, code_emb, lens, B, T, step, cond_free, out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_diff_sample(dtts_handle* h, const float* code_emb, const int* lens, int B, int T, unsigned long long seed,
+                     const int* sample_ids, int n_steps, const float* x_init, const float* step_noise, float* mel_out, int denorm,
+                     void* stream) {
+    DTTS_API_BEGIN
+    h->m->diff_sample(code_emb, lens, B, T, seed, sample_ids, n_steps, x_init, step_noise, mel_out, denorm, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T, float* y,
+                            void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_attention_block(prefix, x, lens, B, C, T, y, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_resblock(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int T, int step, float* y,
+                     void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_resblock(prefix, x, lens, B, T, step, y, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_conv1d(dtts_handle* h, const char* name, const float* x, const int* lens_in, int B, int Cin, int Tin, int Cout, int KW,
+                   int stride, int dil, int pad, int pro_act, int epi_act, int gate, int phases, const float* res, float* y,
+                   int Tout_alloc, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_conv1d(name, x, lens_in, B, Cin, Tin, Cout, KW, stride, dil, pad, pro_act, epi_act, gate, phases, res, y, Tout_alloc,
+                    (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_philox_normal(dtts_handle* h, float* out, int n, int B, unsigned long long seed, const int* sample_ids, int stage,
+                          int step, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_philox_normal(out, n, B, seed, sample_ids, stage, step, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Common definitions for libdetail_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace dtts {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define DTTS_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            throw ::dtts::Error(-2, std::string(#expr) + " failed: " + hipGetErrorString(_e) + \
+                                        " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+
+#define DTTS_REQUIRE(cond, msg)                                                      \
+    do {                                                                             \
+        if (!(cond))                                                                 \
+            throw ::dtts::Error(-1, std::string("invalid argument: ") + (msg) +      \
+                                        " [" #cond "] at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// noise streams of the Philox spec (oracle/philox.py)
+enum NoiseStage : int { STAGE_GPT_SAMPLE = 1, STAGE_DIFF_INIT = 2, STAGE_DIFF_STEP = 3, STAGE_FLOW_PRIOR = 4 };
+
+// activation ids shared by prologues / epilogues
+enum Act : int {
+    ACT_NONE = 0,
+    ACT_SILU = 1,
+    ACT_LRELU = 2,     // slope given separately
+    ACT_RELU = 3,
+    ACT_GELU_NEW = 4,
+    ACT_TANH = 5,
+    ACT_MISH = 6,
+};
+
+// epilogue pairing modes: packed weight rows (2r, 2r+1) hold the two halves of a gated pair
+enum Gate : int {
+    GATE_NONE = 0,
+    GATE_TANH_SIGMOID = 1,   // tanh(a_r) * sigmoid(b_r)            (WN, modules.py:15-22)
+    GATE_GLU = 2,            // a_r * sigmoid(b_r)                   (Conv1dGLU, modules.py:517-523)
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_LRELU: return v >= 0.f ? v : v * slope;
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU_NEW: {
+            float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+            return 0.5f * v * (1.f + tanhf(u));
+        }
+        case ACT_TANH: return tanhf(v);
+        case ACT_MISH: {
+            float sp = v > 20.f ? v : log1pf(expf(v));
+            return v * tanhf(sp);
+        }
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+}  // namespace dtts

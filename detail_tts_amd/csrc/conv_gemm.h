@@ -1,0 +1,54 @@
+// Conv1d / Linear / ConvTranspose1d as an fp32-MFMA GEMM over [B, C, T] activations.
+//
+//   y[b, co, n] = epi( sum_{tap, ci} Wp[tap][ci][co] * pro(x[b, ci, n*stride + tap*dil - pad]) )
+//
+// Weights are pre-packed by the host (detail_tts_amd/packing.py) K-major:
+//   Wp[(tap * CinP + ci) * CoutP + co], CinP % 16 == 0, CoutP % BM == 0, zero padded,
+// so the kernel never bounds-checks a weight load.
+#pragma once
+#include "common.h"
+
+namespace dtts {
+
+struct ConvParams {
+    // input
+    const float* x = nullptr;
+    long long x_bs = 0;      // batch stride (floats)
+    int x_cs = 0;            // channel stride (floats) == allocated T of the input buffer
+    const int* len_in = nullptr;   // [B] valid input length per sample (null -> Tin)
+    int Tin = 0;
+    // prologue: v = act(a*x + d) with (a,d) = pro_ab[b][ci][0..1]; positions outside [0,len) are 0
+    const float* pro_ab = nullptr;
+    int pro_act = ACT_NONE;
+    float pro_slope = 0.f;
+    // weights
+    const float* w = nullptr;
+    const float* bias = nullptr;   // [CoutP] in packed row order (or null)
+    int Cin = 0, CinP = 0, Cout = 0, CoutP = 0, KW = 1, stride = 1, dil = 1, pad = 0;
+    // per-sample per-row additive term (packed row order), e.g. WN cond_layer slice or Generator.cond(g)
+    const float* badd = nullptr;
+    int badd_bs = 0;
+    // epilogue
+    int gate = GATE_NONE;          // pairs packed rows (2r, 2r+1) -> output channel r
+    int epi_act = ACT_NONE;
+    float epi_slope = 0.f;
+    float out_scale = 1.f;         // applied after act, before residual
+    const float* res = nullptr;    // residual, same indexing as y
+    long long res_bs = 0;
+    int res_cs = 0;
+    float res_scale = 1.f;
+    int res_bmod = 0;              // residual batch index = b % res_bmod (0: b) — shared residual across batch halves
+    int mask_out = 0;              // unused rows/cols are never written; kept for clarity
+    // output
+    float* y = nullptr;
+    long long y_bs = 0;
+    int y_cs = 0;
+    const int* len_out = nullptr;  // [B] valid number of output columns n per sample (null -> Nout)
+    int Nout = 0;                  // number of GEMM columns per sample (max)
+    int phases = 1;                // ConvTranspose: packed row = ph*Cout + co, t_out = n*phases + ph
+    int B = 0;
+};
+
+void launch_conv_gemm(const ConvParams& p, hipStream_t stream);
+
+}  // namespace dtts

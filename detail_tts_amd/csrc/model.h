@@ -1,0 +1,130 @@
+// Host-side runtime of libdetail_hip.so: weight binding, workspace, stage orchestration.
+// Everything here enqueues work on the caller's HIP stream; no hidden synchronisation except
+// workspace growth (hipMalloc) which only happens when a call needs more memory than any before it.
+#pragma once
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "conv_gemm.h"
+#include "ops.h"
+#include "../../include/detail_hip.h"
+
+namespace dtts {
+
+struct PackedConv {
+    const float* w = nullptr;
+    const float* b = nullptr;   // padded to CoutP, packed row order (may be null)
+    int Cin = 0, CinP = 0, Cout = 0, CoutP = 0, KW = 1;
+};
+
+static inline int packed_cout(int cout) { return cout > 64 ? round_up(cout, 128) : (cout > 32 ? 64 : 32); }
+
+struct AttnBlockW {
+    const float *gn_g = nullptr, *gn_b = nullptr, *bias_tab = nullptr;
+    PackedConv qkv, proj;
+    int C = 0, H = 0;
+};
+
+struct ResBlockW {
+    const float *gn1_g = nullptr, *gn1_b = nullptr, *gn2_g = nullptr, *gn2_b = nullptr;
+    PackedConv c1, c2, emb;
+    int index = 0;   // row block in the scale/shift table
+};
+
+struct DiffLayerW {
+    ResBlockW rb;
+    AttnBlockW at;
+};
+
+class Arena {
+public:
+    ~Arena();
+    void ensure(size_t bytes);            // grow (sync + realloc) if needed, then reset
+    void reset() { off_ = 0; }
+    size_t mark() const { return off_; }
+    void rewind(size_t m) { off_ = m; }
+    float* f32(size_t n) { return static_cast<float*>(raw(n * sizeof(float))); }
+    int* i32(size_t n) { return static_cast<int*>(raw(n * sizeof(int))); }
+    void* raw(size_t bytes);
+    size_t capacity() const { return cap_; }
+
+private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, off_ = 0;
+};
+
+class Model {
+public:
+    Model(const dtts_config& cfg, int device);
+    ~Model();
+
+    void bind_weights(const void* blob, size_t nbytes, const char* const* names, const unsigned long long* offsets,
+                      const unsigned long long* numels, int n, hipStream_t stream);
+
+    // ---- stage B
+    void diff_conditioning(const float* refer, const int* lens_host, int B, int Tmax, float* cond_out, hipStream_t s);
+    void diff_timestep_independent(const float* latent_cm, const int* lens_n_host, int B, int nmax, const float* cond,
+                                   float* code_emb, hipStream_t s);
+    void diff_forward(const float* x, const float* code_emb, const int* lens_host, int B, int T, int step, int cond_free,
+                      float* out, hipStream_t s);
+    void diff_sample(const float* code_emb, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
+                     int n_steps, const float* x_init, const float* step_noise, float* mel_out, int denorm, hipStream_t s);
+    // ---- unit ops used by the parity tests
+    void op_attention_block(const char* prefix, const float* x, const int* lens_host, int B, int C, int T, float* y, hipStream_t s);
+    void op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y, hipStream_t s);
+    void op_conv1d(const char* name, const float* x, const int* lens_in_host, int B, int Cin, int Tin, int Cout, int KW, int stride,
+                   int dil, int pad, int pro_act, int epi_act, int gate, int phases, const float* res, float* y, int Tout_alloc,
+                   hipStream_t s);
+    void op_philox_normal(float* out, int n, int B, unsigned long long seed, const int* sample_ids_host, int stage, int step,
+                          hipStream_t s);
+
+    std::string last_error;
+    dtts_config cfg;
+    int device;
+
+private:
+    friend struct Stage;
+    const float* W(const std::string& name, size_t numel) const;
+    const float* Wopt(const std::string& name, size_t numel) const;
+    PackedConv conv(const std::string& name, int Cin, int Cout, int KW, bool bias = true, int cout_p = 0) const;
+    AttnBlockW attn_block(const std::string& prefix, int C, int H) const;
+    ResBlockW res_block(const std::string& prefix, int C, int index) const;
+    void build_diffusion(hipStream_t s);
+
+    const int* upload_ints(const int* host, int n, hipStream_t s);
+
+    // building blocks on [B, C, T] buffers (all lens are device pointers)
+    void run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const;
+    void attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens, int B,
+                         int T, int Ta, hipStream_t s);
+    void res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T, int Ta,
+                       int step, hipStream_t s);
+    void diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, int B, int T, int step, float* out2,
+                           hipStream_t s);
+
+    std::unordered_map<std::string, std::pair<const float*, size_t>> weights_;
+    bool bound_ = false;
+
+    // diffusion
+    std::vector<DiffLayerW> integ_, layers_;
+    std::vector<ResBlockW> tail_;
+    std::vector<AttnBlockW> latcond_, ctx_;
+    PackedConv inp_block_, integ1_, integ2_, out_conv_, latcond0_, ctx0_, ctx1_, te0_, te2_;
+    const float *out_gn_g_ = nullptr, *out_gn_b_ = nullptr, *code_gn_g_ = nullptr, *code_gn_b_ = nullptr, *uncond_ = nullptr;
+    float* ss_table_ = nullptr;      // [n_resblocks][2C][NS]
+    int n_steps_ = 0;
+    std::vector<int> timestep_map_;
+    std::vector<DiffStepCoefs> step_coefs_;
+
+    Arena ws_;        // per-call activations
+    Arena persist_;   // tables built at bind time
+    int* lens_dev_ = nullptr;   // small ring of device int buffers
+    size_t lens_off_ = 0;
+};
+
+}  // namespace dtts

@@ -1,0 +1,723 @@
+// Model runtime: weight lookup, workspace, diffusion-stage orchestration (see model.h).
+#include "model.h"
+
+#include <cmath>
+
+namespace dtts {
+
+// ------------------------------------------------------------------------------------------ Arena
+Arena::~Arena() {
+    if (base_) (void)hipFree(base_);
+}
+
+void Arena::ensure(size_t bytes) {
+    if (bytes > cap_) {
+        DTTS_CHECK_HIP(hipDeviceSynchronize());
+        if (base_) DTTS_CHECK_HIP(hipFree(base_));
+        base_ = nullptr;
+        cap_ = 0;
+        const size_t want = bytes + bytes / 8 + (1u << 20);
+        DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&base_), want));
+        cap_ = want;
+    }
+    off_ = 0;
+}
+
+void* Arena::raw(size_t bytes) {
+    const size_t a = (off_ + 255) & ~size_t(255);
+    if (a + bytes > cap_) throw Error(-3, "workspace arena overflow (internal sizing bug)");
+    off_ = a + bytes;
+    return base_ + a;
+}
+
+// ------------------------------------------------------------------------------------------ Model
+Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) {
+    DTTS_CHECK_HIP(hipSetDevice(dev));
+    DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&lens_dev_), 1 << 16));
+}
+
+Model::~Model() {
+    if (lens_dev_) (void)hipFree(lens_dev_);
+}
+
+const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
+    // small ring buffer; entries stay valid for at least the next ~16K ints of uploads
+    const size_t cap = (1 << 16) / sizeof(int);
+    DTTS_REQUIRE((size_t)n <= cap / 4, "too many ints");
+    if (lens_off_ + n > cap) lens_off_ = 0;
+    int* dst = lens_dev_ + lens_off_;
+    lens_off_ += (size_t)((n + 15) & ~15);
+    DTTS_CHECK_HIP(hipMemcpyAsync(dst, host, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    return dst;
+}
+
+const float* Model::Wopt(const std::string& name, size_t numel) const {
+    auto it = weights_.find(name);
+    if (it == weights_.end()) return nullptr;
+    if (it->second.second != numel)
+        throw Error(-4, "weight '" + name + "': expected " + std::to_string(numel) + " floats, blob has " +
+                            std::to_string(it->second.second));
+    return it->second.first;
+}
+
+const float* Model::W(const std::string& name, size_t numel) const {
+    const float* p = Wopt(name, numel);
+    if (!p) throw Error(-4, "weight '" + name + "' missing from the bound blob");
+    return p;
+}
+
+PackedConv Model::conv(const std::string& name, int Cin, int Cout, int KW, bool bias, int cout_p) const {
+    PackedConv pc;
+    pc.Cin = Cin;
+    pc.CinP = round_up(Cin, 16);
+    pc.Cout = Cout;
+    pc.CoutP = cout_p ? cout_p : packed_cout(Cout);
+    pc.KW = KW;
+    pc.w = W(name + ".wp", (size_t)KW * pc.CinP * pc.CoutP);
+    pc.b = bias ? W(name + ".bp", (size_t)pc.CoutP) : nullptr;
+    return pc;
+}
+
+AttnBlockW Model::attn_block(const std::string& p, int C, int H) const {
+    AttnBlockW a;
+    a.C = C;
+    a.H = H;
+    a.gn_g = W(p + ".norm.weight", C);
+    a.gn_b = W(p + ".norm.bias", C);
+    a.qkv = conv(p + ".qkv", C, 3 * C, 1);
+    a.proj = conv(p + ".proj_out", C, C, 1);
+    a.bias_tab = W(p + ".bias_tab", (size_t)H * 129);
+    return a;
+}
+
+ResBlockW Model::res_block(const std::string& p, int C, int index) const {
+    ResBlockW r;
+    r.index = index;
+    r.gn1_g = W(p + ".in_layers.0.weight", C);
+    r.gn1_b = W(p + ".in_layers.0.bias", C);
+    r.c1 = conv(p + ".in_layers.2", C, C, 1);
+    r.emb = conv(p + ".emb_layers.1", C, 2 * C, 1);
+    r.gn2_g = W(p + ".out_layers.0.weight", C);
+    r.gn2_b = W(p + ".out_layers.0.bias", C);
+    r.c2 = conv(p + ".out_layers.3", C, C, 3);
+    return r;
+}
+
+void Model::bind_weights(const void* blob, size_t nbytes, const char* const* names, const unsigned long long* offsets,
+                         const unsigned long long* numels, int n, hipStream_t stream) {
+    weights_.clear();
+    bound_ = false;
+    for (int i = 0; i < n; ++i) {
+        DTTS_REQUIRE((offsets[i] + numels[i]) * sizeof(float) <= nbytes, "weight table entry outside the blob");
+        DTTS_REQUIRE(offsets[i] % 4 == 0, "weight offsets must be 16-byte aligned");
+        weights_[names[i]] = {static_cast<const float*>(blob) + offsets[i], (size_t)numels[i]};
+    }
+    if (weights_.count("diffusion.inp_block.wp")) build_diffusion(stream);
+    bound_ = true;
+}
+
+void Model::run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const {
+    p.w = pc.w;
+    if (!p.bias) p.bias = pc.b;
+    p.Cin = pc.Cin;
+    p.CinP = pc.CinP;
+    p.Cout = pc.Cout;
+    p.CoutP = pc.CoutP;
+    p.KW = pc.KW;
+    launch_conv_gemm(p, s);
+}
+
+// ---- diffusion schedule (float64 on the host, cast to fp32 on use: vqvae/utils/diffusion.py:179-228, 1181-1195, 1315)
+static void make_schedule(int trained, int steps, float cfk_k, std::vector<int>& tmap, std::vector<DiffStepCoefs>& coefs) {
+    std::vector<double> betas(trained), ac(trained);
+    const double scale = 1000.0 / trained, b0 = scale * 0.0001, b1 = scale * 0.02;
+    double prod = 1.0;
+    for (int i = 0; i < trained; ++i) {
+        betas[i] = trained > 1 ? b0 + (b1 - b0) * (double)i / (double)(trained - 1) : b0;
+        prod *= (1.0 - betas[i]);
+        ac[i] = prod;
+    }
+    // space_timesteps(trained, [steps])  (vqvae/utils/diffusion.py:1223-1272)
+    std::vector<char> use(trained, 0);
+    const double frac = steps <= 1 ? 1.0 : (double)(trained - 1) / (double)(steps - 1);
+    double cur = 0.0;
+    for (int i = 0; i < steps; ++i) {
+        use[(int)std::nearbyint(cur)] = 1;   // Python round(): half to even == nearbyint in the default mode
+        cur += frac;
+    }
+    tmap.clear();
+    std::vector<double> nb;
+    double last = 1.0;
+    for (int i = 0; i < trained; ++i)
+        if (use[i]) {
+            nb.push_back(1.0 - ac[i] / last);
+            last = ac[i];
+            tmap.push_back(i);
+        }
+    const int n = (int)nb.size();
+    std::vector<double> acp(n), acp_prev(n), post_var(n);
+    prod = 1.0;
+    for (int i = 0; i < n; ++i) {
+        acp_prev[i] = prod;
+        prod *= (1.0 - nb[i]);
+        acp[i] = prod;
+    }
+    for (int i = 0; i < n; ++i) post_var[i] = nb[i] * (1.0 - acp_prev[i]) / (1.0 - acp[i]);
+    coefs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        DiffStepCoefs k;
+        k.sqrt_recip_ac = (float)std::sqrt(1.0 / acp[i]);
+        k.sqrt_recipm1_ac = (float)std::sqrt(1.0 / acp[i] - 1.0);
+        k.coef1 = (float)(nb[i] * std::sqrt(acp_prev[i]) / (1.0 - acp[i]));
+        k.coef2 = (float)((1.0 - acp_prev[i]) * std::sqrt(1.0 - nb[i]) / (1.0 - acp[i]));
+        k.min_log = (float)std::log(i == 0 ? post_var[1] : post_var[i]);
+        k.max_log = (float)std::log(nb[i]);
+        k.cfk = (float)(cfk_k * (1.0 - (double)i / (double)n));
+        k.nonzero = i != 0;
+        coefs[i] = k;
+    }
+}
+
+void Model::build_diffusion(hipStream_t s) {
+    const int C = cfg.diff_channels, H = cfg.diff_heads, NL = cfg.diff_layers;
+    const std::string d = "diffusion.";
+    integ_.clear();
+    layers_.clear();
+    tail_.clear();
+    latcond_.clear();
+    ctx_.clear();
+    int rbi = 0;
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = d + "conditioning_timestep_integrator." + std::to_string(i);
+        integ_.push_back({res_block(p + ".resblk", C, rbi++), attn_block(p + ".attn", C, H)});
+    }
+    for (int i = 0; i < NL; ++i) {
+        const std::string p = d + "layers." + std::to_string(i);
+        layers_.push_back({res_block(p + ".resblk", C, rbi++), attn_block(p + ".attn", C, H)});
+    }
+    for (int i = NL; i < NL + 3; ++i) tail_.push_back(res_block(d + "layers." + std::to_string(i), C, rbi++));
+    inp_block_ = conv(d + "inp_block", cfg.mel_channels, C, 3);
+    integ1_ = conv(d + "integrating_conv.a", C, C, 1);           // columns 0..C-1 of the 1x1 (x path) + bias
+    integ2_ = conv(d + "integrating_conv.b", C, C, 1, false);    // columns C..2C-1 (code path)
+    out_gn_g_ = W(d + "out.0.weight", C);
+    out_gn_b_ = W(d + "out.0.bias", C);
+    out_conv_ = conv(d + "out.2", C, cfg.diff_out_channels, 3);
+    code_gn_g_ = W(d + "code_norm.weight", C);
+    code_gn_b_ = W(d + "code_norm.bias", C);
+    uncond_ = W(d + "unconditioned_embedding", C);
+    latcond0_ = conv(d + "latent_conditioner.0", C, C, 3);
+    for (int i = 1; i < 5; ++i) latcond_.push_back(attn_block(d + "latent_conditioner." + std::to_string(i), C, H));
+    ctx0_ = conv(d + "contextual_embedder.0", cfg.mel_channels, C, 3);
+    ctx1_ = conv(d + "contextual_embedder.1", C, 2 * C, 3);
+    for (int i = 2; i < 7; ++i) ctx_.push_back(attn_block(d + "contextual_embedder." + std::to_string(i), 2 * C, H));
+    te0_ = conv(d + "time_embed.0", C, C, 1);
+    te2_ = conv(d + "time_embed.2", C, C, 1);
+
+    make_schedule(cfg.diff_trained_steps, cfg.diff_steps, cfg.cond_free_k, timestep_map_, step_coefs_);
+    n_steps_ = (int)timestep_map_.size();
+
+    // ---- timestep tables on the device: t_emb = time_embed(sinusoid(ts)) for every sampling step, then
+    // every ResBlock's emb_layers (SiLU -> Linear) -> ss_table[rb][2C][NS]   (vqvae/diff_model.py:294, 108)
+    const int NS = n_steps_, NRB = rbi;
+    persist_.ensure(sizeof(float) * ((size_t)NRB * 2 * C * NS + 3 * (size_t)C * NS) + sizeof(int) * NS + 4096);
+    ss_table_ = persist_.f32((size_t)NRB * 2 * C * NS);
+    float* sinus = persist_.f32((size_t)C * NS);
+    float* t1 = persist_.f32((size_t)C * NS);
+    float* temb = persist_.f32((size_t)C * NS);
+    int* ts_dev = persist_.i32(NS);
+    DTTS_CHECK_HIP(hipMemcpyAsync(ts_dev, timestep_map_.data(), sizeof(int) * NS, hipMemcpyHostToDevice, s));
+    launch_timestep_sinusoid(ts_dev, NS, C, sinus, s);
+    ConvParams p;
+    p.B = 1;
+    p.Tin = NS;
+    p.Nout = NS;
+    p.x_cs = NS;
+    p.y_cs = NS;
+    p.x = sinus;
+    p.y = t1;
+    p.epi_act = ACT_SILU;
+    run_conv(te0_, p, s);
+    p.x = t1;
+    p.y = temb;
+    p.epi_act = ACT_NONE;
+    run_conv(te2_, p, s);
+    auto emb_of = [&](const ResBlockW& rb) {
+        ConvParams q;
+        q.B = 1;
+        q.Tin = NS;
+        q.Nout = NS;
+        q.x_cs = NS;
+        q.y_cs = NS;
+        q.x = temb;
+        q.pro_act = ACT_SILU;
+        q.y = ss_table_ + (size_t)rb.index * 2 * C * NS;
+        run_conv(rb.emb, q, s);
+    };
+    for (auto& l : integ_) emb_of(l.rb);
+    for (auto& l : layers_) emb_of(l.rb);
+    for (auto& r : tail_) emb_of(r);
+}
+
+// ------------------------------------------------------------------------------ building blocks
+// AttentionBlock (vqvae/utils/diff_util.py:209-215): y = x + proj(attn(qkv(GN(x))))
+void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens,
+                            int B, int T, int Ta, hipStream_t s) {
+    const int C = w.C, D = C / w.H;
+    const long long bs = (long long)C * Ta;
+    int groups = 32;
+    while (C % groups) groups /= 2;
+    launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ab, s);
+    ConvParams p;
+    p.B = B;
+    p.Tin = T;
+    p.Nout = T;
+    p.len_in = lens;
+    p.len_out = lens;
+    p.x = x;
+    p.x_bs = bs;
+    p.x_cs = Ta;
+    p.pro_ab = ab;
+    p.y = qkv;
+    p.y_bs = 3 * bs;
+    p.y_cs = Ta;
+    run_conv(w.qkv, p, s);
+    AttnParams a;
+    a.qkv = qkv;
+    a.bs = 3 * bs;
+    a.cs = Ta;
+    a.q_off = 0;
+    a.k_off = D;
+    a.v_off = 2 * D;
+    a.head_stride = 3 * D;
+    a.out = att;
+    a.o_bs = bs;
+    a.o_cs = Ta;
+    a.lens = lens;
+    a.T = T;
+    a.B = B;
+    a.H = w.H;
+    a.D = D;
+    a.scale = 1.f / std::sqrt((float)D);
+    a.bias_tab = w.bias_tab;
+    launch_flash_attention(a, s);
+    ConvParams q;
+    q.B = B;
+    q.Tin = T;
+    q.Nout = T;
+    q.len_in = lens;
+    q.len_out = lens;
+    q.x = att;
+    q.x_bs = bs;
+    q.x_cs = Ta;
+    q.y = y;
+    q.y_bs = bs;
+    q.y_cs = Ta;
+    q.res = x;
+    q.res_bs = bs;
+    q.res_cs = Ta;
+    run_conv(w.proj, q, s);
+}
+
+// diffusion ResBlock (vqvae/diff_model.py:106-119): y = x + conv3(SiLU(AdaGN(conv1(SiLU(GN(x))))))
+void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T,
+                          int Ta, int step, hipStream_t s) {
+    const int C = cfg.diff_channels;
+    const long long bs = (long long)C * Ta;
+    int groups = 32;
+    while (C % groups) groups /= 2;
+    launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ab, s);
+    ConvParams p;
+    p.B = B;
+    p.Tin = T;
+    p.Nout = T;
+    p.len_in = lens;
+    p.len_out = lens;
+    p.x = x;
+    p.x_bs = bs;
+    p.x_cs = Ta;
+    p.pro_ab = ab;
+    p.pro_act = ACT_SILU;
+    p.y = h1;
+    p.y_bs = bs;
+    p.y_cs = Ta;
+    run_conv(w.c1, p, s);
+    const float* ada = ss_table_ + (size_t)w.index * 2 * C * n_steps_ + step;
+    launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s);
+    ConvParams q = p;
+    q.x = h1;
+    q.pad = 1;
+    q.y = y;
+    q.res = x;
+    q.res_bs = bs;
+    q.res_cs = Ta;
+    run_conv(w.c2, q, s);
+}
+
+// One batched (cond | uncond) DiffusionTts.forward: x [B,128,T]; cbuf0 [2B,768,T] = (code_emb | uncond broadcast);
+// out2 [2B,256,T].  lens2 = device lens repeated twice.
+void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, int B, int T, int step, float* out2,
+                              hipStream_t s) {
+    const int C = cfg.diff_channels, B2 = 2 * B, Ta = T;
+    const size_t act = (size_t)B2 * C * Ta;
+    float* bufA = ws_.f32(act);
+    float* bufB = ws_.f32(act);
+    float* bufC = ws_.f32(act);
+    float* qkv = ws_.f32(3 * act);
+    float* ab = ws_.f32((size_t)B2 * C * 2);
+    const long long bs = (long long)C * Ta;
+
+    auto dlayer = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp) {
+        res_block_fwd(l.rb, in, tmp, mid, ab, lens2, B2, T, Ta, step, s);
+        attention_block(l.at, mid, outp, qkv, tmp, ab, lens2, B2, T, Ta, s);
+    };
+    // conditioning_timestep_integrator on the code embeddings (vqvae/diff_model.py:295)
+    dlayer(integ_[0], cbuf0, bufB, bufC, bufA);
+    dlayer(integ_[1], bufA, bufB, bufC, bufA);
+    dlayer(integ_[2], bufA, bufB, bufC, bufA);          // bufA = code path
+    // inp_block + integrating_conv on cat([x, code]) (:296-298) as two accumulating 1x1 GEMMs
+    ConvParams p;
+    p.B = B;
+    p.Tin = T;
+    p.Nout = T;
+    p.len_in = lens2;
+    p.len_out = lens2;
+    p.x = x;
+    p.x_bs = (long long)cfg.mel_channels * T;
+    p.x_cs = T;
+    p.pad = 1;
+    p.y = bufB;                                          // [B,768,T] (first half only)
+    p.y_bs = bs;
+    p.y_cs = Ta;
+    run_conv(inp_block_, p, s);
+    ConvParams q;
+    q.B = B;
+    q.Tin = T;
+    q.Nout = T;
+    q.len_in = lens2;
+    q.len_out = lens2;
+    q.x = bufB;
+    q.x_bs = bs;
+    q.x_cs = Ta;
+    q.y = bufC;                                          // x-path contribution + bias, B samples
+    q.y_bs = bs;
+    q.y_cs = Ta;
+    run_conv(integ1_, q, s);
+    ConvParams r;
+    r.B = B2;
+    r.Tin = T;
+    r.Nout = T;
+    r.len_in = lens2;
+    r.len_out = lens2;
+    r.x = bufA;
+    r.x_bs = bs;
+    r.x_cs = Ta;
+    r.y = bufB;
+    r.y_bs = bs;
+    r.y_cs = Ta;
+    r.res = bufC;
+    r.res_bs = bs;
+    r.res_cs = Ta;
+    r.res_bmod = B;                                      // both halves share the x-path term
+    run_conv(integ2_, r, s);
+    // main stack (:299-309)
+    float* cur = bufB;
+    float* t1 = bufA;
+    float* t2 = bufC;
+    for (auto& l : layers_) dlayer(l, cur, t1, t2, cur);   // output back into `cur` (x is dead after the residual add)
+    for (auto& rb : tail_) {
+        res_block_fwd(rb, cur, t1, t2, ab, lens2, B2, T, Ta, step, s);
+        std::swap(cur, t2);
+    }
+    // out: GN, SiLU, conv k3 (:312)
+    int groups = 32;
+    while (C % groups) groups /= 2;
+    launch_gn_coeffs(cur, bs, Ta, lens2, T, B2, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, s);
+    ConvParams o;
+    o.B = B2;
+    o.Tin = T;
+    o.Nout = T;
+    o.len_in = lens2;
+    o.len_out = lens2;
+    o.x = cur;
+    o.x_bs = bs;
+    o.x_cs = Ta;
+    o.pro_ab = ab;
+    o.pro_act = ACT_SILU;
+    o.pad = 1;
+    o.y = out2;
+    o.y_bs = (long long)cfg.diff_out_channels * T;
+    o.y_cs = T;
+    run_conv(out_conv_, o, s);
+}
+
+static size_t pair_ws_bytes(int B, int C, int T) {
+    const size_t act = (size_t)2 * B * C * T;
+    return sizeof(float) * (6 * act + (size_t)4 * B * C) + 8 * 256;
+}
+
+// ------------------------------------------------------------------------------ stage entry points
+void Model::diff_forward(const float* x, const float* code_emb, const int* lens_host, int B, int T, int step, int cond_free,
+                         float* out, hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
+    const int C = cfg.diff_channels, OC = cfg.diff_out_channels;
+    ws_.ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 4096);
+    std::vector<int> l2(2 * B);
+    for (int i = 0; i < B; ++i) l2[i] = l2[B + i] = lens_host ? lens_host[i] : T;
+    const int* lens2 = upload_ints(l2.data(), 2 * B, s);
+    float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
+    float* out2 = ws_.f32((size_t)2 * B * OC * T);
+    const size_t half = (size_t)B * C * T;
+    if (code_emb)
+        DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
+    else
+        launch_broadcast_channels(uncond_, B, C, T, cbuf0, (long long)C * T, T, s);
+    launch_broadcast_channels(uncond_, B, C, T, cbuf0 + half, (long long)C * T, T, s);
+    diff_forward_pair(x, cbuf0, lens2, B, T, step, out2, s);
+    const float* src = out2 + (cond_free ? (size_t)B * OC * T : 0);
+    DTTS_CHECK_HIP(hipMemcpyAsync(out, src, sizeof(float) * (size_t)B * OC * T, hipMemcpyDeviceToDevice, s));
+}
+
+void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int T, unsigned long long seed,
+                        const int* sample_ids_host, int n_steps, const float* x_init, const float* step_noise, float* mel_out,
+                        int denorm, hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    const int C = cfg.diff_channels, OC = cfg.diff_out_channels, MC = cfg.mel_channels;
+    if (n_steps <= 0 || n_steps > n_steps_) n_steps = n_steps_;
+    const size_t per_call = pair_ws_bytes(B, C, T);
+    ws_.ensure(per_call + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
+    std::vector<int> l2(2 * B);
+    for (int i = 0; i < B; ++i) l2[i] = l2[B + i] = lens_host ? lens_host[i] : T;
+    const int* lens2 = upload_ints(l2.data(), 2 * B, s);
+    const int* sids = upload_ints(sample_ids_host, B, s);
+    float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
+    float* out2 = ws_.f32((size_t)2 * B * OC * T);
+    const size_t half = (size_t)B * C * T;
+    DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
+    launch_broadcast_channels(uncond_, B, C, T, cbuf0 + half, (long long)C * T, T, s);
+    // x_T  (vqvae/model_24k.py:488); per-sample noise is indexed over the sample's own [128, len]
+    float* x = mel_out;
+    const long long xbs = (long long)MC * T;
+    if (x_init) {
+        DTTS_CHECK_HIP(hipMemcpyAsync(x, x_init, sizeof(float) * (size_t)B * MC * T, hipMemcpyDeviceToDevice, s));
+    } else {
+        DTTS_CHECK_HIP(hipMemsetAsync(x, 0, sizeof(float) * (size_t)B * MC * T, s));
+        // generate per sample with its own length so that element order == reference tensor order
+        for (int b = 0; b < B; ++b) {
+            const int len = lens_host ? lens_host[b] : T;
+            if (len == T) {
+                launch_philox_normal(x + (size_t)b * xbs, xbs, MC * T, 1, seed, sids + b, STAGE_DIFF_INIT, 0, 1.f, s);
+            } else {
+                // compact [128, len] then scatter rows into the padded buffer
+                float* tmp = out2;   // free until the first forward
+                launch_philox_normal(tmp, 0, MC * len, 1, seed, sids + b, STAGE_DIFF_INIT, 0, 1.f, s);
+                DTTS_CHECK_HIP(hipMemcpy2DAsync(x + (size_t)b * xbs, sizeof(float) * T, tmp, sizeof(float) * len,
+                                                sizeof(float) * len, MC, hipMemcpyDeviceToDevice, s));
+            }
+        }
+    }
+    const size_t mark = ws_.mark();
+    for (int k = 0; k < n_steps; ++k) {
+        const int i = n_steps_ - 1 - k;
+        ws_.rewind(mark);                              // the forward's scratch is re-carved every step
+        diff_forward_pair(x, cbuf0, lens2, B, T, i, out2, s);
+        const bool last = (k == n_steps - 1);
+        launch_diff_update(x, xbs, T, out2, (long long)OC * T, T, lens2, T, B, MC, step_coefs_[i], seed, sids, i,
+                           step_noise ? step_noise + (size_t)k * B * MC * T : nullptr, (denorm && last) ? 1 : 0, s);
+    }
+}
+
+void Model::diff_conditioning(const float* refer, const int* lens_host, int B, int Tmax, float* cond_out, hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    const int C = cfg.diff_channels, C2 = 2 * C;
+    const int T1 = (Tmax - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1;
+    std::vector<int> l0(B), l1(B), l2(B);
+    for (int b = 0; b < B; ++b) {
+        l0[b] = lens_host ? lens_host[b] : Tmax;
+        l1[b] = (l0[b] - 1) / 2 + 1;
+        l2[b] = (l1[b] - 1) / 2 + 1;
+    }
+    const size_t act = (size_t)B * C2 * T2;
+    ws_.ensure(sizeof(float) * ((size_t)B * C * T1 + 3 * act + 3 * act + (size_t)2 * B * C2) + 8192);
+    const int* d0 = upload_ints(l0.data(), B, s);
+    const int* d1 = upload_ints(l1.data(), B, s);
+    const int* d2 = upload_ints(l2.data(), B, s);
+    float* h1 = ws_.f32((size_t)B * C * T1);
+    float* a = ws_.f32(act);
+    float* bb = ws_.f32(act);
+    float* att = ws_.f32(act);
+    float* qkv = ws_.f32(3 * act);
+    float* ab = ws_.f32((size_t)2 * B * C2);
+    ConvParams p;
+    p.B = B;
+    p.Tin = Tmax;
+    p.Nout = T1;
+    p.len_in = d0;
+    p.len_out = d1;
+    p.x = refer;
+    p.x_bs = (long long)cfg.mel_channels * Tmax;
+    p.x_cs = Tmax;
+    p.stride = 2;
+    p.pad = 1;
+    p.y = h1;
+    p.y_bs = (long long)C * T1;
+    p.y_cs = T1;
+    run_conv(ctx0_, p, s);
+    ConvParams q;
+    q.B = B;
+    q.Tin = T1;
+    q.Nout = T2;
+    q.len_in = d1;
+    q.len_out = d2;
+    q.x = h1;
+    q.x_bs = (long long)C * T1;
+    q.x_cs = T1;
+    q.stride = 2;
+    q.pad = 1;
+    q.y = a;
+    q.y_bs = (long long)C2 * T2;
+    q.y_cs = T2;
+    run_conv(ctx1_, q, s);
+    float* cur = a;
+    float* nxt = bb;
+    for (auto& blk : ctx_) {
+        attention_block(blk, cur, nxt, qkv, att, ab, d2, B, T2, T2, s);
+        std::swap(cur, nxt);
+    }
+    launch_mean_time(cur, (long long)C2 * T2, T2, d2, T2, B, C2, cond_out, s);
+}
+
+void Model::diff_timestep_independent(const float* latent_cm, const int* lens_n_host, int B, int nmax, const float* cond,
+                                      float* code_emb, hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    const int C = cfg.diff_channels;
+    const size_t act = (size_t)B * C * nmax;
+    ws_.ensure(sizeof(float) * (3 * act + 3 * act + (size_t)2 * B * C) + 8192);
+    std::vector<int> ln(B);
+    for (int b = 0; b < B; ++b) ln[b] = lens_n_host ? lens_n_host[b] : nmax;
+    const int* dl = upload_ints(ln.data(), B, s);
+    float* a = ws_.f32(act);
+    float* bb = ws_.f32(act);
+    float* att = ws_.f32(act);
+    float* qkv = ws_.f32(3 * act);
+    float* ab = ws_.f32((size_t)2 * B * C);
+    const long long bs = (long long)C * nmax;
+    ConvParams p;
+    p.B = B;
+    p.Tin = nmax;
+    p.Nout = nmax;
+    p.len_in = dl;
+    p.len_out = dl;
+    p.x = latent_cm;
+    p.x_bs = bs;
+    p.x_cs = nmax;
+    p.pad = 1;
+    p.y = a;
+    p.y_bs = bs;
+    p.y_cs = nmax;
+    run_conv(latcond0_, p, s);
+    float* cur = a;
+    float* nxt = bb;
+    for (auto& blk : latcond_) {
+        attention_block(blk, cur, nxt, qkv, att, ab, dl, B, nmax, nmax, s);
+        std::swap(cur, nxt);
+    }
+    int groups = 32;
+    while (C % groups) groups /= 2;
+    // code_norm(code_emb) * (1 + cond_scale) + cond_shift  (vqvae/diff_model.py:236, 242), then nearest x4 (:252)
+    launch_gn_coeffs(cur, bs, nmax, dl, nmax, B, C, groups, code_gn_g_, code_gn_b_, 1e-5f, cond, 1, 2 * C, ab, s);
+    launch_affine_apply(cur, bs, nmax, ab, dl, nmax, B, C, 4, ACT_NONE, code_emb, (long long)C * 4 * nmax, 4 * nmax, s);
+}
+
+void Model::op_attention_block(const char* prefix, const float* x, const int* lens_host, int B, int C, int T, float* y,
+                               hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    AttnBlockW w = attn_block(prefix, C, cfg.diff_heads);
+    const size_t act = (size_t)B * C * T;
+    ws_.ensure(sizeof(float) * (4 * act + (size_t)2 * B * C) + 8192);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    float* qkv = ws_.f32(3 * act);
+    float* att = ws_.f32(act);
+    float* ab = ws_.f32((size_t)2 * B * C);
+    attention_block(w, x, y, qkv, att, ab, dl, B, T, T, s);
+}
+
+void Model::op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y,
+                        hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
+    const int C = cfg.diff_channels;
+    const ResBlockW* found = nullptr;
+    const std::string pf(prefix);
+    auto check = [&](const ResBlockW& r, const std::string& name) {
+        if (name == pf) found = &r;
+    };
+    for (size_t i = 0; i < integ_.size(); ++i) check(integ_[i].rb, "diffusion.conditioning_timestep_integrator." + std::to_string(i) + ".resblk");
+    for (size_t i = 0; i < layers_.size(); ++i) check(layers_[i].rb, "diffusion.layers." + std::to_string(i) + ".resblk");
+    for (size_t i = 0; i < tail_.size(); ++i) check(tail_[i], "diffusion.layers." + std::to_string(layers_.size() + i));
+    DTTS_REQUIRE(found, "unknown resblock prefix");
+    const size_t act = (size_t)B * C * T;
+    ws_.ensure(sizeof(float) * (act + (size_t)2 * B * C) + 8192);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    float* h1 = ws_.f32(act);
+    float* ab = ws_.f32((size_t)2 * B * C);
+    res_block_fwd(*found, x, h1, y, ab, dl, B, T, T, step, s);
+}
+
+// Generic conv entry for parity tests.  In phases mode (ConvTranspose1d) Cout is the real channel count per phase,
+// the packed weight holds phases*Cout rows and KW/pad describe the equivalent correlation (see packing.py).
+void Model::op_conv1d(const char* name, const float* x, const int* lens_in_host, int B, int Cin, int Tin, int Cout, int KW,
+                      int stride, int dil, int pad, int pro_act, int epi_act, int gate, int phases, const float* res, float* y,
+                      int Tout_alloc, hipStream_t s) {
+    DTTS_REQUIRE(!weights_.empty(), "weights not bound");
+    const int rows = Cout * (phases > 1 ? phases : 1);
+    PackedConv pc = conv(name, Cin, rows, KW, Wopt(std::string(name) + ".bp", (size_t)packed_cout(rows)) != nullptr);
+    const int Nout = (Tin + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    std::vector<int> li(B), lo(B);
+    for (int b = 0; b < B; ++b) {
+        li[b] = lens_in_host ? lens_in_host[b] : Tin;
+        lo[b] = (li[b] + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    }
+    const int* dli = upload_ints(li.data(), B, s);
+    const int* dlo = upload_ints(lo.data(), B, s);
+    const int cout_real = gate ? Cout / 2 : Cout;
+    ConvParams p;
+    p.B = B;
+    p.Tin = Tin;
+    p.Nout = Nout;
+    p.len_in = dli;
+    p.len_out = dlo;
+    p.x = x;
+    p.x_bs = (long long)Cin * Tin;
+    p.x_cs = Tin;
+    p.stride = stride;
+    p.dil = dil;
+    p.pad = pad;
+    p.pro_act = pro_act;
+    p.pro_slope = 0.1f;
+    p.epi_act = epi_act;
+    p.epi_slope = 0.1f;
+    p.gate = gate;
+    p.phases = phases > 1 ? phases : 1;
+    p.y = y;
+    p.y_bs = (long long)cout_real * Tout_alloc;
+    p.y_cs = Tout_alloc;
+    if (res) {
+        p.res = res;
+        p.res_bs = p.y_bs;
+        p.res_cs = Tout_alloc;
+    }
+    run_conv(pc, p, s);
+}
+
+void Model::op_philox_normal(float* out, int n, int B, unsigned long long seed, const int* sample_ids_host, int stage, int step,
+                             hipStream_t s) {
+    const int* sids = upload_ints(sample_ids_host, B, s);
+    launch_philox_normal(out, n, n, B, seed, sids, stage, step, 1.f, s);
+}
+
+}  // namespace dtts

@@ -1,0 +1,191 @@
+"""Weight packer: folded reference tensors -> kernel-ready blob for libdetail_hip.so.
+
+Layouts (must match detail_tts_amd/csrc/conv_gemm.h and model.hip):
+  * every Conv1d / Linear / HF Conv1D becomes a K-major GEMM operand
+        wp[tap][ci][co]  (shape [KW, CinP, CoutP], CinP = ceil16(Cin), CoutP = packed_cout(rows), zero padded)
+    and a bias `bp[CoutP]` in packed row order;
+  * gated convs (WN in_layers: tanh/sigmoid halves, Conv1dGLU) interleave their output rows so that
+    packed rows (2r, 2r+1) = (a_r, b_r) land in adjacent MFMA accumulator registers;
+  * ConvTranspose1d(k, s, p) becomes a `phases = s` correlation: packed row = ph*Cout + co,
+        y[co, q*s + ph] = sum_d sum_ci x[ci, q + d] * w[ci, co, ph + p - d*s],   d in [dmin, dmax]
+    stored as taps d - dmin with `pad = -dmin`;
+  * AttentionBlock relative-position bias (vqvae/utils/xtransformers.py:146-186) becomes a per-head table over
+    clamp(s - t, -64, 64): bias_tab[h][off + 64] = emb[bucket(off)][h] * sqrt(head_dim).
+
+These are weight-only transforms done once at load time on the host (like folding weight-norm).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from .config import load_config
+
+F32 = np.float32
+
+
+def ceil_to(a, m):
+    return (a + m - 1) // m * m
+
+
+def packed_cout(rows):
+    return ceil_to(rows, 128) if rows > 64 else (64 if rows > 32 else 32)
+
+
+def pack_conv(w, b=None, row_perm=None):
+    """w [Cout, Cin, k] (torch Conv1d layout) -> (wp [k, CinP, CoutP], bp [CoutP] | None)."""
+    w = np.asarray(w, F32)
+    if w.ndim == 2:
+        w = w[:, :, None]
+    if row_perm is not None:
+        w = w[row_perm]
+        if b is not None:
+            b = np.asarray(b, F32)[row_perm]
+    cout, cin, k = w.shape
+    cinp, coutp = ceil_to(cin, 16), packed_cout(cout)
+    wp = np.zeros((k, cinp, coutp), F32)
+    wp[:, :cin, :cout] = w.transpose(2, 1, 0)
+    bp = None
+    if b is not None:
+        bp = np.zeros((coutp,), F32)
+        bp[:cout] = b
+    return wp, bp
+
+
+def gate_perm(n_rows):
+    """[a_0..a_{h-1}, b_0..b_{h-1}] -> [a_0, b_0, a_1, b_1, ...]"""
+    h = n_rows // 2
+    perm = np.empty(n_rows, np.int64)
+    perm[0::2] = np.arange(h)
+    perm[1::2] = h + np.arange(h)
+    return perm
+
+
+def convtranspose_as_phases(w, stride, padding):
+    """w [Cin, Cout, k] -> (w_eq [stride*Cout, Cin, KW], pad) for the phase decomposition."""
+    w = np.asarray(w, F32)
+    cin, cout, k = w.shape
+    dmin = -((k - 1 - padding) // stride)           # ceil((p-k+1)/s)
+    dmax = (stride - 1 + padding) // stride
+    kw = dmax - dmin + 1
+    weq = np.zeros((stride * cout, cin, kw), F32)
+    for ph in range(stride):
+        for d in range(dmin, dmax + 1):
+            j = ph + padding - d * stride
+            if 0 <= j < k:
+                weq[ph * cout:(ph + 1) * cout, :, d - dmin] = w[:, :, j].T
+    return weq, -dmin
+
+
+def rel_bucket(rel, num_buckets=32, max_distance=64):
+    """RelativePositionBias._relative_position_bucket(causal=False); float32 log like torch."""
+    rel = np.asarray(rel, np.int64)
+    n = -rel
+    nb = num_buckets // 2
+    ret = (n < 0).astype(np.int64) * nb
+    n = np.abs(n)
+    max_exact = nb // 2
+    is_small = n < max_exact
+    with np.errstate(divide="ignore"):
+        val = np.log(n.astype(F32) / F32(max_exact)) / F32(math.log(max_distance / max_exact)) * F32(nb - max_exact)
+    val_large = np.minimum(max_exact + np.where(is_small, 0, val).astype(np.int64), nb - 1)
+    return ret + np.where(is_small, n, val_large)
+
+
+def bias_table(emb, head_dim, clip=64):
+    """emb [32, H] -> [H, 2*clip+1] over offsets s - t in [-clip, clip] (beyond: same bucket)."""
+    off = np.arange(-clip, clip + 1)
+    b = rel_bucket(off)
+    assert rel_bucket(np.array([clip]))[0] == rel_bucket(np.array([10 ** 6]))[0]
+    assert rel_bucket(np.array([-clip]))[0] == rel_bucket(np.array([-10 ** 6]))[0]
+    return np.ascontiguousarray((emb[b] * F32(math.sqrt(head_dim))).T, F32)
+
+
+class Packer:
+    def __init__(self):
+        self.entries: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def add(self, name, arr):
+        assert name not in self.entries, name
+        self.entries[name] = np.ascontiguousarray(arr, F32)
+
+    def conv(self, name, w, b=None, row_perm=None, out_name=None):
+        wp, bp = pack_conv(w, b, row_perm)
+        out_name = out_name or name
+        self.add(out_name + ".wp", wp)
+        if bp is not None:
+            self.add(out_name + ".bp", bp)
+
+    def blob(self):
+        """-> (flat fp32 array, names, offsets, numels); every tensor 64-byte aligned."""
+        names, offsets, numels, total = [], [], [], 0
+        for k, v in self.entries.items():
+            names.append(k)
+            offsets.append(total)
+            numels.append(v.size)
+            total += ceil_to(v.size, 16)
+        flat = np.zeros(total, F32)
+        for k, o, n in zip(names, offsets, numels):
+            flat[o:o + n] = self.entries[k].reshape(-1)
+        return flat, names, np.array(offsets, np.uint64), np.array(numels, np.uint64)
+
+
+def _attention_block(pk, P, p, ch, heads):
+    pk.add(p + ".norm.weight", P[p + ".norm.weight"])
+    pk.add(p + ".norm.bias", P[p + ".norm.bias"])
+    pk.conv(p + ".qkv", P[p + ".qkv.weight"], P[p + ".qkv.bias"])
+    pk.conv(p + ".proj_out", P[p + ".proj_out.weight"], P[p + ".proj_out.bias"])
+    pk.add(p + ".bias_tab", bias_table(P[p + ".relative_pos_embeddings.relative_attention_bias.weight"], ch // heads))
+
+
+def _diff_resblock(pk, P, p):
+    for n in ("in_layers.0.weight", "in_layers.0.bias", "out_layers.0.weight", "out_layers.0.bias"):
+        pk.add(f"{p}.{n}", P[f"{p}.{n}"])
+    pk.conv(p + ".in_layers.2", P[p + ".in_layers.2.weight"], P[p + ".in_layers.2.bias"])
+    pk.conv(p + ".emb_layers.1", P[p + ".emb_layers.1.weight"], P[p + ".emb_layers.1.bias"])
+    pk.conv(p + ".out_layers.3", P[p + ".out_layers.3.weight"], P[p + ".out_layers.3.bias"])
+
+
+def pack_diffusion(pk, P, cfg):
+    d = cfg["diffusion"]
+    mc, heads, nl = d["model_channels"], d["num_heads"], d["num_layers"]
+    pk.add("diffusion.unconditioned_embedding", P["diffusion.unconditioned_embedding"].reshape(-1))
+    pk.conv("diffusion.inp_block", P["diffusion.inp_block.weight"], P["diffusion.inp_block.bias"])
+    for i in (0, 2):
+        pk.conv(f"diffusion.time_embed.{i}", P[f"diffusion.time_embed.{i}.weight"], P[f"diffusion.time_embed.{i}.bias"])
+    pk.add("diffusion.code_norm.weight", P["diffusion.code_norm.weight"])
+    pk.add("diffusion.code_norm.bias", P["diffusion.code_norm.bias"])
+    pk.conv("diffusion.latent_conditioner.0", P["diffusion.latent_conditioner.0.weight"], P["diffusion.latent_conditioner.0.bias"])
+    for i in range(1, 5):
+        _attention_block(pk, P, f"diffusion.latent_conditioner.{i}", mc, heads)
+    pk.conv("diffusion.contextual_embedder.0", P["diffusion.contextual_embedder.0.weight"], P["diffusion.contextual_embedder.0.bias"])
+    pk.conv("diffusion.contextual_embedder.1", P["diffusion.contextual_embedder.1.weight"], P["diffusion.contextual_embedder.1.bias"])
+    for i in range(2, 7):
+        _attention_block(pk, P, f"diffusion.contextual_embedder.{i}", 2 * mc, heads)
+    for i in range(3):
+        p = f"diffusion.conditioning_timestep_integrator.{i}"
+        _diff_resblock(pk, P, p + ".resblk")
+        _attention_block(pk, P, p + ".attn", mc, heads)
+    w = P["diffusion.integrating_conv.weight"]
+    pk.conv("diffusion.integrating_conv.a", w[:, :mc], P["diffusion.integrating_conv.bias"])
+    pk.conv("diffusion.integrating_conv.b", w[:, mc:], None)
+    for i in range(nl):
+        p = f"diffusion.layers.{i}"
+        _diff_resblock(pk, P, p + ".resblk")
+        _attention_block(pk, P, p + ".attn", mc, heads)
+    for i in range(nl, nl + 3):
+        _diff_resblock(pk, P, f"diffusion.layers.{i}")
+    pk.add("diffusion.out.0.weight", P["diffusion.out.0.weight"])
+    pk.add("diffusion.out.0.bias", P["diffusion.out.0.bias"])
+    pk.conv("diffusion.out.2", P["diffusion.out.2.weight"], P["diffusion.out.2.bias"])
+
+
+def pack_all(P, cfg=None, parts=("diffusion",)):
+    """P: folded fp32 dict (weights.select_inference_params). Returns a Packer."""
+    cfg = load_config(cfg)
+    pk = Packer()
+    if "diffusion" in parts:
+        pack_diffusion(pk, P, cfg)
+    return pk

@@ -1,0 +1,174 @@
+"""Thin Python owner of a libdetail_hip.so handle.  PyTorch is used only for device memory and streams."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import load_config
+from .packing import pack_all
+from .weights import select_inference_params
+
+
+class DttsError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _ints(a):
+    if a is None:
+        return None
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+    return arr.ctypes.data_as(_lib.c_int_p), arr
+
+
+def _check(t, name):
+    if t is None:
+        return
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise DttsError(f"{name}: expected a contiguous float32 CUDA tensor")
+
+
+ALL_PARTS = ("diffusion", "gpt", "vocoder")
+
+
+class Runtime:
+    """One handle per (device, stream).  `state` is a reference-format state dict (torch tensors or numpy
+    arrays; weight-norm pairs accepted) or an already folded dict."""
+
+    def __init__(self, state, cfg=None, device="cuda:0", parts=ALL_PARTS, folded=False, extra=None):
+        self.lib = _lib.load()
+        self.cfg = load_config(cfg)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise DttsError("libdetail_hip runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        torch.cuda.set_device(self.device)
+        c = _lib.DttsConfig()
+        self.lib.dtts_default_config(C.byref(c))
+        d, g, v = self.cfg["diffusion"], self.cfg["gpt"], self.cfg["vaegan"]
+        c.diff_channels, c.diff_layers, c.diff_heads = d["model_channels"], d["num_layers"], d["num_heads"]
+        c.mel_channels, c.diff_out_channels = d["in_channels"], d["out_channels"]
+        c.gpt_dim, c.gpt_layers, c.gpt_heads, c.gpt_mel_codes = g["model_dim"], g["layers"], g["heads"], g["number_mel_codes"]
+        c.gpt_text_tokens = g["number_text_tokens"] + 1
+        c.gpt_max_mel_pos, c.gpt_max_text_pos = g["max_mel_tokens"] + 3, g["max_text_tokens"] + 2
+        self.h = C.c_void_p()
+        rc = self.lib.dtts_create(C.byref(self.h), C.byref(c), self.device.index or 0)
+        if rc != 0:
+            raise DttsError(f"dtts_create failed ({rc}): {self.lib.dtts_last_error(None).decode()}")
+        self.parts = tuple(parts)
+        P = state if (folded or not self.parts) else select_inference_params(state, self.cfg)
+        pk = pack_all(P, self.cfg, parts=self.parts)
+        for k, v in (extra or {}).items():          # test hook: ad-hoc packed tensors
+            pk.add(k, v)
+        flat, names, offsets, numels = pk.blob()
+        self.blob = torch.from_numpy(flat).to(self.device)
+        self._names = [n.encode() for n in names]
+        self._bind(offsets, numels)
+
+    def _bind(self, offsets, numels):
+        n = len(self._names)
+        arr = (C.c_char_p * n)(*self._names)
+        self._offsets, self._numels = np.ascontiguousarray(offsets), np.ascontiguousarray(numels)
+        rc = self.lib.dtts_bind_weights(self.h, _ptr(self.blob), self.blob.numel() * 4, arr,
+                                        self._offsets.ctypes.data_as(_lib.c_u64_p), self._numels.ctypes.data_as(_lib.c_u64_p),
+                                        n, self._stream())
+        self._rc(rc)
+
+    def broadcast_weights(self, src=0):
+        """One-time RCCL broadcast of the packed blob from rank `src` over xGMI."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.blob, src=src)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _rc(self, rc):
+        if rc != 0:
+            raise DttsError(f"libdetail_hip error {rc}: {self.lib.dtts_last_error(self.h).decode()}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                torch.cuda.synchronize(self.device)
+                self.lib.dtts_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ stage B
+    def diff_conditioning(self, refer, lens=None):
+        _check(refer, "refer")
+        B, _, T = refer.shape
+        out = torch.empty((B, 2 * self.cfg["diffusion"]["model_channels"]), device=self.device, dtype=torch.float32)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_diff_conditioning(self.h, _ptr(refer), li[0] if li else None, B, T, _ptr(out), self._stream()))
+        return out
+
+    def diff_timestep_independent(self, latent_cm, cond, lens_n=None):
+        _check(latent_cm, "latent_cm"); _check(cond, "cond")
+        B, Cc, n = latent_cm.shape
+        out = torch.zeros((B, Cc, 4 * n), device=self.device, dtype=torch.float32)
+        li = _ints(lens_n)
+        self._rc(self.lib.dtts_diff_timestep_independent(self.h, _ptr(latent_cm), li[0] if li else None, B, n, _ptr(cond),
+                                                         _ptr(out), self._stream()))
+        return out
+
+    def diff_forward(self, x, step, code_emb=None, cond_free=False, lens=None):
+        _check(x, "x"); _check(code_emb, "code_emb")
+        B, _, T = x.shape
+        out = torch.zeros((B, self.cfg["diffusion"]["out_channels"], T), device=self.device, dtype=torch.float32)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_diff_forward(self.h, _ptr(x), _ptr(code_emb), li[0] if li else None, B, T, int(step),
+                                            1 if cond_free else 0, _ptr(out), self._stream()))
+        return out
+
+    def diff_sample(self, code_emb, seed, sample_ids, lens=None, n_steps=0, x_init=None, step_noise=None, denorm=True):
+        _check(code_emb, "code_emb"); _check(x_init, "x_init"); _check(step_noise, "step_noise")
+        B, _, T = code_emb.shape
+        out = torch.zeros((B, self.cfg["diffusion"]["in_channels"], T), device=self.device, dtype=torch.float32)
+        li, si = _ints(lens), _ints(sample_ids)
+        self._rc(self.lib.dtts_diff_sample(self.h, _ptr(code_emb), li[0] if li else None, B, T, int(seed), si[0], int(n_steps),
+                                           _ptr(x_init), _ptr(step_noise), _ptr(out), 1 if denorm else 0, self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ unit ops
+    def op_attention_block(self, prefix, x, lens=None):
+        _check(x, "x")
+        B, Cc, T = x.shape
+        y = torch.zeros_like(x)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_op_attention_block(self.h, prefix.encode(), _ptr(x), li[0] if li else None, B, Cc, T, _ptr(y), self._stream()))
+        return y
+
+    def op_resblock(self, prefix, x, step, lens=None):
+        _check(x, "x")
+        B, Cc, T = x.shape
+        y = torch.zeros_like(x)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_op_resblock(self.h, prefix.encode(), _ptr(x), li[0] if li else None, B, T, int(step), _ptr(y), self._stream()))
+        return y
+
+    def op_conv1d(self, name, x, cout, kw, stride=1, dil=1, pad=0, pro_act=0, epi_act=0, gate=0, phases=1, res=None, lens_in=None):
+        _check(x, "x"); _check(res, "res")
+        B, Cin, Tin = x.shape
+        nout = (Tin + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        tout = nout * max(1, phases)
+        cr = cout // 2 if gate else cout
+        y = torch.zeros((B, cr, tout), device=self.device, dtype=torch.float32)
+        li = _ints(lens_in)
+        self._rc(self.lib.dtts_op_conv1d(self.h, name.encode(), _ptr(x), li[0] if li else None, B, Cin, Tin, cout, kw, stride, dil, pad,
+                                         pro_act, epi_act, gate, phases, _ptr(res), _ptr(y), tout, self._stream()))
+        return y
+
+    def op_philox_normal(self, n, seed, sample_ids, stage, step):
+        si = _ints(sample_ids)
+        B = len(si[1])
+        out = torch.empty((B, n), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_op_philox_normal(self.h, _ptr(out), n, B, int(seed), si[0], int(stage), int(step), self._stream()))
+        return out

@@ -1,0 +1,127 @@
+/* libdetail_hip.so — C ABI of the MI355X-native detail_tts acoustic-synthesis hot path.
+ *
+ * The reference (adelacvg/detail_tts) is pure Python/PyTorch and has NO native/FFI layer
+ * (SURVEY.md §1, §8b); its drop-in boundary is the Python surface
+ *   prepare/load_infer.py:8   load_model
+ *   vqvae/model_24k.py:774    SynthesizerTrn.infer
+ *   vqvae/model_24k.py:848    SynthesizerTrn.infer_flowvae
+ *   vqvae/model_24k.py:479    do_spectrogram_diffusion
+ *   gpt/model.py:514          UnifiedVoice.inference_speech_tortoise
+ *   gpt/model.py:429          UnifiedVoice.forward(return_latent=True)
+ *   vqvae/diff_model.py:221/231/262  DiffusionTts.get_conditioning / timestep_independent / forward
+ *   vqvae/model_24k.py:269    Generator.forward
+ * which detail_tts_amd/ mirrors.  This header is what that Python layer binds (ctypes); each entry point
+ * names the reference function whose device work it replaces.
+ *
+ * Conventions: every function returns 0 on success or a negative code (message via
+ * dtts_last_error); no exceptions, no torch types; activation pointers are DEVICE pointers to fp32
+ * [B, C, T] (channel-major, time contiguous) buffers owned by the caller; `lens`/`sample_ids`
+ * arrays are HOST int32 arrays of B entries; all launches are asynchronous on `stream`
+ * (a hipStream_t passed as void*), with no hidden synchronisation except when the internal
+ * workspace has to grow.  One handle per (device, stream); not thread-safe.
+ */
+#ifndef DETAIL_HIP_H
+#define DETAIL_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dtts_handle dtts_handle;
+
+typedef struct dtts_config {
+    /* diffusion (vqvae/configs/config_24k.json "diffusion") */
+    int diff_channels;      /* 768 */
+    int diff_layers;        /* 10  */
+    int diff_heads;         /* 16  */
+    int mel_channels;       /* 128 */
+    int diff_out_channels;  /* 256 */
+    int diff_steps;         /* 50  (vqvae/model_24k.py:581) */
+    int diff_trained_steps; /* 4000 */
+    float cond_free_k;      /* 2.0 */
+    /* gpt */
+    int gpt_dim;            /* 768 */
+    int gpt_layers;         /* 10 */
+    int gpt_heads;          /* 16 */
+    int gpt_mel_codes;      /* 8194 */
+    int gpt_text_tokens;    /* 257 rows in text_embedding */
+    int gpt_max_mel_pos;    /* 1603 */
+    int gpt_max_text_pos;   /* 802 */
+    /* vaegan */
+    int inter_channels;     /* 192 */
+    int hidden_channels;    /* 192 */
+    int filter_channels;    /* 512 */
+    int enc_heads;          /* 4 */
+    int enc_layers;         /* 3 */
+    int gin_channels;       /* 768 */
+    int upsample_initial_channel; /* 400 */
+    int n_upsamples;        /* 5 */
+    int upsample_rates[8];
+    int upsample_kernels[8];
+    int n_resblock_kernels; /* 3 */
+    int resblock_kernels[4];
+    int resblock_dilations[4];   /* shared (1,3,5) */
+} dtts_config;
+
+/* fills *cfg with the values of the reference's config_24k.json */
+void dtts_default_config(dtts_config* cfg);
+
+int dtts_create(dtts_handle** out, const dtts_config* cfg, int device);
+int dtts_destroy(dtts_handle* h);
+const char* dtts_last_error(dtts_handle* h);   /* h may be NULL: last create() error */
+const char* dtts_version(void);
+
+/* Bind the packed weight blob (one device allocation, owned by the caller, must outlive the handle).
+ * names[i] / offsets[i] (in floats) / numels[i] describe tensor i inside the blob.  Layouts are those
+ * produced by detail_tts_amd/packing.py.  Replaces nn.Module.load_state_dict (prepare/load_infer.py:26).
+ * Also builds the timestep tables (time_embed + every ResBlock emb_layers for the 50 sampling steps,
+ * vqvae/diff_model.py:294, :108) on the device. */
+int dtts_bind_weights(dtts_handle* h, const void* blob_dev, size_t nbytes, const char* const* names,
+                      const unsigned long long* offsets, const unsigned long long* numels, int n, void* stream);
+
+/* ---- stage B: diffusion mel decoder ---------------------------------------------------------- */
+
+/* DiffusionTts.get_conditioning (vqvae/diff_model.py:221-229): refer [B,128,Tmax] -> cond [B,1536] */
+int dtts_diff_conditioning(dtts_handle* h, const float* refer, const int* lens, int B, int Tmax, float* cond_out, void* stream);
+
+/* DiffusionTts.timestep_independent (vqvae/diff_model.py:231-260), latent branch.
+ * latent_cm [B,768,nmax] (channel-major), lens_n[B], cond [B,1536] -> code_emb [B,768,4*nmax] */
+int dtts_diff_timestep_independent(dtts_handle* h, const float* latent_cm, const int* lens_n, int B, int nmax,
+                                   const float* cond, float* code_emb, void* stream);
+
+/* DiffusionTts.forward with precomputed_aligned_embeddings (vqvae/diff_model.py:262-322) at sampling
+ * step `step` (0..diff_steps-1; the model sees timestep_map[step]).  x [B,128,T], code_emb [B,768,T]
+ * (ignored when cond_free) -> out [B,256,T]. */
+int dtts_diff_forward(dtts_handle* h, const float* x, const float* code_emb, const int* lens, int B, int T, int step,
+                      int cond_free, float* out, void* stream);
+
+/* do_spectrogram_diffusion's p_sample_loop (vqvae/model_24k.py:479-492; vqvae/utils/diffusion.py:654-742,
+ * 445-485, 284-386) with classifier-free guidance.  code_emb [B,768,T] -> mel_out [B,128,T].
+ * Noise follows the Philox spec (seed, sample_ids[b], stage, step) unless x_init [B,128,T] /
+ * step_noise [n_steps][B,128,T] (test hooks, may be NULL) are given.  n_steps <= 0 means all.
+ * denorm != 0 applies denormalize_torch_mel (vqvae/model_24k.py:508) to the result. */
+int dtts_diff_sample(dtts_handle* h, const float* code_emb, const int* lens, int B, int T, unsigned long long seed,
+                     const int* sample_ids, int n_steps, const float* x_init, const float* step_noise, float* mel_out,
+                     int denorm, void* stream);
+
+/* ---- unit entry points for parity tests ------------------------------------------------------- */
+/* AttentionBlock.forward (vqvae/utils/diff_util.py:209-215) of the block whose weights start with `prefix` */
+int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T,
+                            float* y, void* stream);
+/* diffusion ResBlock.forward (vqvae/diff_model.py:106-119) at sampling step `step` */
+int dtts_op_resblock(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int T, int step, float* y,
+                     void* stream);
+/* Conv1d via the MFMA GEMM kernel on a packed weight named `name` (F.conv1d semantics + fused options) */
+int dtts_op_conv1d(dtts_handle* h, const char* name, const float* x, const int* lens_in, int B, int Cin, int Tin, int Cout,
+                   int KW, int stride, int dil, int pad, int pro_act, int epi_act, int gate, int phases, const float* res,
+                   float* y, int Tout_alloc, void* stream);
+/* Philox normal fill: out[b, 0..n) for (seed, sample_ids[b], stage, step) */
+int dtts_op_philox_normal(dtts_handle* h, float* out, int n, int B, unsigned long long seed, const int* sample_ids, int stage,
+                          int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETAIL_HIP_H */
