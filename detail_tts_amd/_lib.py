@@ -39,6 +39,10 @@ SIGNATURES = {
     "dtts_diff_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_diff_sample": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dtts_vocoder": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_float, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dtts_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dtts_op_mel_style": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_attention_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_resblock": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_conv1d": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

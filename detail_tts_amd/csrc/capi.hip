@@ -100,6 +100,25 @@ int dtts_diff_sample(dtts_handle* h, const float* code_emb, const int* lens, int
     DTTS_API_END(h)
 }
 
+int dtts_vocoder(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
+                 float noise_scale, const float* noise_override, float* wav, float* trace_z, void* stream) {
+    DTTS_API_BEGIN
+    h->m->vocoder(mel, lens, B, T, seed, sample_ids, noise_scale, noise_override, wav, trace_z, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* lens, int B, int T, float* wav, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_generator(z, g, lens, B, T, wav, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const int* lens, int B, int T, float* g_out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_mel_style(which, mel, lens, B, T, g_out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T, float* y,
                             void* stream) {
     DTTS_API_BEGIN

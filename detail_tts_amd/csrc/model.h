@@ -41,6 +41,32 @@ struct DiffLayerW {
     AttnBlockW at;
 };
 
+struct MelStyleW {           // MelStyleEncoder (vqvae/modules/modules.py:642-720)
+    PackedConv sp0, sp1, t0, t1, qkv, afc, fc;
+    int n_mel = 0, hidden = 0, out = 0;
+};
+
+struct EncLayerW {           // attentions.Encoder layer (vqvae/modules/attentions.py:73-107)
+    PackedConv qkv, o, f1, f2;
+    const float *ek = nullptr, *ev = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+
+struct CouplingW {           // ResidualCouplingLayer + WN (vqvae/modules/modules.py:421-475, 152-229)
+    PackedConv pre, post, cond;
+    PackedConv in[4], res[3], skip[4];
+};
+
+struct ResBlock1W {
+    PackedConv c1[3], c2[3];
+    int k = 3;
+};
+
+struct GenStageW {
+    PackedConv up;
+    int rate = 1, up_pad = 0, cout = 0;
+    ResBlock1W rb[3];
+};
+
 class Arena {
 public:
     ~Arena();
@@ -74,6 +100,14 @@ public:
                       float* out, hipStream_t s);
     void diff_sample(const float* code_emb, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
                      int n_steps, const float* x_init, const float* step_noise, float* mel_out, int denorm, hipStream_t s);
+    // ---- stage C
+    void mel_style(const MelStyleW& w, const float* mel, const int* lens_dev, const int* lens_host, int B, int T, float* g_out,
+                   hipStream_t s);
+    void op_mel_style(const char* which, const float* mel, const int* lens_host, int B, int T, float* g_out, hipStream_t s);
+    void vocoder(const float* mel, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
+                 float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s);
+    void generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
+    void op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
     // ---- unit ops used by the parity tests
     void op_attention_block(const char* prefix, const float* x, const int* lens_host, int B, int C, int T, float* y, hipStream_t s);
     void op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y, hipStream_t s);
@@ -95,6 +129,9 @@ private:
     AttnBlockW attn_block(const std::string& prefix, int C, int H) const;
     ResBlockW res_block(const std::string& prefix, int C, int index) const;
     void build_diffusion(hipStream_t s);
+    void build_vocoder();
+    MelStyleW mel_style_w(const std::string& prefix, int n_mel, int hidden, int out) const;
+    ConvParams cp(const float* x, int cin, float* y, int cout, int B, int T, int Ta, const int* lens) const;
 
     const int* upload_ints(const int* host, int n, hipStream_t s);
 
@@ -120,6 +157,14 @@ private:
     int n_steps_ = 0;
     std::vector<int> timestep_map_;
     std::vector<DiffStepCoefs> step_coefs_;
+
+    // vocoder
+    MelStyleW ref_enc_, gpt_cond_;
+    bool has_vocoder_ = false, has_gpt_ = false;
+    PackedConv in_proj_, enc_out_, enc_proj_, dec_pre_, dec_cond_, dec_post_;
+    std::vector<EncLayerW> enc_layers_;
+    std::vector<CouplingW> flows_;
+    std::vector<GenStageW> gen_;
 
     Arena ws_;        // per-call activations
     Arena persist_;   // tables built at bind time

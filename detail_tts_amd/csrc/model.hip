@@ -113,7 +113,25 @@ void Model::bind_weights(const void* blob, size_t nbytes, const char* const* nam
         weights_[names[i]] = {static_cast<const float*>(blob) + offsets[i], (size_t)numels[i]};
     }
     if (weights_.count("diffusion.inp_block.wp")) build_diffusion(stream);
+    has_vocoder_ = weights_.count("dec.conv_pre.wp") != 0;
+    if (has_vocoder_) build_vocoder();
     bound_ = true;
+}
+
+ConvParams Model::cp(const float* x, int cin, float* y, int cout, int B, int T, int Ta, const int* lens) const {
+    ConvParams p;
+    p.B = B;
+    p.Tin = T;
+    p.Nout = T;
+    p.len_in = lens;
+    p.len_out = lens;
+    p.x = x;
+    p.x_bs = (long long)cin * Ta;
+    p.x_cs = Ta;
+    p.y = y;
+    p.y_bs = (long long)cout * Ta;
+    p.y_cs = Ta;
+    return p;
 }
 
 void Model::run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const {

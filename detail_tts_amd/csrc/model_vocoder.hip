@@ -1,0 +1,432 @@
+// Stage C orchestration: MelStyleEncoder, SpecEncoder (enc_p), inverse flow, HiFiGAN generator.
+// Reference: vqvae/model_24k.py:848-863 (infer_flowvae), :71-124, :127-169, :221-288;
+// vqvae/modules/modules.py:152-229, 240-334, 393-475, 642-720; vqvae/modules/attentions.py:73-107, 161-303, 317-363.
+#include <cmath>
+
+#include "model.h"
+
+namespace dtts {
+
+MelStyleW Model::mel_style_w(const std::string& p, int n_mel, int hidden, int out) const {
+    MelStyleW w;
+    w.n_mel = n_mel;
+    w.hidden = hidden;
+    w.out = out;
+    w.sp0 = conv(p + ".spectral.0.fc", n_mel, hidden, 1);
+    w.sp1 = conv(p + ".spectral.3.fc", hidden, hidden, 1);
+    w.t0 = conv(p + ".temporal.0.conv1.conv", hidden, 2 * hidden, 5);    // rows interleaved (a_r, b_r) for the GLU gate
+    w.t1 = conv(p + ".temporal.1.conv1.conv", hidden, 2 * hidden, 5);
+    w.qkv = conv(p + ".slf_attn.qkv", hidden, 3 * hidden, 1);            // [w_qs; w_ks; w_vs]
+    w.afc = conv(p + ".slf_attn.fc", hidden, hidden, 1);
+    w.fc = conv(p + ".fc.fc", hidden, out, 1);
+    return w;
+}
+
+void Model::build_vocoder() {
+    const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
+    ref_enc_ = mel_style_w("ref_enc", cfg.mel_channels, 128, gin);
+    in_proj_ = conv("in_proj", cfg.mel_channels, inter, 3);
+    enc_layers_.clear();
+    for (int i = 0; i < cfg.enc_layers; ++i) {
+        EncLayerW l;
+        const std::string a = "enc_p.encoder.attn_layers." + std::to_string(i);
+        const int dk = hid / cfg.enc_heads;
+        l.qkv = conv(a + ".qkv", hid, 3 * hid, 1);
+        l.o = conv(a + ".conv_o", hid, hid, 1);
+        l.ek = W(a + ".emb_rel_k", (size_t)9 * dk);
+        l.ev = W(a + ".emb_rel_v", (size_t)9 * dk);
+        l.g1 = W("enc_p.encoder.norm_layers_1." + std::to_string(i) + ".gamma", hid);
+        l.b1 = W("enc_p.encoder.norm_layers_1." + std::to_string(i) + ".beta", hid);
+        l.g2 = W("enc_p.encoder.norm_layers_2." + std::to_string(i) + ".gamma", hid);
+        l.b2 = W("enc_p.encoder.norm_layers_2." + std::to_string(i) + ".beta", hid);
+        l.f1 = conv("enc_p.encoder.ffn_layers." + std::to_string(i) + ".conv_1", hid, filt, 3);
+        l.f2 = conv("enc_p.encoder.ffn_layers." + std::to_string(i) + ".conv_2", filt, hid, 3);
+        enc_layers_.push_back(l);
+    }
+    enc_out_ = conv("enc_p.out_proj", hid, inter, 1);
+    enc_proj_ = conv("enc_p.proj", inter, 2 * inter, 1);
+    flows_.clear();
+    for (int f = 0; f < 8; f += 2) {
+        CouplingW c;
+        const std::string p = "flow.flows." + std::to_string(f);
+        c.pre = conv(p + ".pre", inter / 2, hid, 1);
+        c.post = conv(p + ".post", hid, inter / 2, 1);
+        c.cond = conv(p + ".enc.cond_layer", gin, 2 * hid * 4, 1);        // rows interleaved per layer
+        for (int l = 0; l < 4; ++l) {
+            c.in[l] = conv(p + ".enc.in_layers." + std::to_string(l), hid, 2 * hid, 5);
+            if (l < 3) c.res[l] = conv(p + ".enc.res_skip_layers." + std::to_string(l) + ".res", hid, hid, 1);
+            c.skip[l] = conv(p + ".enc.res_skip_layers." + std::to_string(l) + ".skip", hid, hid, 1);
+        }
+        flows_.push_back(c);
+    }
+    const int c0 = cfg.upsample_initial_channel;
+    dec_pre_ = conv("dec.conv_pre", inter, c0, 7);
+    dec_cond_ = conv("dec.cond", gin, c0, 1);
+    gen_.clear();
+    int ch = c0;
+    for (int i = 0; i < cfg.n_upsamples; ++i) {
+        GenStageW g;
+        const int u = cfg.upsample_rates[i], k = cfg.upsample_kernels[i], pad = (k - u) / 2;
+        const int dmin = -((k - 1 - pad) / u), dmax = (u - 1 + pad) / u;
+        g.rate = u;
+        g.up_pad = -dmin;
+        g.cout = ch / 2;
+        g.up = conv("dec.ups." + std::to_string(i), ch, u * (ch / 2), dmax - dmin + 1);
+        ch /= 2;
+        for (int j = 0; j < cfg.n_resblock_kernels; ++j) {
+            ResBlock1W& r = g.rb[j];
+            r.k = cfg.resblock_kernels[j];
+            const std::string p = "dec.resblocks." + std::to_string(i * cfg.n_resblock_kernels + j);
+            for (int l = 0; l < 3; ++l) {
+                r.c1[l] = conv(p + ".convs1." + std::to_string(l), ch, ch, r.k);
+                r.c2[l] = conv(p + ".convs2." + std::to_string(l), ch, ch, r.k);
+            }
+        }
+        gen_.push_back(g);
+    }
+    dec_post_ = conv("dec.conv_post", ch, 1, 7, false);
+}
+
+// MelStyleEncoder.forward.  mel [B,n_mel,T] (positions >= len are treated as zero == the reference's x*mask /
+// masked_fill), g_out [B,out].
+void Model::mel_style(const MelStyleW& w, const float* mel, const int* lens, const int* lens_host, int B, int T, float* g_out,
+                      hipStream_t s) {
+    const int H = w.hidden;
+    const size_t act = (size_t)B * H * T;
+    float* a = ws_.f32(act);
+    float* b = ws_.f32(act);
+    float* qkv = ws_.f32(3 * act);
+    float* y = ws_.f32((size_t)B * w.out * T);
+    // spectral: Linear -> Mish -> Linear -> Mish  (modules.py:661-668)
+    ConvParams p = cp(mel, w.n_mel, a, H, B, T, T, lens);
+    p.epi_act = ACT_MISH;
+    run_conv(w.sp0, p, s);
+    p = cp(a, H, b, H, B, T, T, lens);
+    p.epi_act = ACT_MISH;
+    run_conv(w.sp1, p, s);
+    // temporal: 2 x Conv1dGLU (conv k5 -> a*sigmoid(b) + residual)  (modules.py:517-523)
+    p = cp(b, H, a, H, B, T, T, lens);
+    p.pad = 2;
+    p.gate = GATE_GLU;
+    p.res = b;
+    p.res_bs = (long long)H * T;
+    p.res_cs = T;
+    run_conv(w.t0, p, s);
+    p = cp(a, H, b, H, B, T, T, lens);
+    p.pad = 2;
+    p.gate = GATE_GLU;
+    p.res = a;
+    p.res_bs = (long long)H * T;
+    p.res_cs = T;
+    run_conv(w.t1, p, s);
+    // self-attention, 2 heads, temperature sqrt(d_model) (modules.py:576-578), padded keys masked
+    p = cp(b, H, qkv, 3 * H, B, T, T, lens);
+    run_conv(w.qkv, p, s);
+    AttnParams at;
+    at.qkv = qkv;
+    at.bs = (long long)3 * H * T;
+    at.cs = T;
+    at.q_off = 0;
+    at.k_off = H;
+    at.v_off = 2 * H;
+    at.head_stride = H / 2;
+    at.out = a;
+    at.o_bs = (long long)H * T;
+    at.o_cs = T;
+    at.lens = lens;
+    at.T = T;
+    at.B = B;
+    at.H = 2;
+    at.D = H / 2;
+    at.scale = 1.f / std::sqrt((float)H);
+    launch_flash_attention(at, s);
+    p = cp(a, H, qkv, H, B, T, T, lens);         // reuse qkv's first block as the post-attention activation
+    p.res = b;
+    p.res_bs = (long long)H * T;
+    p.res_cs = T;
+    run_conv(w.afc, p, s);
+    p = cp(qkv, H, y, w.out, B, T, T, lens);
+    run_conv(w.fc, p, s);
+    launch_mean_time(y, (long long)w.out * T, T, lens, T, B, w.out, g_out, s);
+    (void)lens_host;
+}
+
+static size_t mel_style_ws(int B, int H, int out, int T) { return sizeof(float) * ((size_t)5 * B * H * T + (size_t)B * out * T) + 8 * 256; }
+
+void Model::op_mel_style(const char* which, const float* mel, const int* lens_host, int B, int T, float* g_out, hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    const std::string n(which);
+    const MelStyleW* w = nullptr;
+    if (n == "ref_enc" && has_vocoder_) w = &ref_enc_;
+    if (n == "gpt.conditioning_encoder" && has_gpt_) w = &gpt_cond_;
+    DTTS_REQUIRE(w, "unknown / unbound MelStyleEncoder");
+    ws_.ensure(mel_style_ws(B, w->hidden, w->out, T) + 4096);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    mel_style(*w, mel, dl, l.data(), B, T, g_out, s);
+}
+
+// Generator.forward (vqvae/model_24k.py:269-288).  z [B,192,T], g [B,768] -> wav [B,1,256*T]
+void Model::generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    const int c0 = cfg.upsample_initial_channel;
+    // workspace: every stage holds C_i * T_i = c0*T*(rate product)/2^i floats per sample; 6 live buffers of the largest
+    size_t biggest = (size_t)c0 * T;
+    {
+        size_t ch = c0, t = T;
+        for (auto& st : gen_) {
+            ch /= 2;
+            t *= st.rate;
+            biggest = std::max(biggest, ch * t);
+        }
+    }
+    const size_t buf = (size_t)B * biggest;
+    const size_t mark = ws_.mark();
+    float* X = ws_.f32(buf);
+    float* R[3] = {ws_.f32(buf), ws_.f32(buf), ws_.f32(buf)};
+    float* T1 = ws_.f32(buf);
+    float* T2 = ws_.f32(buf);
+    float* gc = ws_.f32((size_t)B * dec_cond_.CoutP);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+
+    // cond(g): 1x1 conv on a length-1 sequence -> per-sample additive rows for conv_pre
+    ConvParams p;
+    p.B = B;
+    p.Tin = 1;
+    p.Nout = 1;
+    p.x = g;
+    p.x_bs = cfg.gin_channels;
+    p.x_cs = 1;
+    p.y = gc;
+    p.y_bs = dec_cond_.CoutP;
+    p.y_cs = 1;
+    run_conv(dec_cond_, p, s);
+    p = cp(z, cfg.inter_channels, X, c0, B, T, T, dl);
+    p.pad = 3;
+    p.badd = gc;
+    p.badd_bs = dec_cond_.CoutP;
+    run_conv(dec_pre_, p, s);
+
+    int ch = c0, Tc = T;
+    for (size_t i = 0; i < gen_.size(); ++i) {
+        const GenStageW& st = gen_[i];
+        const int Tn = Tc * st.rate, cn = ch / 2;
+        std::vector<int> ln(B);
+        for (int b = 0; b < B; ++b) ln[b] = l[b] * st.rate;
+        const int* dln = upload_ints(ln.data(), B, s);
+        // x = ups[i](leaky_relu(x, 0.1)) as `rate` polyphase correlations in one GEMM
+        ConvParams u = cp(X, ch, T1, cn, B, Tc, Tc, dl);
+        u.pro_act = ACT_LRELU;
+        u.pro_slope = 0.1f;
+        u.pad = st.up_pad;
+        u.phases = st.rate;
+        u.y_bs = (long long)cn * Tn;
+        u.y_cs = Tn;
+        run_conv(st.up, u, s);
+        // three ResBlock1 branches on T1 -> R[j]
+        for (int j = 0; j < cfg.n_resblock_kernels; ++j) {
+            const ResBlock1W& rb = st.rb[j];
+            const float* cur = T1;
+            for (int li = 0; li < 3; ++li) {
+                const int d = cfg.resblock_dilations[li];
+                ConvParams a = cp(cur, cn, T2, cn, B, Tn, Tn, dln);
+                a.pro_act = ACT_LRELU;
+                a.pro_slope = 0.1f;
+                a.dil = d;
+                a.pad = (rb.k * d - d) / 2;
+                run_conv(rb.c1[li], a, s);
+                ConvParams c = cp(T2, cn, R[j], cn, B, Tn, Tn, dln);
+                c.pro_act = ACT_LRELU;
+                c.pro_slope = 0.1f;
+                c.pad = (rb.k - 1) / 2;
+                c.res = cur;
+                c.res_bs = (long long)cn * Tn;
+                c.res_cs = Tn;
+                run_conv(rb.c2[li], c, s);
+                cur = R[j];
+            }
+        }
+        launch_add3_scale(R[0], R[1], R[2], 1.f / 3.f, X, (long long)B * cn * Tn, s);
+        ch = cn;
+        Tc = Tn;
+        dl = dln;
+        l = ln;
+    }
+    // x = tanh(conv_post(leaky_relu(x)))  — F.leaky_relu default slope 0.01 (model_24k.py:284)
+    ConvParams o = cp(X, ch, wav, 1, B, Tc, Tc, dl);
+    o.pro_act = ACT_LRELU;
+    o.pro_slope = 0.01f;
+    o.pad = 3;
+    o.epi_act = ACT_TANH;
+    run_conv(dec_post_, o, s);
+    ws_.rewind(mark);
+}
+
+static size_t generator_ws(const dtts_config& cfg, int B, int T) {
+    size_t biggest = (size_t)cfg.upsample_initial_channel * T, ch = cfg.upsample_initial_channel, t = T;
+    for (int i = 0; i < cfg.n_upsamples; ++i) {
+        ch /= 2;
+        t *= cfg.upsample_rates[i];
+        biggest = std::max(biggest, ch * t);
+    }
+    return sizeof(float) * (6 * (size_t)B * biggest + (size_t)B * 1024) + 16 * 256;
+}
+
+void Model::op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    ws_.ensure(generator_ws(cfg, B, T) + 8192);
+    DTTS_CHECK_HIP(hipMemsetAsync(wav, 0, sizeof(float) * (size_t)B * 256 * T, s));
+    generator(z, g, lens_host, B, T, wav, s);
+}
+
+// SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863), batched with per-sample lengths.
+void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
+                    float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    DTTS_REQUIRE(T % 4 == 0, "mel length must be a multiple of 4 (assert y.shape[-1]%4==0, model_24k.py:851)");
+    const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
+    const int H = cfg.enc_heads, dk = hid / H;
+    const size_t a192 = (size_t)B * hid * T;
+    const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256;
+    ws_.ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, T)) + 8192);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    const int* sids = upload_ints(sample_ids_host, B, s);
+
+    float* g = ws_.f32((size_t)B * gin);
+    float* x = ws_.f32(a192);
+    float* y = ws_.f32(a192);
+    float* qkv = ws_.f32(3 * a192);
+    float* att = ws_.f32(a192);
+    float* ffn = ws_.f32((size_t)B * filt * T);
+    float* relk = ws_.f32((size_t)B * H * T * 9);
+    float* ml = ws_.f32((size_t)B * H * T * 2);
+    float* stats = ws_.f32(2 * a192);
+    float* Gc = ws_.f32((size_t)B * 2048);
+
+    // g = ref_enc(y * y_mask, y_mask)  (:855)
+    {
+        const size_t m = ws_.mark();
+        mel_style(ref_enc_, mel, dl, l.data(), B, T, g, s);
+        ws_.rewind(m);
+    }
+    // x = in_proj(y) ; enc_p(x, y_lengths)  (:856-857)
+    ConvParams p = cp(mel, cfg.mel_channels, x, inter, B, T, T, dl);
+    p.pad = 1;
+    run_conv(in_proj_, p, s);
+    const float scale = 1.f / std::sqrt((float)dk);
+    for (auto& L : enc_layers_) {
+        p = cp(x, hid, qkv, 3 * hid, B, T, T, dl);
+        run_conv(L.qkv, p, s);
+        launch_vits_rel_key(qkv, (long long)3 * hid * T, T, 0, dk, L.ek, relk, dl, B, H, dk, T, 4, scale, s);
+        AttnParams at;
+        at.qkv = qkv;
+        at.bs = (long long)3 * hid * T;
+        at.cs = T;
+        at.q_off = 0;
+        at.k_off = hid;
+        at.v_off = 2 * hid;
+        at.head_stride = dk;
+        at.out = att;
+        at.o_bs = (long long)hid * T;
+        at.o_cs = T;
+        at.lens = dl;
+        at.T = T;
+        at.B = B;
+        at.H = H;
+        at.D = dk;
+        at.scale = scale;
+        at.band = relk;
+        at.band_w = 4;
+        at.ml_out = ml;
+        launch_flash_attention(at, s);
+        launch_vits_rel_value(qkv, (long long)3 * hid * T, T, 0, hid, dk, relk, ml, L.ev, att, (long long)hid * T, T, dl, B, H, dk, T,
+                              4, scale, s);
+        p = cp(att, hid, y, hid, B, T, T, dl);
+        run_conv(L.o, p, s);
+        launch_ln_channels(x, y, (long long)hid * T, T, dl, T, B, hid, L.g1, L.b1, 1e-5f, x, (long long)hid * T, T, s);
+        p = cp(x, hid, ffn, filt, B, T, T, dl);
+        p.pad = 1;
+        p.epi_act = ACT_RELU;
+        run_conv(L.f1, p, s);
+        p = cp(ffn, filt, y, hid, B, T, T, dl);
+        p.pad = 1;
+        run_conv(L.f2, p, s);
+        launch_ln_channels(x, y, (long long)hid * T, T, dl, T, B, hid, L.g2, L.b2, 1e-5f, x, (long long)hid * T, T, s);
+    }
+    p = cp(x, hid, y, inter, B, T, T, dl);
+    run_conv(enc_out_, p, s);
+    p = cp(y, inter, stats, 2 * inter, B, T, T, dl);
+    run_conv(enc_proj_, p, s);
+    // z_p = m_p + randn * exp(logs_p) * noise_scale (:860), written channel-flipped (= the first Flip of the reversed flow)
+    float* zc = x;
+    float* zn = y;
+    launch_flow_prior(stats, (long long)2 * inter * T, T, dl, T, B, inter, noise_scale, seed, sids, noise_override, 1, zc,
+                      (long long)inter * T, T, s);
+    // z = flow(z_p, mask, g, reverse=True) (:861): reversed(flows) = Flip, C6, Flip, C4, Flip, C2, Flip, C0
+    float* h = att;
+    float* acts = qkv;                 // [B,192,T]
+    float* skip = qkv + a192;          // [B,192,T]
+    float* h2 = qkv + 2 * a192;
+    float* mbuf = ffn;                 // [B,96,T]
+    for (int f = (int)flows_.size() - 1; f >= 0; --f) {
+        const CouplingW& c = flows_[f];
+        // G = cond_layer(g): [B, 1536] in packed (gate-interleaved) row order
+        ConvParams q;
+        q.B = B;
+        q.Tin = 1;
+        q.Nout = 1;
+        q.x = g;
+        q.x_bs = gin;
+        q.x_cs = 1;
+        q.y = Gc;
+        q.y_bs = c.cond.CoutP;
+        q.y_cs = 1;
+        run_conv(c.cond, q, s);
+        // h = pre(x0) * mask
+        p = cp(zc, inter / 2, h, hid, B, T, T, dl);
+        p.x_bs = (long long)inter * T;            // x0 = first half of the channels
+        run_conv(c.pre, p, s);
+        float* hc = h;
+        float* hn = h2;
+        for (int li = 0; li < 4; ++li) {
+            // acts = tanh(a + g_l) * sigmoid(b + g_l), (a|b) = in_layer(h)   (modules.py:15-22, 212-221)
+            p = cp(hc, hid, acts, hid, B, T, T, dl);
+            p.pad = 2;
+            p.gate = GATE_TANH_SIGMOID;
+            p.badd = Gc + (size_t)li * 2 * hid;
+            p.badd_bs = c.cond.CoutP;
+            run_conv(c.in[li], p, s);
+            if (li < 3) {
+                p = cp(acts, hid, hn, hid, B, T, T, dl);       // x = (x + res_acts) * mask
+                p.res = hc;
+                p.res_bs = (long long)hid * T;
+                p.res_cs = T;
+                run_conv(c.res[li], p, s);
+            }
+            p = cp(acts, hid, skip, hid, B, T, T, dl);         // output += skip_acts
+            if (li > 0) {
+                p.res = skip;
+                p.res_bs = (long long)hid * T;
+                p.res_cs = T;
+            }
+            run_conv(c.skip[li], p, s);
+            if (li < 3) std::swap(hc, hn);
+        }
+        // m = post(out) * mask ; x1 = (x1 - m) * mask ; then Flip (fused) unless this is the last flow
+        p = cp(skip, hid, mbuf, inter / 2, B, T, T, dl);
+        run_conv(c.post, p, s);
+        launch_coupling_reverse(zc, mbuf, zn, (long long)inter * T, T, dl, T, B, inter, f > 0 ? 1 : 0, s);
+        std::swap(zc, zn);
+    }
+    if (trace_z) DTTS_CHECK_HIP(hipMemcpyAsync(trace_z, zc, sizeof(float) * a192, hipMemcpyDeviceToDevice, s));
+    // o = dec(z, g)  (:862)
+    DTTS_CHECK_HIP(hipMemsetAsync(wav, 0, sizeof(float) * (size_t)B * 256 * T, s));
+    generator(zc, g, l.data(), B, T, wav, s);
+}
+
+}  // namespace dtts

@@ -49,8 +49,8 @@ void launch_diff_update(float* x, long long x_bs, int x_cs, const float* model_o
 // y = a*x + b*z (generic elementwise with optional exp on second operand) used by the flow prior:
 // z_p = m + noise * exp(logs) * noise_scale  (vqvae/model_24k.py:860)
 void launch_flow_prior(const float* stats, long long s_bs, int s_cs, const int* lens, int T, int B, int C, float noise_scale,
-                       unsigned long long seed, const int* sample_ids, const float* noise_override, float* z, long long z_bs,
-                       int z_cs, hipStream_t s);
+                       unsigned long long seed, const int* sample_ids, const float* noise_override, int flip, float* z,
+                       long long z_bs, int z_cs, hipStream_t s);
 
 // x1 <- (x1 - m) on channels [c0, c0+C) then channel flip of the whole [B, Ctot, T] tensor fused:
 // coupling reverse step + Flip (vqvae/modules/modules.py:393-400, 471-475).

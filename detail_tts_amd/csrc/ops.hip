@@ -246,8 +246,8 @@ void launch_diff_update(float* x, long long x_bs, int x_cs, const float* model_o
 
 // ---------------------------------------------------------------------------------------------
 __global__ void flow_prior_kernel(const float* stats, long long s_bs, int s_cs, const int* lens, int T, int C, float noise_scale,
-                                  unsigned long long seed, const int* sample_ids, const float* noise_override, float* z,
-                                  long long z_bs, int z_cs) {
+                                  unsigned long long seed, const int* sample_ids, const float* noise_override, int flip,
+                                  float* z, long long z_bs, int z_cs) {
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : T;
     const unsigned sample = (unsigned)sample_ids[b];
@@ -264,17 +264,17 @@ __global__ void flow_prior_kernel(const float* stats, long long s_bs, int s_cs, 
             const int c = e / len, t = e - c * len;
             const float m = sb[(long long)c * s_cs + t], logs = sb[(long long)(C + c) * s_cs + t];
             const float nv = noise_override ? noise_override[(long long)b * C * T + (long long)c * T + t] : nz[i];
-            zb[(long long)c * z_cs + t] = m + nv * expf(logs) * noise_scale;
+            zb[(long long)(flip ? C - 1 - c : c) * z_cs + t] = m + nv * expf(logs) * noise_scale;
         }
     }
 }
 
 void launch_flow_prior(const float* stats, long long s_bs, int s_cs, const int* lens, int T, int B, int C, float noise_scale,
-                       unsigned long long seed, const int* sample_ids, const float* noise_override, float* z, long long z_bs,
-                       int z_cs, hipStream_t s) {
+                       unsigned long long seed, const int* sample_ids, const float* noise_override, int flip, float* z,
+                       long long z_bs, int z_cs, hipStream_t s) {
     const int nblk = (C * T + 3) / 4;
     hipLaunchKernelGGL(flow_prior_kernel, dim3(cdiv(nblk, 256) > 64 ? 64 : cdiv(nblk, 256), B), dim3(256), 0, s, stats, s_bs,
-                       s_cs, lens, T, C, noise_scale, seed, sample_ids, noise_override, z, z_bs, z_cs);
+                       s_cs, lens, T, C, noise_scale, seed, sample_ids, noise_override, flip, z, z_bs, z_cs);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -182,10 +182,74 @@ def pack_diffusion(pk, P, cfg):
     pk.conv("diffusion.out.2", P["diffusion.out.2.weight"], P["diffusion.out.2.bias"])
 
 
+def _mel_style(pk, P, p):
+    pk.conv(p + ".spectral.0.fc", P[p + ".spectral.0.fc.weight"], P[p + ".spectral.0.fc.bias"])
+    pk.conv(p + ".spectral.3.fc", P[p + ".spectral.3.fc.weight"], P[p + ".spectral.3.fc.bias"])
+    for i in range(2):
+        w = P[p + f".temporal.{i}.conv1.conv.weight"]
+        pk.conv(p + f".temporal.{i}.conv1.conv", w, P[p + f".temporal.{i}.conv1.conv.bias"], row_perm=gate_perm(w.shape[0]))
+    wq = np.concatenate([P[p + f".slf_attn.{n}.weight"] for n in ("w_qs", "w_ks", "w_vs")], 0)
+    bq = np.concatenate([P[p + f".slf_attn.{n}.bias"] for n in ("w_qs", "w_ks", "w_vs")], 0)
+    pk.conv(p + ".slf_attn.qkv", wq, bq)
+    pk.conv(p + ".slf_attn.fc", P[p + ".slf_attn.fc.weight"], P[p + ".slf_attn.fc.bias"])
+    pk.conv(p + ".fc.fc", P[p + ".fc.fc.weight"], P[p + ".fc.fc.bias"])
+
+
+def pack_vocoder(pk, P, cfg):
+    v = cfg["vaegan"]
+    hid = v["hidden_channels"]
+    _mel_style(pk, P, "ref_enc")
+    pk.conv("in_proj", P["in_proj.weight"], P["in_proj.bias"])
+    for i in range(v["n_layers"]):
+        a = f"enc_p.encoder.attn_layers.{i}"
+        wq = np.concatenate([P[f"{a}.{n}.weight"] for n in ("conv_q", "conv_k", "conv_v")], 0)
+        bq = np.concatenate([P[f"{a}.{n}.bias"] for n in ("conv_q", "conv_k", "conv_v")], 0)
+        pk.conv(a + ".qkv", wq, bq)
+        pk.conv(a + ".conv_o", P[a + ".conv_o.weight"], P[a + ".conv_o.bias"])
+        pk.add(a + ".emb_rel_k", P[a + ".emb_rel_k"][0])
+        pk.add(a + ".emb_rel_v", P[a + ".emb_rel_v"][0])
+        for n in ("norm_layers_1", "norm_layers_2"):
+            pk.add(f"enc_p.encoder.{n}.{i}.gamma", P[f"enc_p.encoder.{n}.{i}.gamma"])
+            pk.add(f"enc_p.encoder.{n}.{i}.beta", P[f"enc_p.encoder.{n}.{i}.beta"])
+        for n in ("conv_1", "conv_2"):
+            pk.conv(f"enc_p.encoder.ffn_layers.{i}.{n}", P[f"enc_p.encoder.ffn_layers.{i}.{n}.weight"], P[f"enc_p.encoder.ffn_layers.{i}.{n}.bias"])
+    pk.conv("enc_p.out_proj", P["enc_p.out_proj.weight"], P["enc_p.out_proj.bias"])
+    pk.conv("enc_p.proj", P["enc_p.proj.weight"], P["enc_p.proj.bias"])
+    for f in (0, 2, 4, 6):
+        p = f"flow.flows.{f}"
+        pk.conv(p + ".pre", P[p + ".pre.weight"], P[p + ".pre.bias"])
+        pk.conv(p + ".post", P[p + ".post.weight"], P[p + ".post.bias"])
+        gp = gate_perm(2 * hid)
+        cperm = np.concatenate([l * 2 * hid + gp for l in range(4)])
+        pk.conv(p + ".enc.cond_layer", P[p + ".enc.cond_layer.weight"], P[p + ".enc.cond_layer.bias"], row_perm=cperm)
+        for l in range(4):
+            pk.conv(p + f".enc.in_layers.{l}", P[p + f".enc.in_layers.{l}.weight"], P[p + f".enc.in_layers.{l}.bias"], row_perm=gp)
+            w, b = P[p + f".enc.res_skip_layers.{l}.weight"], P[p + f".enc.res_skip_layers.{l}.bias"]
+            if l < 3:
+                pk.conv(p + f".enc.res_skip_layers.{l}.res", w[:hid], b[:hid])
+                pk.conv(p + f".enc.res_skip_layers.{l}.skip", w[hid:], b[hid:])
+            else:
+                pk.conv(p + f".enc.res_skip_layers.{l}.skip", w, b)
+    pk.conv("dec.conv_pre", P["dec.conv_pre.weight"], P["dec.conv_pre.bias"])
+    pk.conv("dec.cond", P["dec.cond.weight"], P["dec.cond.bias"])
+    for i, (u, k) in enumerate(zip(v["upsample_rates"], v["upsample_kernel_sizes"])):
+        weq, _pad = convtranspose_as_phases(P[f"dec.ups.{i}.weight"], u, (k - u) // 2)
+        pk.conv(f"dec.ups.{i}", weq, np.tile(P[f"dec.ups.{i}.bias"], u))
+    nk = len(v["resblock_kernel_sizes"])
+    for i in range(len(v["upsample_rates"]) * nk):
+        for cs in ("convs1", "convs2"):
+            for l in range(3):
+                p = f"dec.resblocks.{i}.{cs}.{l}"
+                pk.conv(p, P[p + ".weight"], P[p + ".bias"])
+    pk.conv("dec.conv_post", P["dec.conv_post.weight"], None)
+
+
 def pack_all(P, cfg=None, parts=("diffusion",)):
     """P: folded fp32 dict (weights.select_inference_params). Returns a Packer."""
     cfg = load_config(cfg)
     pk = Packer()
     if "diffusion" in parts:
         pack_diffusion(pk, P, cfg)
+    if "vocoder" in parts:
+        pack_vocoder(pk, P, cfg)
     return pk

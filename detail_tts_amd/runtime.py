@@ -137,6 +137,33 @@ class Runtime:
                                            _ptr(x_init), _ptr(step_noise), _ptr(out), 1 if denorm else 0, self._stream()))
         return out
 
+    # ------------------------------------------------------------------ stage C
+    def vocoder(self, mel, seed, sample_ids, lens=None, noise_scale=0.667, noise_override=None, return_z=False):
+        _check(mel, "mel"); _check(noise_override, "noise_override")
+        B, _, T = mel.shape
+        wav = torch.empty((B, 1, 256 * T), device=self.device, dtype=torch.float32)
+        z = torch.zeros((B, self.cfg["vaegan"]["inter_channels"], T), device=self.device, dtype=torch.float32) if return_z else None
+        li, si = _ints(lens), _ints(sample_ids)
+        self._rc(self.lib.dtts_vocoder(self.h, _ptr(mel), li[0] if li else None, B, T, int(seed), si[0], float(noise_scale),
+                                       _ptr(noise_override), _ptr(wav), _ptr(z), self._stream()))
+        return (wav, z) if return_z else wav
+
+    def generator(self, z, g, lens=None):
+        _check(z, "z"); _check(g, "g")
+        B, _, T = z.shape
+        wav = torch.empty((B, 1, 256 * T), device=self.device, dtype=torch.float32)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_generator(self.h, _ptr(z), _ptr(g), li[0] if li else None, B, T, _ptr(wav), self._stream()))
+        return wav
+
+    def mel_style(self, which, mel, lens=None):
+        _check(mel, "mel")
+        B, _, T = mel.shape
+        out = torch.empty((B, self.cfg["vaegan"]["gin_channels"]), device=self.device, dtype=torch.float32)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_op_mel_style(self.h, which.encode(), _ptr(mel), li[0] if li else None, B, T, _ptr(out), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ unit ops
     def op_attention_block(self, prefix, x, lens=None):
         _check(x, "x")

@@ -106,6 +106,21 @@ int dtts_diff_sample(dtts_handle* h, const float* code_emb, const int* lens, int
                      const int* sample_ids, int n_steps, const float* x_init, const float* step_noise, float* mel_out,
                      int denorm, void* stream);
 
+/* ---- stage C: flow-VAE front + HiFiGAN generator -------------------------------------------------- */
+
+/* SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863): ref_enc -> in_proj -> enc_p -> z_p -> flow^-1 -> dec.
+ * mel [B,128,T] (denormalised log-mel, T % 4 == 0) -> wav [B,1,256*T].  The z_p noise follows the Philox spec
+ * unless noise_override [B,192,T] is given.  trace_z (may be NULL) receives z [B,192,T]. */
+int dtts_vocoder(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
+                 float noise_scale, const float* noise_override, float* wav, float* trace_z, void* stream);
+
+/* Generator.forward (vqvae/model_24k.py:269-288): z [B,192,T], g [B,768] -> wav [B,1,256*T] */
+int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* lens, int B, int T, float* wav, void* stream);
+
+/* MelStyleEncoder.forward (vqvae/modules/modules.py:696-720) of "ref_enc" or "gpt.conditioning_encoder":
+ * mel [B,128,T] -> g [B,768] */
+int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const int* lens, int B, int T, float* g_out, void* stream);
+
 /* ---- unit entry points for parity tests ------------------------------------------------------- */
 /* AttentionBlock.forward (vqvae/utils/diff_util.py:209-215) of the block whose weights start with `prefix` */
 int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T,

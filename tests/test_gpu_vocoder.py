@@ -1,0 +1,73 @@
+"""GPU parity: HIP stage C (MelStyleEncoder, enc_p, inverse flow, HiFiGAN generator) vs oracle + golden."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def rt(weights):
+    from detail_tts_amd.runtime import Runtime
+    return Runtime(weights, folded=True, parts=("vocoder",))
+
+
+def test_ref_enc_golden(rt, weights, golden):
+    """Row 0 (unpadded) is pinned by the reference fixture.  Row 1 is padded (29 of 40 frames): the reference's
+    padded-batch arithmetic leaks Mish(bias) of the padding frames through the k=5 convs into the last valid frames,
+    which never happens on its real path (infer is batch 1, unpadded).  A batch here is DEFINED as independent
+    single-utterance runs, so row 1 is checked against the oracle run on the truncated utterance."""
+    from oracle import gpt as G
+    g = golden("mel_style")
+    out = host(rt.mel_style("ref_enc", dev(g["x2"]), g["len2"]))
+    assert maxabs(out[0], g["ref_enc2"][0, :, 0]) < 1e-4
+    L = int(g["len2"][1])
+    alone = G.mel_style_encoder(weights, "ref_enc", g["x2"][1:2, :, :L], [L])[0, :, 0]
+    assert maxabs(out[1], alone) < 1e-4
+
+
+def test_generator_golden(rt, golden):
+    g = golden("vocoder")
+    wav = host(rt.generator(dev(g["z"]), dev(g["g"][:, :, 0])))
+    assert wav.shape == g["wav"].shape
+    assert maxabs(wav, g["wav"]) < 1e-4, maxabs(wav, g["wav"])
+    assert float(np.abs(g["wav"]).max()) > 1e-3     # the fixture is not a trivially small signal
+
+
+def test_infer_flowvae_golden(rt, golden):
+    g = golden("vocoder")
+    wav, z = rt.vocoder(dev(g["mel"]), int(g["seed"]), [int(g["sample_id"])], return_z=True)
+    assert maxabs(host(z), g["z"]) < 2e-4, maxabs(host(z), g["z"])
+    r = rms(host(wav), g["wav"])
+    assert r < 1e-3 * max(1.0, float(np.sqrt(np.mean(g["wav"] ** 2))) * 10), r
+    assert r < 1e-4, r
+
+
+def test_vocoder_varlen_batch_vs_oracle(rt, weights):
+    from oracle import vocoder as V
+    rs = np.random.RandomState(11)
+    mel = (rs.randn(2, 128, 40) * 2 - 5).astype(np.float32)
+    lens = [40, 28]
+    wav = host(rt.vocoder(dev(mel), 77, [4, 5], lens=lens))
+    for b, L in enumerate(lens):
+        ref = V.infer_flowvae(weights, mel[b:b + 1, :, :L], [L], 77, [4 + b])[0, 0]
+        got = wav[b, 0, :256 * L]
+        assert rms(got, ref) < 1e-4, (b, rms(got, ref))
+        assert np.all(wav[b, 0, 256 * L:] == 0)
