@@ -26,6 +26,12 @@ class DttsConfig(C.Structure):
     ]
 
 
+class DttsGptOptions(C.Structure):
+    _fields_ = [("seed", C.c_ulonglong), ("sample_ids", c_int_p), ("max_generate_length", C.c_int), ("top_k", C.c_int),
+                ("top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float), ("suppress_eos", C.c_int),
+                ("forced_uniforms", C.c_void_p), ("forced_codes", c_int_p)]
+
+
 # name -> (restype, argtypes); every symbol include/detail_hip.h declares
 SIGNATURES = {
     "dtts_version": (C.c_char_p, []),
@@ -34,6 +40,10 @@ SIGNATURES = {
     "dtts_destroy": (C.c_int, [C.c_void_p]),
     "dtts_last_error": (C.c_char_p, [C.c_void_p]),
     "dtts_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), c_u64_p, c_u64_p, C.c_int, C.c_void_p]),
+    "dtts_gpt_generate": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int,
+                                    C.POINTER(DttsGptOptions), c_int_p, c_int_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dtts_gpt_latents": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_diff_conditioning": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_diff_timestep_independent": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dtts_diff_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

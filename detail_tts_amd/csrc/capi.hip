@@ -72,6 +72,25 @@ int dtts_bind_weights(dtts_handle* h, const void* blob, size_t nbytes, const cha
     DTTS_API_END(h)
 }
 
+int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
+                      int Lt_max, int B, const dtts_gpt_options* opts, int* codes_out, int* ncodes_out, float* latents_cm,
+                      int lat_stride, void* stream) {
+    DTTS_API_BEGIN
+    DTTS_REQUIRE(opts && opts->sample_ids, "options");
+    h->m->gpt_generate(refer, refer_lens, Tr, text, text_lens, Lt_max, B, *opts, codes_out, ncodes_out, latents_cm, lat_stride,
+                       (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_gpt_latents(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
+                     int Lt_max, const int* codes, const int* ncodes, int n_max, int B, float* latents_cm, int lat_stride,
+                     void* stream) {
+    DTTS_API_BEGIN
+    h->m->gpt_latents(refer, refer_lens, Tr, text, text_lens, Lt_max, codes, ncodes, n_max, B, latents_cm, lat_stride,
+                      (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_diff_conditioning(dtts_handle* h, const float* refer, const int* lens, int B, int Tmax, float* cond_out, void* stream) {
     DTTS_API_BEGIN
     h->m->diff_conditioning(refer, lens, B, Tmax, cond_out, (hipStream_t)stream);

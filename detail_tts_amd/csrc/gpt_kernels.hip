@@ -1,0 +1,512 @@
+// GPT decode-loop kernels for gfx950 (see gpt_kernels.h).  The decode step streams ~308 MB of fp32 weights
+// per token regardless of the batch -> these kernels are HBM-bound: wide (16 B/lane) coalesced
+// weight loads, many waves in flight, wave64 shuffle reductions, no MFMA.
+#include "gpt_kernels.h"
+#include "philox.h"
+
+namespace dtts {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm on vectors
+__device__ __forceinline__ void block_ln_256(float* v, int n_per, int C, const float* g, const float* bta, float* red) {
+    // v: this thread's n_per values (strided by 256 over C). Normalises in place.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int i = 0; i < n_per; ++i) s += v[i];
+    s = wsum(s);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    float q = 0.f;
+    for (int i = 0; i < n_per; ++i) {
+        const int c = tid + i * 256;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    q = wsum(q);
+    __syncthreads();
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)C + 1e-5f);
+    for (int i = 0; i < n_per; ++i) {
+        const int c = tid + i * 256;
+        if (c < C) v[i] = (v[i] - mean) * rstd * g[c] + bta[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void vec_layernorm_kernel(const float* x, const float* g1, const float* b1, const float* g2,
+                                                            const float* b2, float* y, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float v[8];
+    const int n_per = (C + 255) / 256;
+    for (int i = 0; i < n_per; ++i) {
+        const int c = tid + i * 256;
+        v[i] = c < C ? x[(long long)b * C + c] : 0.f;
+    }
+    block_ln_256(v, n_per, C, g1, b1, red);
+    if (g2) block_ln_256(v, n_per, C, g2, b2, red);
+    for (int i = 0; i < n_per; ++i) {
+        const int c = tid + i * 256;
+        if (c < C) y[(long long)b * C + c] = v[i];
+    }
+}
+
+void launch_vec_layernorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, hipStream_t s) {
+    DTTS_REQUIRE(C <= 2048, "vec_layernorm width");
+    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, gamma, beta, nullptr, nullptr, y, C);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+void launch_vec_layernorm2(const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* y, int B, int C,
+                           hipStream_t s) {
+    DTTS_REQUIRE(C <= 2048, "vec_layernorm width");
+    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, g1, b1, g2, b2, y, C);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ skinny GEMM
+int gemv_slices(int K, int CoutP) {
+    const int colblocks = cdiv(CoutP, 256);
+    int s = 768 / colblocks;
+    if (s < 1) s = 1;
+    if (s > K / 8) s = K / 8 > 0 ? K / 8 : 1;
+    return s;
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restrict__ W, int K, int CoutP, const float* __restrict__ x,
+                                                          int x_stride, int B, float* __restrict__ part, int rows_per_slice) {
+    const int lane = threadIdx.x;
+    const int col = blockIdx.x * 256 + lane * 4;
+    if (col >= CoutP) return;
+    const int k0 = blockIdx.y * rows_per_slice;
+    const int k1 = min(K, k0 + rows_per_slice);
+    float4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* wp = W + (long long)k0 * CoutP + col;
+    int i = k0;
+    for (; i + 4 <= k1; i += 4) {
+        float4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (long long)u * CoutP);
+        wp += 4LL * CoutP;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float* xr = x + (long long)(b < B ? b : B - 1) * x_stride + i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xv = xr[u];
+                acc[b].x += w[u].x * xv; acc[b].y += w[u].y * xv; acc[b].z += w[u].z * xv; acc[b].w += w[u].w * xv;
+            }
+        }
+    }
+    for (; i < k1; ++i) {
+        const float4 w = *reinterpret_cast<const float4*>(wp);
+        wp += CoutP;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float xv = x[(long long)(b < B ? b : B - 1) * x_stride + i];
+            acc[b].x += w.x * xv; acc[b].y += w.y * xv; acc[b].z += w.z * xv; acc[b].w += w.w * xv;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < B) *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * B + b) * CoutP + col) = acc[b];
+}
+
+void launch_gemv_partial(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices, hipStream_t s) {
+    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && CoutP % 4 == 0, "gemv shape");
+    DTTS_REQUIRE((long long)slices * CoutP <= 262144, "gemv partial scratch");
+    const int rps = cdiv(K, slices);
+    dim3 grid(cdiv(CoutP, 256), slices);
+    if (B <= 1) hipLaunchKernelGGL(gemv_partial_kernel<1>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
+    else if (B <= 4) hipLaunchKernelGGL(gemv_partial_kernel<4>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
+    else if (B <= 8) hipLaunchKernelGGL(gemv_partial_kernel<8>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
+    else hipLaunchKernelGGL(gemv_partial_kernel<16>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+__global__ void gemv_finish_kernel(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act,
+                                   const float* res, int res_stride, float* y, int y_stride) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (col >= Cout) return;
+    float v = bias ? bias[col] : 0.f;
+    for (int sl = 0; sl < slices; ++sl) v += part[((long long)sl * B + b) * CoutP + col];
+    v = act_apply(v, act, 0.f);
+    if (res) v += res[(long long)b * res_stride + col];
+    y[(long long)b * y_stride + col] = v;
+}
+
+void launch_gemv_finish(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act, const float* res,
+                        int res_stride, float* y, int y_stride, hipStream_t s) {
+    hipLaunchKernelGGL(gemv_finish_kernel, dim3(cdiv(Cout, 256), B), dim3(256), 0, s, part, slices, B, Cout, CoutP, bias, act, res,
+                       res_stride, y, y_stride);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+__global__ void gemv_finish_qkv_kernel(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf,
+                                       float* cache, long long cache_bs, int cache_cs, const int* pos) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (col >= 3 * C) return;
+    float v = bias[col];
+    for (int sl = 0; sl < slices; ++sl) v += part[((long long)sl * B + b) * CoutP + col];
+    if (col < C) qbuf[(long long)b * C + col] = v;
+    else cache[(long long)b * cache_bs + (long long)(col - C) * cache_cs + pos[b]] = v;
+}
+
+void launch_gemv_finish_qkv(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf, float* cache,
+                            long long cache_bs, int cache_cs, const int* pos, hipStream_t s) {
+    hipLaunchKernelGGL(gemv_finish_qkv_kernel, dim3(cdiv(3 * C, 256), B), dim3(256), 0, s, part, slices, B, C, CoutP, bias, qbuf, cache,
+                       cache_bs, cache_cs, pos);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ decode attention
+template <int D>
+__global__ __launch_bounds__(64) void decode_attention_kernel(const float* qbuf, const float* cache, long long cache_bs, int cache_cs,
+                                                              const int* klen, int H, float* out) {
+    extern __shared__ float sc[];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = H * D;
+    const int n = klen[b];
+    const float* kp = cache + (long long)b * cache_bs + (long long)(h * D) * cache_cs;
+    const float* vp = kp + (long long)C * cache_cs;
+    float q[D];
+    const float scale = rsqrtf((float)D);
+#pragma unroll
+    for (int c = 0; c < D; ++c) q[c] = qbuf[(long long)b * C + h * D + c] * scale;
+    float mx = -INFINITY;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int s = s0 + lane;
+        float a = -INFINITY;
+        if (s < n) {
+            a = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) a += q[c] * kp[(long long)c * cache_cs + s];
+            sc[s] = a;
+        }
+        mx = fmaxf(mx, a);
+    }
+    mx = wmax(mx);
+    float l = 0.f;
+    float o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) o[c] = 0.f;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int s = s0 + lane;
+        if (s < n) {
+            const float p = expf(sc[s] - mx);
+            l += p;
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] += p * vp[(long long)c * cache_cs + s];
+        }
+    }
+    l = wsum(l);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const float t = wsum(o[c]);
+        if (lane == 0) out[(long long)b * C + h * D + c] = t * inv;
+    }
+}
+
+void launch_decode_attention(const float* qbuf, const float* cache, long long cache_bs, int cache_cs, const int* klen, int B, int H,
+                             int D, float* out, hipStream_t s) {
+    DTTS_REQUIRE(D == 48, "decode attention head dim");
+    hipLaunchKernelGGL(decode_attention_kernel<48>, dim3(H, B), dim3(64), sizeof(float) * cache_cs, s, qbuf, cache, cache_bs, cache_cs,
+                       klen, H, out);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+__global__ void kv_to_cache_kernel(const float* qkv, long long bs, int cs, const int* lens, int C, float* cache, long long cache_bs,
+                                   int cache_cs) {
+    const int row = blockIdx.y, b = blockIdx.z;   // row in [0, 2C)
+    const int len = lens[b];
+    const float* src = qkv + (long long)b * bs + (long long)(C + row) * cs;
+    float* dst = cache + (long long)b * cache_bs + (long long)row * cache_cs;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < len; t += gridDim.x * blockDim.x) dst[t] = src[t];
+}
+
+void launch_kv_to_cache(const float* qkv, long long bs, int cs, const int* lens, int L, int B, int C, float* cache, long long cache_bs,
+                        int cache_cs, hipStream_t s) {
+    hipLaunchKernelGGL(kv_to_cache_kernel, dim3(cdiv(L, 128), 2 * C, B), dim3(128), 0, s, qkv, bs, cs, lens, C, cache, cache_bs, cache_cs);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ embeddings
+__global__ void build_prefix_kernel(const float* cond, const int* text_ids, int text_stride, const int* text_lens, const float* text_emb,
+                                    const float* text_pos, const float* mel_emb, const float* mel_pos, const int* mel_ids,
+                                    int mel_stride, const int* mel_lens, int C, int Lmax, float* emb) {
+    const int j = blockIdx.x, b = blockIdx.y;          // column
+    const int tl = text_lens[b];                        // number of text positions (start + ids + stop)
+    const int ml = mel_lens[b];                         // number of mel input tokens (start + history)
+    if (j >= 1 + tl + ml) return;
+    float* col = emb + (long long)b * C * Lmax + j;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v;
+        if (j == 0) v = cond[(long long)b * C + c];
+        else if (j <= tl) {
+            const int id = text_ids[(long long)b * text_stride + (j - 1)];
+            v = text_emb[(long long)id * C + c] + text_pos[(long long)(j - 1) * C + c];
+        } else {
+            const int k = j - 1 - tl;
+            const int id = mel_ids[(long long)b * mel_stride + k];
+            v = mel_emb[(long long)id * C + c] + mel_pos[(long long)k * C + c];
+        }
+        col[(long long)c * Lmax] = v;
+    }
+}
+
+void launch_build_prefix(const float* cond, const int* text_ids, int text_stride, const int* text_lens, const float* text_emb,
+                         const float* text_pos, const float* mel_emb, const float* mel_pos, const int* mel_ids, int mel_stride,
+                         const int* mel_lens, int B, int C, int Lmax, float* emb, hipStream_t s) {
+    hipLaunchKernelGGL(build_prefix_kernel, dim3(Lmax, B), dim3(256), 0, s, cond, text_ids, text_stride, text_lens, text_emb, text_pos,
+                       mel_emb, mel_pos, mel_ids, mel_stride, mel_lens, C, Lmax, emb);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+__global__ void gather_last_kernel(const float* x, long long bs, int cs, const int* lens, int col_off, int C, float* y) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    y[(long long)b * C + c] = x[(long long)b * bs + (long long)c * cs + lens[b] - 1 + col_off];
+}
+
+void launch_gather_last(const float* x, long long bs, int cs, const int* lens, int col_off, int B, int C, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(gather_last_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, x, bs, cs, lens, col_off, C, y);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ sampler
+// HF GenerationMixin._sample logits processing + inverse-CDF multinomial of the Philox spec.
+constexpr int SAMP_THREADS = 1024;
+constexpr int SORT_MAX = 16384;
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ float block_reduce_max(float v, float* red) {
+    v = wmax(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < SAMP_THREADS / 64; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+__device__ float block_reduce_sum(float v, float* red) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < SAMP_THREADS / 64; ++i) r += red[i];
+    return r;
+}
+// exclusive prefix of one value per thread across the block; returns prefix, *total gets the block total
+__device__ float block_exclusive_scan(float v, float* red, float* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    float base = 0.f, tot = 0.f;
+    for (int i = 0; i < SAMP_THREADS / 64; ++i) {
+        if (i < wave) base += red[i];
+        tot += red[i];
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerParams p) {
+    extern __shared__ float smem[];
+    float* sv = smem;                                   // [Vpad] processed scores
+    const int Vpad = (p.V + 3) & ~3;
+    float* skey = sv + Vpad;                            // [SORT_MAX]
+    unsigned short* sidx = reinterpret_cast<unsigned short*>(skey + SORT_MAX);   // [SORT_MAX]
+    __shared__ float red[SAMP_THREADS / 64];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_u[4];
+    __shared__ int sh_i[4];
+
+    const int tid = threadIdx.x, b = blockIdx.x, V = p.V;
+    int token;
+    if (p.forced_tokens) {
+        token = p.forced_tokens[(long long)b * p.f_stride + p.step];
+    } else {
+        // 1. repetition penalty over every id in the row's input_ids, temperature
+        const float* lg = p.logits + (long long)b * p.Vs;
+        const unsigned char* seen = p.seen + (long long)b * V;
+        for (int v = tid; v < V; v += SAMP_THREADS) {
+            float x = lg[v];
+            if (p.suppress_eos && v == p.eos) x = -INFINITY;
+            if (seen[v]) x = x < 0.f ? x * p.repetition_penalty : x / p.repetition_penalty;
+            sv[v] = x / p.temperature;
+        }
+        __syncthreads();
+        // 2. top-k: threshold = k-th largest value (radix select on order-preserving keys)
+        if (p.top_k > 0 && p.top_k < V) {
+            unsigned prefix = 0, mask = 0;
+            int krem = p.top_k;
+            for (int pass = 3; pass >= 0; --pass) {
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                const int sh = pass * 8;
+                for (int v = tid; v < V; v += SAMP_THREADS) {
+                    const unsigned k = f2ord(sv[v]);
+                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int acc = 0, bin = 255;
+                    for (; bin > 0; --bin) {
+                        if (acc + (int)hist[bin] >= krem) break;
+                        acc += (int)hist[bin];
+                    }
+                    sh_u[0] = (unsigned)bin;
+                    sh_i[0] = krem - acc;
+                }
+                __syncthreads();
+                prefix |= sh_u[0] << sh;
+                mask |= 255u << sh;
+                krem = sh_i[0];
+                __syncthreads();
+            }
+            const float thr = ord2f(prefix);
+            for (int v = tid; v < V; v += SAMP_THREADS)
+                if (sv[v] < thr) sv[v] = -INFINITY;
+            __syncthreads();
+        }
+        // 3. softmax statistics of the kept set
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, sv[v]);
+        mx = block_reduce_max(mx, red);
+        // 4. top-p (nucleus): ascending sort of the kept candidates, drop the tail whose cumulative prob <= 1 - top_p
+        if (p.top_p < 1.0f) {
+            if (tid == 0) sh_i[1] = 0;
+            __syncthreads();
+            for (int v = tid; v < V; v += SAMP_THREADS)
+                if (sv[v] > -INFINITY) {
+                    const int slot = atomicAdd(&sh_i[1], 1);
+                    skey[slot] = sv[v];
+                    sidx[slot] = (unsigned short)v;
+                }
+            __syncthreads();
+            const int M = sh_i[1];
+            int n2 = 64;
+            while (n2 < M) n2 <<= 1;
+            for (int i = M + tid; i < n2; i += SAMP_THREADS) { skey[i] = INFINITY; sidx[i] = 0xffff; }
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2; i += SAMP_THREADS) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const bool asc = (i & k) == 0;
+                            const float a = skey[i], c = skey[ixj];
+                            const unsigned short ia = sidx[i], ic = sidx[ixj];
+                            // total order: value, then id (deterministic for ties)
+                            const bool gt = (a > c) || (a == c && ia > ic);
+                            if (gt == asc) { skey[i] = c; skey[ixj] = a; sidx[i] = ic; sidx[ixj] = ia; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            // Z over the kept set, then inclusive cumulative prob in ascending order
+            float z = 0.f;
+            for (int i = tid; i < M; i += SAMP_THREADS) z += expf(skey[i] - mx);
+            z = block_reduce_sum(z, red);
+            const int per = (n2 + SAMP_THREADS - 1) / SAMP_THREADS;
+            const int i0 = tid * per;
+            float loc = 0.f;
+            for (int i = i0; i < i0 + per && i < M; ++i) loc += expf(skey[i] - mx) / z;
+            float tot;
+            float run = block_exclusive_scan(loc, red, &tot);
+            const float cut = 1.0f - p.top_p;
+            for (int i = i0; i < i0 + per && i < M; ++i) {
+                run += expf(skey[i] - mx) / z;
+                if (run <= cut && i != M - 1) sv[sidx[i]] = -INFINITY;
+            }
+            __syncthreads();
+        }
+        // 5. inverse-CDF draw in vocabulary order
+        const int per = (V + SAMP_THREADS - 1) / SAMP_THREADS;
+        const int v0 = tid * per;
+        float loc = 0.f;
+        for (int v = v0; v < v0 + per && v < V; ++v) loc += (sv[v] > -INFINITY) ? expf(sv[v] - mx) : 0.f;
+        float tot;
+        float run = block_exclusive_scan(loc, red, &tot);
+        float u;
+        if (p.forced_u) u = p.forced_u[(long long)b * p.u_stride + p.step];
+        else {
+            float uu[4];
+            philox_uniform4(p.seed, (unsigned)p.sample_ids[b], STAGE_GPT_SAMPLE, p.step, 0u, uu);
+            u = uu[0];
+        }
+        const float target = u * tot;
+        if (tid == 0) { sh_i[2] = V; sh_i[3] = -1; }
+        __syncthreads();
+        int last_kept = -1;
+        for (int v = v0; v < v0 + per && v < V; ++v) {
+            if (sv[v] > -INFINITY) {
+                run += expf(sv[v] - mx);
+                last_kept = v;
+                if (run > target) { atomicMin(&sh_i[2], v); break; }
+            }
+        }
+        if (last_kept >= 0) atomicMax(&sh_i[3], last_kept);
+        __syncthreads();
+        token = sh_i[2] < V ? sh_i[2] : sh_i[3];
+    }
+    const bool fin = p.finished[b] != 0;
+    if (fin) token = p.eos;
+    __syncthreads();
+    if (tid == 0) {
+        p.codes[(long long)b * p.codes_stride + p.step] = token;
+        p.seen[(long long)b * V + token] = 1;
+        if (token == p.eos) p.finished[b] = 1;
+    }
+    // next input embedding: mel_embedding[token] + mel_pos_embedding[step + 1]   (gpt/model.py:134-136 with position k)
+    for (int c = tid; c < p.C; c += SAMP_THREADS)
+        p.x_next[(long long)b * p.C + c] = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(p.step + 1) * p.C + c];
+}
+
+void launch_sampler(const SamplerParams& p, hipStream_t s) {
+    DTTS_REQUIRE(p.V <= SORT_MAX && p.V < 65535, "vocabulary too large for the LDS sampler");
+    const size_t lds = sizeof(float) * (size_t)(((p.V + 3) & ~3) + SORT_MAX) + sizeof(unsigned short) * SORT_MAX;
+    static bool once = false;
+    if (!once) {
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024));
+        once = true;
+    }
+    hipLaunchKernelGGL(sampler_kernel, dim3(p.B), dim3(SAMP_THREADS), lds, s, p);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace dtts

@@ -56,6 +56,11 @@ struct CouplingW {           // ResidualCouplingLayer + WN (vqvae/modules/module
     PackedConv in[4], res[3], skip[4];
 };
 
+struct GptLayerW {
+    const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    PackedConv attn, proj, fc, fc2;
+};
+
 struct ResBlock1W {
     PackedConv c1[3], c2[3];
     int k = 3;
@@ -100,6 +105,13 @@ public:
                       float* out, hipStream_t s);
     void diff_sample(const float* code_emb, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
                      int n_steps, const float* x_init, const float* step_noise, float* mel_out, int denorm, hipStream_t s);
+    // ---- stage A
+    void gpt_generate(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
+                      int Lt_max, int B, const dtts_gpt_options& o, int* codes_host, int* ncodes_host, float* latents_cm,
+                      int lat_stride, hipStream_t s);
+    void gpt_latents(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
+                     int Lt_max, const int* codes_host, const int* ncodes_host, int n_max, int B, float* latents_cm, int lat_stride,
+                     hipStream_t s);
     // ---- stage C
     void mel_style(const MelStyleW& w, const float* mel, const int* lens_dev, const int* lens_host, int B, int T, float* g_out,
                    hipStream_t s);
@@ -130,6 +142,9 @@ private:
     ResBlockW res_block(const std::string& prefix, int C, int index) const;
     void build_diffusion(hipStream_t s);
     void build_vocoder();
+    void build_gpt();
+    void gpt_prefill_layers(float* x, const int* lens, int B, int L, float* kv_cache, long long kv_layer_stride, long long kv_bs,
+                            int kv_cs, hipStream_t s);
     MelStyleW mel_style_w(const std::string& prefix, int n_mel, int hidden, int out) const;
     ConvParams cp(const float* x, int cin, float* y, int cout, int B, int T, int Ta, const int* lens) const;
 
@@ -165,6 +180,12 @@ private:
     std::vector<EncLayerW> enc_layers_;
     std::vector<CouplingW> flows_;
     std::vector<GenStageW> gen_;
+
+    // gpt
+    std::vector<GptLayerW> gpt_layers_;
+    PackedConv mel_head_;
+    const float *lnf_g_ = nullptr, *lnf_b_ = nullptr, *fin_g_ = nullptr, *fin_b_ = nullptr;
+    const float *text_emb_ = nullptr, *mel_emb_ = nullptr, *text_pos_ = nullptr, *mel_pos_ = nullptr;
 
     Arena ws_;        // per-call activations
     Arena persist_;   // tables built at bind time

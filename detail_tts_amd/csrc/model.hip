@@ -115,6 +115,8 @@ void Model::bind_weights(const void* blob, size_t nbytes, const char* const* nam
     if (weights_.count("diffusion.inp_block.wp")) build_diffusion(stream);
     has_vocoder_ = weights_.count("dec.conv_pre.wp") != 0;
     if (has_vocoder_) build_vocoder();
+    has_gpt_ = weights_.count("gpt.mel_head.wp") != 0;
+    if (has_gpt_) build_gpt();
     bound_ = true;
 }
 

@@ -244,6 +244,25 @@ def pack_vocoder(pk, P, cfg):
     pk.conv("dec.conv_post", P["dec.conv_post.weight"], None)
 
 
+def pack_gpt(pk, P, cfg):
+    g = cfg["gpt"]
+    _mel_style(pk, P, "gpt.conditioning_encoder")
+    for l in range(g["layers"]):
+        p = f"gpt.gpt.h.{l}"
+        for n in ("ln_1", "ln_2"):
+            pk.add(f"{p}.{n}.weight", P[f"{p}.{n}.weight"])
+            pk.add(f"{p}.{n}.bias", P[f"{p}.{n}.bias"])
+        for n in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):      # HF Conv1D: weight [in, out]
+            pk.conv(f"{p}.{n}", P[f"{p}.{n}.weight"].T, P[f"{p}.{n}.bias"])
+    for n in ("gpt.gpt.ln_f", "gpt.final_norm"):
+        pk.add(n + ".weight", P[n + ".weight"])
+        pk.add(n + ".bias", P[n + ".bias"])
+    pk.conv("gpt.mel_head", P["gpt.mel_head.weight"], P["gpt.mel_head.bias"])
+    for n in ("gpt.text_embedding.weight", "gpt.mel_embedding.weight", "gpt.text_pos_embedding.emb.weight",
+              "gpt.mel_pos_embedding.emb.weight"):
+        pk.add(n, P[n])
+
+
 def pack_all(P, cfg=None, parts=("diffusion",)):
     """P: folded fp32 dict (weights.select_inference_params). Returns a Packer."""
     cfg = load_config(cfg)
@@ -252,4 +271,6 @@ def pack_all(P, cfg=None, parts=("diffusion",)):
         pack_diffusion(pk, P, cfg)
     if "vocoder" in parts:
         pack_vocoder(pk, P, cfg)
+    if "gpt" in parts:
+        pack_gpt(pk, P, cfg)
     return pk

@@ -101,6 +101,62 @@ class Runtime:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ stage A
+    @staticmethod
+    def _pad_text(texts):
+        """list of 1-D int arrays (as api.py passes them, trailing 0 included) -> (padded [B,Lmax] int32, lens)"""
+        lens = np.array([len(t) for t in texts], np.int32)
+        out = np.zeros((len(texts), int(lens.max())), np.int32)
+        for i, t in enumerate(texts):
+            out[i, :len(t)] = np.asarray(t, np.int32)
+        return out, lens
+
+    def gpt_generate(self, refer, refer_lens, texts, seed, sample_ids, max_generate_length=600, top_k=50, top_p=0.8,
+                     temperature=0.8, repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None):
+        """-> (codes int32 [B,G] incl. stop, ncodes [B], latents_cm float32 cuda [B,768,G])"""
+        _check(refer, "refer"); _check(forced_uniforms, "forced_uniforms")
+        B, _, Tr = refer.shape
+        text, tl = self._pad_text(texts)
+        G = int(max_generate_length)
+        si = _ints(sample_ids)
+        rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
+        o = _lib.DttsGptOptions()
+        o.seed, o.sample_ids, o.max_generate_length, o.top_k = int(seed), si[0], G, int(top_k or 0)
+        o.top_p, o.temperature, o.repetition_penalty = float(top_p if top_p is not None else 1.0), float(temperature), float(repetition_penalty)
+        o.suppress_eos = 1 if suppress_eos else 0
+        o.forced_uniforms = forced_uniforms.data_ptr() if forced_uniforms is not None else None
+        fc = None
+        if forced_codes is not None:
+            fc = np.full((B, G), 8193, np.int32)
+            for b, c in enumerate(forced_codes):
+                fc[b, :len(c)] = np.asarray(c, np.int32)
+            o.forced_codes = fc.ctypes.data_as(_lib.c_int_p)
+        codes = np.zeros((B, G), np.int32)
+        ncodes = np.zeros((B,), np.int32)
+        lat = torch.zeros((B, self.cfg["gpt"]["model_dim"], G), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_gpt_generate(self.h, _ptr(refer), rl[0], Tr, text.ctypes.data_as(_lib.c_int_p),
+                                            tl.ctypes.data_as(_lib.c_int_p), text.shape[1], B, C.byref(o),
+                                            codes.ctypes.data_as(_lib.c_int_p), ncodes.ctypes.data_as(_lib.c_int_p), _ptr(lat), G,
+                                            self._stream()))
+        return codes, ncodes, lat
+
+    def gpt_latents(self, refer, refer_lens, texts, codes_list):
+        """teacher-forced latents (UnifiedVoice.forward(return_latent=True)) -> cuda [B,768,n_max] channel-major"""
+        _check(refer, "refer")
+        B, _, Tr = refer.shape
+        text, tl = self._pad_text(texts)
+        nn = np.array([len(c) for c in codes_list], np.int32)
+        nmax = int(nn.max())
+        codes = np.zeros((B, nmax), np.int32)
+        for b, c in enumerate(codes_list):
+            codes[b, :len(c)] = np.asarray(c, np.int32)
+        rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
+        lat = torch.zeros((B, self.cfg["gpt"]["model_dim"], nmax), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_gpt_latents(self.h, _ptr(refer), rl[0], Tr, text.ctypes.data_as(_lib.c_int_p), tl.ctypes.data_as(_lib.c_int_p),
+                                           text.shape[1], codes.ctypes.data_as(_lib.c_int_p), nn.ctypes.data_as(_lib.c_int_p), nmax, B,
+                                           _ptr(lat), nmax, self._stream()))
+        return lat
+
     # ------------------------------------------------------------------ stage B
     def diff_conditioning(self, refer, lens=None):
         _check(refer, "refer")

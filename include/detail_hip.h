@@ -81,6 +81,39 @@ const char* dtts_version(void);
 int dtts_bind_weights(dtts_handle* h, const void* blob_dev, size_t nbytes, const char* const* names,
                       const unsigned long long* offsets, const unsigned long long* numels, int n, void* stream);
 
+/* ---- stage A: GPT autoregressive code decode ---------------------------------------------------------- */
+
+/* Sampling options of HF generate() as the reference calls it (vqvae/model_24k.py:782-792): do_sample, top_p 0.8,
+ * temperature 0.8, repetition_penalty 2.0, max_generate_length 600; top_k is HF's effective default 50. */
+typedef struct dtts_gpt_options {
+    unsigned long long seed;
+    const int* sample_ids;          /* HOST [B]: Philox stream id of each utterance */
+    int max_generate_length;        /* number of tokens generated at most (stop included) */
+    int top_k;                      /* <= 0 disables */
+    float top_p, temperature, repetition_penalty;
+    int suppress_eos;               /* != 0: the stop token can never be drawn (benchmarks with random weights) */
+    const float* forced_uniforms;   /* DEVICE [B][max_generate_length] uniforms replacing the Philox draw (tests), or NULL */
+    const int* forced_codes;        /* HOST [B][max_generate_length] teacher-forced tokens (no sampling), or NULL */
+} dtts_gpt_options;
+
+/* UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF GenerationMixin._sample, with a real KV cache
+ * (mel position k for the k-th code) and the sampler on the device.  refer [B,128,Tr] device, refer_lens HOST,
+ * text HOST int32 [B][Lt_max] exactly as api.py passes it (trailing 0 included), text_lens HOST.
+ * Outputs: codes HOST int32 [B][max_generate_length] (stop token included, rows padded with 8193), ncodes HOST [B],
+ * latents_cm DEVICE [B,768,lat_stride]: column k = final_norm(ln_f(h)) at decode step k, i.e. the same values the
+ * reference recomputes with UnifiedVoice.forward(return_latent=True).  Synchronises the stream
+ * once every 16 tokens (finish flags) and at the end (codes). */
+int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
+                      int Lt_max, int B, const dtts_gpt_options* opts, int* codes_out, int* ncodes_out, float* latents_cm,
+                      int lat_stride, void* stream);
+
+/* UnifiedVoice.forward(..., return_latent=True) (gpt/model.py:429-491) as called at vqvae/model_24k.py:796-799:
+ * teacher-forced pass over [cond | text | start, codes, stop]; codes HOST [B][n_max], ncodes HOST [B] ->
+ * latents_cm DEVICE [B,768,lat_stride] (columns 0..ncodes[b]-1). */
+int dtts_gpt_latents(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
+                     int Lt_max, const int* codes, const int* ncodes, int n_max, int B, float* latents_cm, int lat_stride,
+                     void* stream);
+
 /* ---- stage B: diffusion mel decoder ---------------------------------------------------------- */
 
 /* DiffusionTts.get_conditioning (vqvae/diff_model.py:221-229): refer [B,128,Tmax] -> cond [B,1536] */

@@ -1,0 +1,73 @@
+"""GPU parity: HIP stage A (conditioning encoder, GPT prefill + KV-cache decode, sampler) vs oracle + golden."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def rt(weights):
+    from detail_tts_amd.runtime import Runtime
+    return Runtime(weights, folded=True, parts=("gpt",))
+
+
+def test_conditioning_encoder_golden(rt, golden):
+    g = golden("mel_style")
+    out = host(rt.mel_style("gpt.conditioning_encoder", dev(g["refer"])))
+    assert maxabs(out, g["gpt_cond"][:, :, 0]) < 1e-4
+
+
+def test_teacher_forced_latents_golden(rt, golden):
+    g = golden("gpt_forced")
+    lat = host(rt.gpt_latents(dev(g["refer"]), None, [g["text"][0]], [g["codes"][0]]))
+    ref = g["latent"].transpose(0, 2, 1)
+    assert lat.shape == ref.shape
+    assert maxabs(lat, ref) < 2e-4, maxabs(lat, ref)
+
+
+def test_decode_latents_equal_teacher_forced_golden(rt, golden):
+    """KV-cache decode with forced tokens: the per-step hidden states are the reference's return_latent values."""
+    g = golden("gpt_forced")
+    n = g["codes"].shape[1]
+    codes, ncodes, lat = rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], 1, [0], max_generate_length=n + 1,
+                                         forced_codes=[g["codes"][0]])
+    assert np.array_equal(codes[0, :n], g["codes"][0])
+    assert codes[0, n] == 8193 and ncodes[0] == n + 1
+    assert maxabs(host(lat)[:, :, :n], g["latent"].transpose(0, 2, 1)) < 2e-4
+
+
+def test_generate_matches_reference_hf_loop(rt, golden):
+    """Free sampling under the Philox multinomial: same codes as the reference's HF generate() (golden)."""
+    g = golden("gpt_generate")
+    codes, ncodes, _ = rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], int(g["seed"]), [int(g["sample_id"])],
+                                       max_generate_length=10)
+    assert np.array_equal(codes[0], g["codes"][0]), (codes[0], g["codes"][0])
+
+
+@pytest.mark.parametrize("top_k", [50, 0])
+def test_generate_batch_varlen_vs_oracle(rt, weights, top_k):
+    from oracle import gpt as G
+    rs = np.random.RandomState(21)
+    refer = (rs.randn(2, 128, 50) * 2 - 5).astype(np.float32)
+    rl = [50, 33]
+    texts = [np.concatenate([rs.randint(3, 255, 9), [0]]), np.concatenate([rs.randint(3, 255, 5), [0]])]
+    codes, ncodes, lat = rt.gpt_generate(dev(refer), rl, texts, 5, [31, 32], max_generate_length=6, top_k=top_k)
+    for b in range(2):
+        ref, rlat = G.generate(weights, refer[b:b + 1, :, :rl[b]], [rl[b]], texts[b][None], 5, [31 + b], max_generate_length=6,
+                               top_k=top_k or None, return_latents=True)
+        assert np.array_equal(codes[b, :ref.shape[1]], ref[0]), (b, codes[b], ref)
+        assert maxabs(host(lat)[b, :, :ref.shape[1]], rlat[0].T) < 2e-4
