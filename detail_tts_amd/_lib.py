@@ -32,6 +32,11 @@ class DttsGptOptions(C.Structure):
                 ("forced_uniforms", C.c_void_p), ("forced_codes", c_int_p)]
 
 
+class DttsKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_longlong), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/detail_hip.h declares
 SIGNATURES = {
     "dtts_version": (C.c_char_p, []),
@@ -40,6 +45,8 @@ SIGNATURES = {
     "dtts_destroy": (C.c_int, [C.c_void_p]),
     "dtts_last_error": (C.c_char_p, [C.c_void_p]),
     "dtts_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), c_u64_p, c_u64_p, C.c_int, C.c_void_p]),
+    "dtts_profile_enable": (C.c_int, [C.c_int]),
+    "dtts_profile_report": (C.c_int, [C.POINTER(DttsKernelStat), C.c_int]),
     "dtts_gpt_generate": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int,
                                     C.POINTER(DttsGptOptions), c_int_p, c_int_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_gpt_latents": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int,

@@ -15,6 +15,7 @@
 // leaves registers.  K is staged K-major [D][64] (pitch 80) and V transposed [64][D+4] in LDS
 // so both A-operand reads are conflict-free ds_read_b32.
 #include "attention.h"
+#include "prof.h"
 
 namespace dtts {
 
@@ -188,6 +189,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 void launch_flash_attention(const AttnParams& p, hipStream_t stream) {
     DTTS_REQUIRE(p.B > 0 && p.H > 0 && p.T > 0, "empty attention");
     dim3 grid(cdiv(p.T, QPB), p.H, p.B);
+    const char* tag = p.D == 48 ? "flash_attn_kernel<48>" : p.D == 64 ? "flash_attn_kernel<64>" : p.D == 96 ? "flash_attn_kernel<96>" : "flash_attn_kernel<192>";
+    const double pairs = (double)p.B * p.H * (double)p.T * p.T * (p.causal ? 0.5 : 1.0);
+    ProfScope ps(tag, 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
     auto lds = [](int D) { return sizeof(float) * (size_t)(D * KPITCH + KT * (D + 4) + 2 * BIAS_CLIP + 1); };
     switch (p.D) {
         case 48: hipLaunchKernelGGL(flash_attn_kernel<48>, grid, dim3(256), lds(48), stream, p); break;

@@ -2,6 +2,7 @@
 #include <mutex>
 
 #include "model.h"
+#include "prof.h"
 
 using dtts::Model;
 
@@ -42,6 +43,28 @@ void dtts_default_config(dtts_config* c) {
     c->n_resblock_kernels = 3;
     const int rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
     for (int i = 0; i < 3; ++i) { c->resblock_kernels[i] = rk[i]; c->resblock_dilations[i] = rd[i]; }
+}
+
+int dtts_profile_enable(int on) {
+    dtts::Profiler::get().reset();
+    dtts::Profiler::get().on = on != 0;
+    return 0;
+}
+
+int dtts_profile_report(dtts_kernel_stat* out, int max_entries) {
+    auto v = dtts::Profiler::get().report();
+    int n = 0;
+    for (auto& st : v) {
+        if (n >= max_entries) break;
+        std::memset(&out[n], 0, sizeof(out[n]));
+        std::strncpy(out[n].name, st.name.c_str(), sizeof(out[n].name) - 1);
+        out[n].launches = st.launches;
+        out[n].total_ms = st.ms;
+        out[n].flops = st.flops;
+        out[n].bytes = st.bytes;
+        ++n;
+    }
+    return n;
 }
 
 int dtts_create(dtts_handle** out, const dtts_config* cfg, int device) {

@@ -10,6 +10,7 @@
 // through registers (double-buffered LDS, one barrier per K-step) because the input path applies
 // the fused prologue (GroupNorm affine + SiLU / leaky-relu, zero padding, per-sample length).
 #include "conv_gemm.h"
+#include "prof.h"
 
 namespace dtts {
 
@@ -202,14 +203,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_cfg(const ConvParams& p, hipStream_t stream) {
+static void launch_cfg(const ConvParams& p, hipStream_t stream, const char* tag) {
     const int XW = (BN - 1) * p.stride + (p.KW - 1) * p.dil + 1;
     DTTS_REQUIRE(XW <= XW_MAX, "conv input tile too wide for the staging registers");
     DTTS_REQUIRE(p.CoutP % BM == 0 && p.CinP % BK == 0, "packed weight padding");
     const size_t lds = sizeof(float) * (2 * BK * BM + 2 * BK * (XW + 1));
     dim3 grid(p.CoutP / BM, cdiv(p.Nout, BN), p.B);
     DTTS_REQUIRE(lds <= 64 * 1024, "conv LDS tile");
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds, stream, p);
+    {
+        // algorithmic work of this launch: 2*rows*Cin*KW MACs per output column; bytes = x + y (+res) + weights once
+        const double cols = (double)p.B * p.Nout;
+        const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;
+        const double bytes = 4.0 * (cols * p.stride * p.Cin + cols * p.Cout * (p.res ? 2.0 : 1.0) + (double)p.Cout * p.Cin * p.KW);
+        ProfScope ps(tag, flops, bytes, stream);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds, stream, p);
+    }
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -222,18 +230,18 @@ void launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     auto fits = [&](int bn) { return (bn - 1) * p.stride + halo + 1 <= XW_MAX; };
     if (p.CoutP % 128 == 0) {
         if (p.Nout >= 96 && fits(128) && (p.Nout % 128 == 0 || p.Nout % 128 > 64 || p.Nout >= 2048))
-            launch_cfg<128, 128, 2, 2>(p, stream);
+            launch_cfg<128, 128, 2, 2>(p, stream, "conv_gemm_kernel<128,128,2,2>");
         else {
             DTTS_REQUIRE(fits(64), "conv halo too large");
-            launch_cfg<128, 64, 2, 2>(p, stream);
+            launch_cfg<128, 64, 2, 2>(p, stream, "conv_gemm_kernel<128,64,2,2>");
         }
     } else if (p.CoutP % 64 == 0) {
-        if (fits(128) && p.Nout > 64) launch_cfg<64, 128, 2, 2>(p, stream);
-        else { DTTS_REQUIRE(fits(64), "conv halo too large"); launch_cfg<64, 64, 2, 2>(p, stream); }
+        if (fits(128) && p.Nout > 64) launch_cfg<64, 128, 2, 2>(p, stream, "conv_gemm_kernel<64,128,2,2>");
+        else { DTTS_REQUIRE(fits(64), "conv halo too large"); launch_cfg<64, 64, 2, 2>(p, stream, "conv_gemm_kernel<64,64,2,2>"); }
     } else {
         DTTS_REQUIRE(p.CoutP % 32 == 0, "CoutP must be a multiple of 32");
         DTTS_REQUIRE(fits(128), "conv halo too large");
-        launch_cfg<32, 128, 1, 4>(p, stream);
+        launch_cfg<32, 128, 1, 4>(p, stream, "conv_gemm_kernel<32,128,1,4>");
     }
 }
 

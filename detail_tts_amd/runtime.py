@@ -56,6 +56,8 @@ class Runtime:
         c.gpt_dim, c.gpt_layers, c.gpt_heads, c.gpt_mel_codes = g["model_dim"], g["layers"], g["heads"], g["number_mel_codes"]
         c.gpt_text_tokens = g["number_text_tokens"] + 1
         c.gpt_max_mel_pos, c.gpt_max_text_pos = g["max_mel_tokens"] + 3, g["max_text_tokens"] + 2
+        from .vqvae.utils.diffusion import space_timesteps
+        self.timestep_map = sorted(space_timesteps(4000, [50]))
         self.h = C.c_void_p()
         rc = self.lib.dtts_create(C.byref(self.h), C.byref(c), self.device.index or 0)
         if rc != 0:
@@ -78,6 +80,19 @@ class Runtime:
                                         self._offsets.ctypes.data_as(_lib.c_u64_p), self._numels.ctypes.data_as(_lib.c_u64_p),
                                         n, self._stream())
         self._rc(rc)
+
+    def profile_enable(self, on=True):
+        self.lib.dtts_profile_enable(1 if on else 0)
+
+    def profile_report(self):
+        arr = (_lib.DttsKernelStat * 64)()
+        n = self.lib.dtts_profile_report(arr, 64)
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops,
+                     bytes=arr[i].bytes) for i in range(n)]
+
+    def rebind(self):
+        """Re-run dtts_bind_weights on the current blob contents (after a broadcast)."""
+        self._bind(self._offsets, self._numels)
 
     def broadcast_weights(self, src=0):
         """One-time RCCL broadcast of the packed blob from rank `src` over xGMI."""

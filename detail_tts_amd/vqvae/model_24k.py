@@ -1,0 +1,127 @@
+"""SynthesizerTrn / Generator / do_spectrogram_diffusion mirrors (reference: vqvae/model_24k.py).
+
+`SynthesizerTrn.infer` keeps the reference signature (vqvae/model_24k.py:774) and its batch-1 behaviour by default;
+keyword-only extras select a real batch (`batch=True`: every row is an independent utterance, bit-for-bit what it
+would be alone), the noise seed / per-utterance stream ids, and forced codes (parity tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..config import COND_FREE_K, INFER_DIFFUSION_STEPS, MAX_GENERATE_LENGTH, MEL_MIN, NOISE_SCALE, REPETITION_PENALTY, TEMPERATURE, \
+    TOP_P, TORCH_MEL_MAX, TRAINED_DIFFUSION_STEPS, load_config
+from ..gpt.model import UnifiedVoice
+from ..runtime import Runtime
+from .diff_model import DiffusionTts
+from .utils.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+
+
+def normalize_torch_mel(mel):
+    return 2 * ((mel - MEL_MIN) / (TORCH_MEL_MAX - MEL_MIN)) - 1
+
+
+def denormalize_torch_mel(norm_mel):
+    return ((norm_mel + 1) / 2) * (TORCH_MEL_MAX - MEL_MIN) + MEL_MIN
+
+
+def do_spectrogram_diffusion(diffusion_model, diffuser, latents, conditioning_latents, temperature=1, verbose=True, *, seed=0,
+                             sample_ids=None, lengths=None):
+    """vqvae/model_24k.py:479-492: latents [B,n,768], conditioning_latents [B,1536] -> normalised mel [B,128,4n]"""
+    if temperature != 1:
+        raise NotImplementedError("temperature != 1 is not used by infer (vqvae/model_24k.py:803)")
+    out_len = latents.shape[1] * 4
+    emb = diffusion_model.timestep_independent(latents, conditioning_latents, out_len, False, lengths=lengths)
+    lens = None if lengths is None else [4 * int(n) for n in lengths]
+    mel = diffuser.p_sample_loop(diffusion_model, (latents.shape[0], 128, out_len), model_kwargs={"precomputed_aligned_embeddings": emb},
+                                 progress=verbose, seed=seed, sample_ids=sample_ids, lens=lens)
+    return mel[:, :, :out_len]
+
+
+class Generator:
+    """vqvae/model_24k.py:221-296"""
+
+    def __init__(self, rt):
+        self.rt = rt
+
+    def forward(self, x, g=None, lengths=None):
+        if g is None:
+            raise NotImplementedError("the inference path always conditions the generator on g (gin_channels=768)")
+        return self.rt.generator(x.float().contiguous(), g.reshape(g.shape[0], -1).float().contiguous(), lengths)
+
+    __call__ = forward
+
+
+class SynthesizerTrn:
+    def __init__(self, state, cfg=None, device="cuda:0", folded=False):
+        self.cfg = load_config(cfg)
+        self.rt = Runtime(state, self.cfg, device=device, folded=folded)
+        self.device = self.rt.device
+        self.gpt = UnifiedVoice(self.rt, self.cfg["gpt"])
+        self.diffusion = DiffusionTts(self.rt, self.cfg["diffusion"])
+        self.dec = Generator(self.rt)
+        self.infer_diffuser = SpacedDiffusion(space_timesteps(TRAINED_DIFFUSION_STEPS, [INFER_DIFFUSION_STEPS]),
+                                              betas=get_named_beta_schedule("linear", TRAINED_DIFFUSION_STEPS),
+                                              conditioning_free=True, conditioning_free_k=COND_FREE_K)
+        self.rt.timestep_map = list(self.infer_diffuser.timestep_map)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise NotImplementedError("re-create the model on the target device (weights are bound to one GPU)")
+        return self
+
+    # ------------------------------------------------------------------------------------------------------------
+    def infer(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
+              forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False, return_lengths=False):
+        """vqvae/model_24k.py:774-810.  Returns wav [B,1,1024*n_max] (B=1 unless batch=True)."""
+        text = torch.as_tensor(text)
+        refer = torch.as_tensor(refer)
+        tl = torch.as_tensor(text_length).reshape(-1).tolist()
+        rl = torch.as_tensor(refer_lengths).reshape(-1).tolist()
+        if not batch:                                             # reference: text = text[0].unsqueeze(0) ... (:775-778)
+            text, refer, tl, rl = text[:1], refer[:1], tl[:1], rl[:1]
+            if forced_codes is not None:
+                forced_codes = forced_codes[:1]
+        B = text.shape[0]
+        refer = refer.to(self.device, torch.float32).contiguous()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        sample_ids = list(range(B)) if sample_ids is None else list(sample_ids)
+        texts = [text[b, : int(tl[b])].cpu().numpy().astype(np.int32) for b in range(B)]
+        rl = [int(v) for v in rl]
+        # ---- stage A: codes + latents (:782-799)
+        if forced_codes is None:
+            codes, ncodes, lat = self.rt.gpt_generate(refer, rl, texts, seed, sample_ids, max_generate_length=max_generate_length,
+                                                      top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
+                                                      repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
+            n = [int(c) - 1 for c in ncodes]                       # codes = codes[:, :-1]  (:795)
+            if min(n) < 1:
+                raise ValueError("an utterance produced no mel codes (stop token first)")
+            lat = lat[:, :, : max(n)].contiguous()                 # decode-time latents == return_latent pass
+        else:
+            n = [len(c) for c in forced_codes]
+            lat = self.rt.gpt_latents(refer, rl, texts, forced_codes)
+        # ---- stage B (:802-804)
+        cond = self.rt.diff_conditioning(refer, rl)
+        code_emb = self.rt.diff_timestep_independent(lat, cond, n)
+        lens_t = [4 * v for v in n]
+        mel = self.rt.diff_sample(code_emb, seed, sample_ids, lens=lens_t, denorm=True)
+        # ---- stage C (:805-809)
+        wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
+        if return_lengths:
+            return wav, [1024 * v for v in n]
+        return wav
+
+    def infer_flowvae(self, y, y_lengths, data=None, noise_scale=NOISE_SCALE, *, batch=False, seed=0, sample_ids=None):
+        """vqvae/model_24k.py:848-863"""
+        y = torch.as_tensor(y)
+        yl = [int(v) for v in torch.as_tensor(y_lengths).reshape(-1).tolist()]
+        if not batch:
+            y, yl = y[:1], yl[:1]
+        assert y.shape[-1] % 4 == 0
+        y = y.to(self.device, torch.float32).contiguous()
+        sample_ids = list(range(y.shape[0])) if sample_ids is None else list(sample_ids)
+        return self.rt.vocoder(y, seed, sample_ids, lens=yl, noise_scale=noise_scale)

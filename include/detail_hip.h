@@ -154,6 +154,19 @@ int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* le
  * mel [B,128,T] -> g [B,768] */
 int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const int* lens, int B, int T, float* g_out, void* stream);
 
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+/* Per-launch hipEvent profiling of the MFMA kernels (conv GEMM, flash attention), recorded on the launch stream.
+ * enable(1) resets the totals; report() synchronises and returns the number of entries written. */
+typedef struct dtts_kernel_stat {
+    char name[64];
+    long long launches;
+    double total_ms;    /* sum of per-launch hipEvent durations */
+    double flops;       /* algorithmic FLOPs of those launches */
+    double bytes;       /* algorithmic bytes (inputs + outputs + weights once) */
+} dtts_kernel_stat;
+int dtts_profile_enable(int on);
+int dtts_profile_report(dtts_kernel_stat* out, int max_entries);
+
 /* ---- unit entry points for parity tests ------------------------------------------------------- */
 /* AttentionBlock.forward (vqvae/utils/diff_util.py:209-215) of the block whose weights start with `prefix` */
 int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T,
