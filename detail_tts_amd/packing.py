@@ -67,6 +67,8 @@ def convtranspose_as_phases(w, stride, padding):
     """w [Cin, Cout, k] -> (w_eq [stride*Cout, Cin, KW], pad) for the phase decomposition."""
     w = np.asarray(w, F32)
     cin, cout, k = w.shape
+    if k - stride != 2 * padding:
+        raise ValueError("only ConvTranspose1d with output length == T*stride (k - s == 2p, as in Generator.ups) is supported")
     dmin = -((k - 1 - padding) // stride)           # ceil((p-k+1)/s)
     dmax = (stride - 1 + padding) // stride
     kw = dmax - dmin + 1

@@ -1,0 +1,199 @@
+"""CPU tests: host logic, packer layouts (checked against the oracle's conv arithmetic), C-ABI exports, N>1 sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_and_hparams():
+    from detail_tts_amd.config import HParams, load_config
+    cfg = load_config({"diffusion": {"g_channels": 768, "num_layers": 10}})
+    assert "g_channels" not in cfg["diffusion"] and cfg["diffusion"]["model_channels"] == 768
+    h = HParams(**cfg)
+    assert h.data.hop_length == 256 and h["vaegan"]["upsample_rates"] == [8, 4, 2, 2, 2] and "gpt" in h
+
+
+def test_reference_config_file_matches_defaults():
+    ref = "/root/reference/vqvae/configs/config_24k.json"
+    if not os.path.exists(ref):
+        pytest.skip("reference not present (GPU box)")
+    from detail_tts_amd.config import DEFAULT_CONFIG, load_config
+    cfg = load_config(ref)
+    for blk in ("diffusion", "gpt"):
+        for k, v in DEFAULT_CONFIG[blk].items():
+            assert cfg[blk][k] == v, (blk, k)
+    for k, v in DEFAULT_CONFIG["vaegan"].items():
+        assert cfg["vaegan"][k] == v, k
+
+
+def test_weight_spec_counts():
+    from detail_tts_amd.weights import folded_param_names, inference_param_spec
+    spec = inference_param_spec()
+    n = sum(int(np.prod(s)) for s, _ in spec.values())
+    assert abs(n - 266.355e6) < 1e4           # 266.35 M unique inference parameters
+    assert len(folded_param_names()) == len(spec) - sum(k.endswith(".weight_v") for k in spec)
+
+
+def test_fold_weight_norm_matches_torch():
+    torch = pytest.importorskip("torch")
+    from detail_tts_amd.weights import fold_weight_norm
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(6, 10, 5))
+    convt = torch.nn.utils.weight_norm(torch.nn.ConvTranspose1d(6, 4, 8, 4, padding=2))
+    with torch.no_grad():
+        conv.weight_g.mul_(1.7)
+        convt.weight_g.mul_(0.6)
+    sd = {"a." + k: v for k, v in conv.state_dict().items()}
+    sd.update({"b." + k: v for k, v in convt.state_dict().items()})
+    f = fold_weight_norm(sd)
+    x = torch.randn(1, 6, 20)
+    with torch.no_grad():
+        wa = conv(x)
+        ref = torch.nn.functional.conv1d(x, torch.from_numpy(f["a.weight"]), torch.from_numpy(f["a.bias"]))
+        assert torch.allclose(wa, ref, atol=1e-5)
+        wb = convt(x)
+        refb = torch.nn.functional.conv_transpose1d(x, torch.from_numpy(f["b.weight"]), torch.from_numpy(f["b.bias"]), stride=4, padding=2)
+        assert torch.allclose(wb, refb, atol=1e-5)
+
+
+def _packed_conv_ref(x, wp, bp, cout, kw, pad, dil=1, stride=1):
+    """numpy emulation of the kernel's GEMM over a packed weight wp[k][CinP][CoutP]."""
+    B, cin, T = x.shape
+    xp = np.pad(x, ((0, 0), (0, wp.shape[1] - cin), (pad, pad)))
+    nout = (T + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    y = np.zeros((B, wp.shape[2], nout), np.float64)
+    for tap in range(kw):
+        seg = xp[:, :, tap * dil: tap * dil + (nout - 1) * stride + 1: stride]
+        y += np.einsum("kc,bkt->bct", wp[tap].astype(np.float64), seg)
+    if bp is not None:
+        y += bp[None, :, None]
+    return y[:, :cout]
+
+
+def test_pack_conv_layout_against_oracle():
+    from detail_tts_amd.packing import pack_conv
+    from oracle import ops
+    rs = np.random.RandomState(0)
+    w, b = rs.randn(37, 21, 5).astype(np.float32), rs.randn(37).astype(np.float32)
+    x = rs.randn(2, 21, 33).astype(np.float32)
+    wp, bp = pack_conv(w, b)
+    assert wp.shape == (5, 32, 64) and bp.shape == (64,)
+    np.testing.assert_allclose(_packed_conv_ref(x, wp, bp, 37, 5, 2), ops.conv1d(x, w, b, padding=2), atol=1e-4)
+
+
+def test_convtranspose_phase_decomposition_against_oracle():
+    from detail_tts_amd.packing import convtranspose_as_phases, pack_conv
+    from oracle import ops
+    rs = np.random.RandomState(1)
+    for (cin, cout, k, s, p) in [(10, 6, 16, 8, 4), (7, 5, 8, 4, 2), (9, 4, 2, 2, 0), (5, 3, 6, 2, 2)]:
+        w, b = rs.randn(cin, cout, k).astype(np.float32), rs.randn(cout).astype(np.float32)
+        x = rs.randn(2, cin, 19).astype(np.float32)
+        weq, pad = convtranspose_as_phases(w, s, p)
+        wp, bp = pack_conv(weq, np.tile(b, s))
+        ref = ops.conv_transpose1d(x, w, b, stride=s, padding=p)
+        rows = _packed_conv_ref(x, wp, bp, s * cout, weq.shape[2], pad)        # [B, s*cout, nq]
+        nq = rows.shape[2]
+        y = rows.reshape(2, s, cout, nq).transpose(0, 2, 3, 1).reshape(2, cout, nq * s)
+        assert y.shape == ref.shape
+        np.testing.assert_allclose(y, ref, atol=1e-4)
+
+
+def test_gate_perm_and_bias_table():
+    from detail_tts_amd.packing import bias_table, gate_perm, rel_bucket
+    from oracle import diffusion as D
+    p = gate_perm(8)
+    assert p.tolist() == [0, 4, 1, 5, 2, 6, 3, 7]
+    emb = np.random.RandomState(2).randn(32, 16).astype(np.float32)
+    tab = bias_table(emb, 48)
+    full = D.rel_bias(emb, 200, 48 ** 0.5)            # [H, T, T]
+    i, j = np.meshgrid(np.arange(200), np.arange(200), indexing="ij")
+    off = np.clip(j - i, -64, 64) + 64
+    np.testing.assert_allclose(tab[:, off], full, rtol=0, atol=0)
+    assert np.array_equal(rel_bucket(np.arange(-300, 300)), D.rel_bucket(np.arange(-300, 300)))
+
+
+def test_schedule_mirror_matches_oracle():
+    from detail_tts_amd.vqvae.utils.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+    from oracle import diffusion as D
+    d = SpacedDiffusion(space_timesteps(4000, [50]), betas=get_named_beta_schedule("linear", 4000))
+    s = D.make_schedule()
+    assert d.timestep_map == s["timestep_map"].tolist() and d.num_timesteps == 50
+    np.testing.assert_allclose(d.betas, s["betas"], rtol=1e-13)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libdetail_hip.so loads without a GPU and exports exactly what include/detail_hip.h declares."""
+    from detail_tts_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libdetail_hip.so not built (run __graft_entry__.build())")
+    hdr = open(os.path.join(ROOT, "include", "detail_hip.h")).read()
+    declared = set(re.findall(r"\b(dtts_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dtts_version()
+    cfg = _lib.DttsConfig()
+    lib.dtts_default_config(ctypes.byref(cfg))
+    assert (cfg.diff_channels, cfg.diff_steps, cfg.gpt_mel_codes, cfg.upsample_rates[0]) == (768, 50, 8194, 8)
+
+
+def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
+    from detail_tts_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.load()
+
+
+def test_product_path_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "detail_tts_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
+
+
+def test_shard_utterances_balanced():
+    from detail_tts_amd.sharding import shard_utterances
+    lens = [234] * 64
+    sh = shard_utterances(lens, 8)
+    assert sorted(sum(sh, [])) == list(range(64)) and all(len(s) == 8 for s in sh)
+    sh = shard_utterances([100, 900, 300, 500, 700], 2)
+    loads = [sum([100, 900, 300, 500, 700][i] for i in s) for s in sh]
+    assert abs(loads[0] - loads[1]) <= 300
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from detail_tts_amd.sharding import broadcast_blob, gather_results, shard_utterances
+    blob = torch.arange(1000, dtype=torch.float32) if rank == 0 else torch.zeros(1000)
+    broadcast_blob(blob, src=0)
+    mine = shard_utterances([234] * 6, world)[rank]
+    allr = gather_results([(i, rank) for i in mine], world)
+    q.put((rank, float(blob.sum()), mine, allr))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_weight_broadcast_and_sharding():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert all(abs(r[1] - 499500.0) < 1e-3 for r in res)                 # both ranks hold rank 0's blob
+    assert sorted(res[0][2] + res[1][2]) == list(range(6))                 # disjoint cover of the utterances
+    assert res[0][3] == res[1][3] and len(sum(res[0][3], [])) == 6         # no data-path collective needed beyond this
