@@ -47,6 +47,7 @@ struct ConvParams {
     int Nout = 0;                  // number of GEMM columns per sample (max)
     int phases = 1;                // ConvTranspose: packed row = ph*Cout + co, t_out = n*phases + ph
     int B = 0;
+    int ablate = 0;                // experiments only (DTTS_CONV_ABLATE): 1 skip global loads, 2 skip LDS stores, 4 skip barriers
 };
 
 void launch_conv_gemm(const ConvParams& p, hipStream_t stream);

@@ -9,33 +9,49 @@
 // read is a conflict-free ds_read_b32 of 32 consecutive floats per lane-half.  Global->LDS goes
 // through registers (double-buffered LDS, one barrier per K-step) because the input path applies
 // the fused prologue (GroupNorm affine + SiLU / leaky-relu, zero padding, per-sample length).
+#include <cstdlib>
 #include "conv_gemm_kernel.h"
 
 namespace dtts {
 
-constexpr int _unused_bk = BK;
+// Tile choice.  DTTS_CONV_BN / DTTS_CONV_BK (environment) force a shape for experiments.
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 
-void launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
+void launch_conv_gemm(const ConvParams& p_in, hipStream_t stream) {
+    static const int ablate = env_int("DTTS_CONV_ABLATE");
+    ConvParams p = p_in;
+    p.ablate = ablate;
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0 && p.Cin > 0, "empty conv");
     DTTS_REQUIRE(p.x && p.w && p.y, "null pointer");
     DTTS_REQUIRE(p.gate == GATE_NONE || p.phases == 1, "gate+phases unsupported");
-    // pick the N tile: wide tiles when the input halo allows it and there are enough columns
+    static const int force_bn = env_int("DTTS_CONV_BN"), force_bk = env_int("DTTS_CONV_BK");
     const int halo = (p.KW - 1) * p.dil;
     auto fits = [&](int bn) { return (bn - 1) * p.stride + halo + 1 <= XW_MAX; };
+    const bool bk32 = (p.CinP % 32 == 0) && force_bk == 32 && p.KW * p.dil <= 3;   // measured slower than BK=16: opt-in only
     if (p.CoutP % 128 == 0) {
-        if (p.Nout >= 96 && fits(128) && (p.Nout % 128 == 0 || p.Nout % 128 > 64 || p.Nout >= 2048))
-            launch_conv_tile<128, 128, 2, 2>(p, stream, "conv_gemm_kernel<128,128,2,2>");
-        else {
+        // BN=128 has the better MFMA:staging ratio; take it unless the ragged tail wastes more than ~10 % of the columns
+        const int pad128 = round_up(p.Nout, 128), pad64 = round_up(p.Nout, 64);
+        bool wide = fits(128) && (pad128 - pad64) * 10 <= p.Nout;
+        if (force_bn == 128 && fits(128)) wide = true;
+        if (force_bn == 64) wide = false;
+        if (wide) {
+            if (bk32) launch_conv_tile<128, 128, 2, 2, 32>(p, stream, "conv_gemm_kernel<128,128,k32>");
+            else launch_conv_tile<128, 128, 2, 2, 16>(p, stream, "conv_gemm_kernel<128,128,k16>");
+        } else {
             DTTS_REQUIRE(fits(64), "conv halo too large");
-            launch_conv_tile<128, 64, 2, 2>(p, stream, "conv_gemm_kernel<128,64,2,2>");
+            if (bk32) launch_conv_tile<128, 64, 2, 2, 32>(p, stream, "conv_gemm_kernel<128,64,k32>");
+            else launch_conv_tile<128, 64, 2, 2, 16>(p, stream, "conv_gemm_kernel<128,64,k16>");
         }
     } else if (p.CoutP % 64 == 0) {
-        if (fits(128) && p.Nout > 64) launch_conv_tile<64, 128, 2, 2>(p, stream, "conv_gemm_kernel<64,128,2,2>");
-        else { DTTS_REQUIRE(fits(64), "conv halo too large"); launch_conv_tile<64, 64, 2, 2>(p, stream, "conv_gemm_kernel<64,64,2,2>"); }
+        if (fits(128) && p.Nout > 64) launch_conv_tile<64, 128, 2, 2, 16>(p, stream, "conv_gemm_kernel<64,128,k16>");
+        else { DTTS_REQUIRE(fits(64), "conv halo too large"); launch_conv_tile<64, 64, 2, 2, 16>(p, stream, "conv_gemm_kernel<64,64,k16>"); }
     } else {
         DTTS_REQUIRE(p.CoutP % 32 == 0, "CoutP must be a multiple of 32");
         DTTS_REQUIRE(fits(128), "conv halo too large");
-        launch_conv_tile<32, 128, 1, 4>(p, stream, "conv_gemm_kernel<32,128,1,4>");
+        launch_conv_tile<32, 128, 1, 4, 16>(p, stream, "conv_gemm_kernel<32,128,k16>");
     }
 }
 

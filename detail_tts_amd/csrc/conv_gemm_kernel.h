@@ -9,14 +9,14 @@ __device__ __forceinline__ float silu_fast(float v) { return v * __frcp_rn(1.f +
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
 constexpr int XCOLS = 3;       // column iterations of 64 lanes -> XW <= 192
 constexpr int XW_MAX = 64 * XCOLS;
 
 // PRO: 0 raw input | 1 affine + SiLU | 2 affine only | 3 leaky-relu (no affine) | 4 SiLU (no affine)
 // EPI: 0 linear (bias, per-sample rows, scale, residual, polyphase scatter) | 1 + generic activation | 2 gated pair
-template <int BM, int BN, int WGM, int WGN, int PRO, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BK, int PRO, int EPI>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    constexpr int XR = BK / 4;                        // channel rows staged per wave
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -48,8 +48,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int nCb = p.CinP / BK;
     const int S = nCb * p.KW;
 
-    float4 wreg[WLOADS];
-    float xreg[4 * XCOLS];
+    float xreg[XR * XCOLS];
 
     // ---- branch-free staging: every load is unconditional on a clamped address, masking happens by select at store
     // time, so all loads of a K-step are in flight together and land behind the MFMA section.
@@ -64,29 +63,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         xok |= (ok ? 1u : 0u) << c;
         xoff[c] = min(max(t, 0), lin_c);
     }
-    const int wrow0 = tid / (BM / 4), wc4 = tid - wrow0 * (BM / 4);      // weight tile: WLOADS rows apart by 256/(BM/4)
-    constexpr int WROW_STEP = 256 / (BM / 4) > 0 ? 256 / (BM / 4) : 1;
-
-    auto load_w = [&](int cb, int tap) {
-        const float* wp = p.w + ((long long)(tap * p.CinP + cb * BK + wrow0)) * p.CoutP + m0 + wc4 * 4;
+    // weight tile: LDS-DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write.  The tile is [BK][BM] row-major in
+    // LDS == lane-linear: float4 #idx of the tile goes to byte offset 16*idx, one wave-instruction fills 1 KiB.
+    auto load_w = [&](int cb, int tap, int buf) {
+        const float* wp = p.w + ((long long)(tap * p.CinP + cb * BK)) * p.CoutP + m0;
+        float* lbase = Ws + buf * BK * BM;
 #pragma unroll
-        for (int i = 0; i < WLOADS; ++i)
-            if (WV4 > 0 || tid < BK * BM / 4) wreg[i] = *reinterpret_cast<const float4*>(wp + (long long)(i * WROW_STEP) * p.CoutP);
-    };
-    auto store_w = [&](int buf) {
-        float* dst = Ws + buf * BK * BM + wrow0 * BM + wc4 * 4;
-#pragma unroll
-        for (int i = 0; i < WLOADS; ++i)
-            if (WV4 > 0 || tid < BK * BM / 4) *reinterpret_cast<float4*>(dst + i * WROW_STEP * BM) = wreg[i];
+        for (int i = 0; i < WLOADS; ++i) {
+            const int idx = tid + i * 256;
+            if (WV4 > 0 || (wave * 64 < BK * BM / 4)) {
+                const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
+                const float* g = wp + (long long)row * p.CoutP + c4 * 4;
+                float* l = lbase + (wave * 64 + i * 256) * 4;      // wave-uniform base; hardware adds lane*16
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+            }
+        }
     };
     // each wave stages 4 of the 16 channel rows; lanes stride over columns
-    float pa[4], pd[4];
+    float pa[XR], pd[XR];
     unsigned rok = 0;
     auto load_x = [&](int cb) {
         rok = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ci = cb * BK + wave * 4 + r;
+        for (int r = 0; r < XR; ++r) {
+            const int ci = cb * BK + wave * XR + r;
             const bool cok = ci < p.Cin;
             const int cic = cok ? ci : p.Cin - 1;
             rok |= (cok ? 1u : 0u) << r;
@@ -98,9 +99,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         }
     };
     auto store_x = [&](int buf) {
-        float* dst = Xs + buf * BK * XWP + (wave * 4) * XWP + lane;
+        float* dst = Xs + buf * BK * XWP + (wave * XR) * XWP + lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < XR; ++r)
 #pragma unroll
             for (int c = 0; c < XCOLS; ++c) {
                 if (c > 0 && 64 * c >= XWP) continue;                          // wave-uniform
@@ -126,9 +127,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int wn0 = (wave % WGN) * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    load_w(0, 0);
+    load_w(0, 0, 0);
     load_x(0);
-    store_w(0);
     store_x(0);
     __syncthreads();
 
@@ -138,29 +138,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         int ntap = tap + 1, ncb = cb;
         if (ntap == p.KW) { ntap = 0; ncb = cb + 1; }
         const bool newx = has_next && (ncb != cb);
-        if (has_next) load_w(ncb, ntap);
-        if (newx) load_x(ncb);
+        if (has_next && !(p.ablate & 1)) load_w(ncb, ntap, (s + 1) & 1);
+        if (newx && !(p.ablate & 1)) load_x(ncb);
 
-        const float* wsb = Ws + (s & 1) * BK * BM + wm0 + l31;
-        const float* xsb = Xs + (cb & 1) * BK * XWP + (wn0 + l31) * p.stride + tap * p.dil;
+        const float* wq = Ws + (s & 1) * BK * BM + lhi * BM + wm0 + l31;
+        const float* xq = Xs + (cb & 1) * BK * XWP + lhi * XWP + (wn0 + l31) * p.stride + tap * p.dil;
+        const int xw2 = 2 * XWP, nstep = 32 * p.stride;
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], bv[TN];
-            const int krow = kk * 2 + lhi;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = wsb[krow * BM + i * 32];
+            for (int i = 0; i < TM; ++i) af[kk][i] = wq[kk * 2 * BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = xsb[krow * XWP + j * 32 * p.stride];
+            for (int j = 0; j < TN; ++j) bf[kk][j] = xq[kk * xw2 + j * nstep];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
 
-        if (has_next) store_w((s + 1) & 1);
-        if (newx) store_x(ncb & 1);
-        __syncthreads();
+        if (newx && !(p.ablate & 2)) store_x(ncb & 1);
+        if (!(p.ablate & 4)) __syncthreads();
         cb = ncb;
         tap = ntap;
     }
@@ -211,23 +212,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 }
 
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK>
 void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
 
 // one translation unit per tile shape instantiates the PRO x EPI grid
-#define DTTS_INSTANTIATE_CONV_TILE(BM, BN, WGM, WGN)                                                                      \
+#define DTTS_INSTANTIATE_CONV_TILE(BM, BN, WGM, WGN, BK)                                                                      \
     template <int PRO, int EPI>                                                                                           \
-    static void launch_pe_##BM##_##BN(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {                   \
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, PRO, EPI>), grid, dim3(256), lds, stream, p);             \
+    static void launch_pe_##BM##_##BN##_##BK(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {                   \
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI>), grid, dim3(256), lds, stream, p);             \
     }                                                                                                                     \
     template <int PRO>                                                                                                    \
-    static void launch_p_##BM##_##BN(const ConvParams& p, int epi, dim3 grid, size_t lds, hipStream_t stream) {           \
-        if (epi == 0) launch_pe_##BM##_##BN<PRO, 0>(p, grid, lds, stream);                                                \
-        else if (epi == 1) launch_pe_##BM##_##BN<PRO, 1>(p, grid, lds, stream);                                           \
-        else launch_pe_##BM##_##BN<PRO, 2>(p, grid, lds, stream);                                                         \
+    static void launch_p_##BM##_##BN##_##BK(const ConvParams& p, int epi, dim3 grid, size_t lds, hipStream_t stream) {           \
+        if (epi == 0) launch_pe_##BM##_##BN##_##BK<PRO, 0>(p, grid, lds, stream);                                                \
+        else if (epi == 1) launch_pe_##BM##_##BN##_##BK<PRO, 1>(p, grid, lds, stream);                                           \
+        else launch_pe_##BM##_##BN##_##BK<PRO, 2>(p, grid, lds, stream);                                                         \
     }                                                                                                                     \
     template <>                                                                                                           \
-    void launch_conv_tile<BM, BN, WGM, WGN>(const ConvParams& p, hipStream_t stream, const char* tag) {                   \
+    void launch_conv_tile<BM, BN, WGM, WGN, BK>(const ConvParams& p, hipStream_t stream, const char* tag) {                   \
         const int XW = (BN - 1) * p.stride + (p.KW - 1) * p.dil + 1;                                                      \
         DTTS_REQUIRE(XW <= XW_MAX, "conv input tile too wide for the staging registers");                                 \
         DTTS_REQUIRE(p.CoutP % BM == 0 && p.CinP % BK == 0, "packed weight padding");                                     \
@@ -245,11 +246,11 @@ void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
         const double bytes = 4.0 * (cols * p.stride * p.Cin + cols * p.Cout * (p.res ? 2.0 : 1.0) + (double)p.Cout * p.Cin * p.KW); \
         {                                                                                                                 \
             ProfScope ps(tag, flops, bytes, stream);                                                                      \
-            if (pro == 0) launch_p_##BM##_##BN<0>(p, epi, grid, lds, stream);                                             \
-            else if (pro == 1) launch_p_##BM##_##BN<1>(p, epi, grid, lds, stream);                                        \
-            else if (pro == 2) launch_p_##BM##_##BN<2>(p, epi, grid, lds, stream);                                        \
-            else if (pro == 3) launch_p_##BM##_##BN<3>(p, epi, grid, lds, stream);                                        \
-            else launch_p_##BM##_##BN<4>(p, epi, grid, lds, stream);                                                      \
+            if (pro == 0) launch_p_##BM##_##BN##_##BK<0>(p, epi, grid, lds, stream);                                             \
+            else if (pro == 1) launch_p_##BM##_##BN##_##BK<1>(p, epi, grid, lds, stream);                                        \
+            else if (pro == 2) launch_p_##BM##_##BN##_##BK<2>(p, epi, grid, lds, stream);                                        \
+            else if (pro == 3) launch_p_##BM##_##BN##_##BK<3>(p, epi, grid, lds, stream);                                        \
+            else launch_p_##BM##_##BN##_##BK<4>(p, epi, grid, lds, stream);                                                      \
         }                                                                                                                 \
         DTTS_CHECK_HIP(hipGetLastError());                                                                                \
     }

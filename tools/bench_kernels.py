@@ -24,9 +24,12 @@ for i, (cin, cout, k, pad) in enumerate(shapes):
 r = Runtime({}, parts=(), extra=extra)
 for i, (cin, cout, k, pad) in enumerate(shapes):
     x = torch.randn(B, cin, T, device="cuda")
-    dt = timeit(lambda: r.op_conv1d(f"c{i}", x, cout, k, pad=pad))
-    fl = 2.0 * cin * cout * k * B * T
-    print(f"conv {cin:4d}->{cout:4d} k{k} B{B} T{T}: {dt*1e6:8.1f} us  {fl/dt/1e12:6.1f} TFLOP/s")
+    for _ in range(3): r.op_conv1d(f"c{i}", x, cout, k, pad=pad)
+    r.profile_enable(True)
+    for _ in range(10): r.op_conv1d(f"c{i}", x, cout, k, pad=pad)
+    for st in r.profile_report():
+        print(f"conv {cin:4d}->{cout:4d} k{k} B{B} T{T}: {st['name']:32s} {st['total_ms']/st['launches']*1e3:8.1f} us  {st['flops']/st['total_ms']/1e9:6.1f} TFLOP/s")
+    r.profile_enable(False)
 if os.environ.get("ATTN", "1") == "1":
     from detail_tts_amd.weights import select_inference_params, synthetic_state_dict
     W = select_inference_params(synthetic_state_dict(0, only_prefixes=["diffusion.layers.3."]))
