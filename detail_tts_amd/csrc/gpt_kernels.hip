@@ -139,12 +139,24 @@ void launch_gemv_partial(const float* W, int K, int CoutP, const float* x, int x
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-__global__ void gemv_finish_kernel(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act,
-                                   const float* res, int res_stride, float* y, int y_stride) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (col >= Cout) return;
-    float v = bias ? bias[col] : 0.f;
-    for (int sl = 0; sl < slices; ++sl) v += part[((long long)sl * B + b) * CoutP + col];
+// finish: 64 columns x 4 slice-groups per 256-thread block; group g sums slices g, g+4, ... then an LDS combine.
+__device__ __forceinline__ float finish_sum(const float* part, int slices, int B, int CoutP, int b, int col, float* red) {
+    const int g = threadIdx.x >> 6;
+    float v = 0.f;
+    for (int sl = g; sl < slices; sl += 4) v += part[((long long)sl * B + b) * CoutP + col];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    return red[threadIdx.x & 63] + red[64 + (threadIdx.x & 63)] + red[128 + (threadIdx.x & 63)] + red[192 + (threadIdx.x & 63)];
+}
+
+__global__ __launch_bounds__(256) void gemv_finish_kernel(const float* part, int slices, int B, int Cout, int CoutP, const float* bias,
+                                                          int act, const float* res, int res_stride, float* y, int y_stride) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y;
+    const int colc = col < CoutP ? col : CoutP - 1;
+    float v = finish_sum(part, slices, B, CoutP, b, colc, red);
+    if (threadIdx.x >= 64 || col >= Cout) return;
+    if (bias) v += bias[col];
     v = act_apply(v, act, 0.f);
     if (res) v += res[(long long)b * res_stride + col];
     y[(long long)b * y_stride + col] = v;
@@ -152,92 +164,99 @@ __global__ void gemv_finish_kernel(const float* part, int slices, int B, int Cou
 
 void launch_gemv_finish(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act, const float* res,
                         int res_stride, float* y, int y_stride, hipStream_t s) {
-    hipLaunchKernelGGL(gemv_finish_kernel, dim3(cdiv(Cout, 256), B), dim3(256), 0, s, part, slices, B, Cout, CoutP, bias, act, res,
+    hipLaunchKernelGGL(gemv_finish_kernel, dim3(cdiv(Cout, 64), B), dim3(256), 0, s, part, slices, B, Cout, CoutP, bias, act, res,
                        res_stride, y, y_stride);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-__global__ void gemv_finish_qkv_kernel(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf,
-                                       float* cache, long long cache_bs, int cache_cs, const int* pos) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (col >= 3 * C) return;
-    float v = bias[col];
-    for (int sl = 0; sl < slices; ++sl) v += part[((long long)sl * B + b) * CoutP + col];
+// cache layout per (layer, sample): K [C][cap] (channel-major, keys contiguous) then V [cap][C] (token-major)
+__global__ __launch_bounds__(256) void gemv_finish_qkv_kernel(const float* part, int slices, int B, int C, int CoutP, const float* bias,
+                                                              float* qbuf, float* cache, long long cache_bs, int cap, const int* pos) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y;
+    float v = finish_sum(part, slices, B, CoutP, b, col < CoutP ? col : CoutP - 1, red);
+    if (threadIdx.x >= 64 || col >= 3 * C) return;
+    v += bias[col];
+    float* cb = cache + (long long)b * cache_bs;
     if (col < C) qbuf[(long long)b * C + col] = v;
-    else cache[(long long)b * cache_bs + (long long)(col - C) * cache_cs + pos[b]] = v;
+    else if (col < 2 * C) cb[(long long)(col - C) * cap + pos[b]] = v;
+    else cb[(long long)C * cap + (long long)pos[b] * C + (col - 2 * C)] = v;
 }
 
 void launch_gemv_finish_qkv(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf, float* cache,
                             long long cache_bs, int cache_cs, const int* pos, hipStream_t s) {
-    hipLaunchKernelGGL(gemv_finish_qkv_kernel, dim3(cdiv(3 * C, 256), B), dim3(256), 0, s, part, slices, B, C, CoutP, bias, qbuf, cache,
+    hipLaunchKernelGGL(gemv_finish_qkv_kernel, dim3(cdiv(3 * C, 64), B), dim3(256), 0, s, part, slices, B, C, CoutP, bias, qbuf, cache,
                        cache_bs, cache_cs, pos);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------ decode attention
 template <int D>
-__global__ __launch_bounds__(64) void decode_attention_kernel(const float* qbuf, const float* cache, long long cache_bs, int cache_cs,
-                                                              const int* klen, int H, float* out) {
-    extern __shared__ float sc[];
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void decode_attention_kernel(const float* qbuf, const float* cache, long long cache_bs, int cap,
+                                                               const int* klen, int H, float* out) {
+    extern __shared__ float sc[];            // [cap] scores / probabilities
+    __shared__ float red[4];
+    __shared__ float part[4][D];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = H * D;
     const int n = klen[b];
-    const float* kp = cache + (long long)b * cache_bs + (long long)(h * D) * cache_cs;
-    const float* vp = kp + (long long)C * cache_cs;
+    const float* kp = cache + (long long)b * cache_bs + (long long)(h * D) * cap;       // K [C][cap]
+    const float* vp = cache + (long long)b * cache_bs + (long long)C * cap + h * D;      // V [cap][C]
     float q[D];
     const float scale = rsqrtf((float)D);
 #pragma unroll
     for (int c = 0; c < D; ++c) q[c] = qbuf[(long long)b * C + h * D + c] * scale;
     float mx = -INFINITY;
-    for (int s0 = 0; s0 < n; s0 += 64) {
-        const int s = s0 + lane;
-        float a = -INFINITY;
-        if (s < n) {
-            a = 0.f;
+    for (int s = tid; s < n; s += 256) {
+        float a = 0.f;
 #pragma unroll
-            for (int c = 0; c < D; ++c) a += q[c] * kp[(long long)c * cache_cs + s];
-            sc[s] = a;
-        }
+        for (int c = 0; c < D; ++c) a += q[c] * kp[(long long)c * cap + s];
+        sc[s] = a;
         mx = fmaxf(mx, a);
     }
     mx = wmax(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
     float l = 0.f;
-    float o[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) o[c] = 0.f;
-    for (int s0 = 0; s0 < n; s0 += 64) {
-        const int s = s0 + lane;
-        if (s < n) {
-            const float p = expf(sc[s] - mx);
-            l += p;
-#pragma unroll
-            for (int c = 0; c < D; ++c) o[c] += p * vp[(long long)c * cache_cs + s];
-        }
+    for (int s = tid; s < n; s += 256) {
+        const float pr = expf(sc[s] - mx);
+        sc[s] = pr;
+        l += pr;
     }
     l = wsum(l);
-    const float inv = 1.f / l;
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        const float t = wsum(o[c]);
-        if (lane == 0) out[(long long)b * C + h * D + c] = t * inv;
-    }
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    l = red[0] + red[1] + red[2] + red[3];
+    // PV: wave g takes keys g, g+4, ...; lanes = channels (token-major V rows are contiguous)
+    float o = 0.f;
+    if (lane < D)
+        for (int s = wave; s < n; s += 4) o += sc[s] * vp[(long long)s * C + lane];
+    if (lane < D) part[wave][lane] = o;
+    __syncthreads();
+    if (tid < D) out[(long long)b * C + h * D + tid] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / l;
 }
 
 void launch_decode_attention(const float* qbuf, const float* cache, long long cache_bs, int cache_cs, const int* klen, int B, int H,
                              int D, float* out, hipStream_t s) {
     DTTS_REQUIRE(D == 48, "decode attention head dim");
-    hipLaunchKernelGGL(decode_attention_kernel<48>, dim3(H, B), dim3(64), sizeof(float) * cache_cs, s, qbuf, cache, cache_bs, cache_cs,
+    hipLaunchKernelGGL(decode_attention_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, qbuf, cache, cache_bs, cache_cs,
                        klen, H, out);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
+// prefill qkv [B, 3C, L] -> cache: K rows copied, V transposed to token-major
 __global__ void kv_to_cache_kernel(const float* qkv, long long bs, int cs, const int* lens, int C, float* cache, long long cache_bs,
-                                   int cache_cs) {
-    const int row = blockIdx.y, b = blockIdx.z;   // row in [0, 2C)
+                                   int cap) {
+    const int row = blockIdx.y, b = blockIdx.z;   // row in [0, 2C): K rows then V rows
     const int len = lens[b];
     const float* src = qkv + (long long)b * bs + (long long)(C + row) * cs;
-    float* dst = cache + (long long)b * cache_bs + (long long)row * cache_cs;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < len; t += gridDim.x * blockDim.x) dst[t] = src[t];
+    float* cb = cache + (long long)b * cache_bs;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < len; t += gridDim.x * blockDim.x) {
+        if (row < C) cb[(long long)row * cap + t] = src[t];
+        else cb[(long long)C * cap + (long long)t * C + (row - C)] = src[t];
+    }
 }
 
 void launch_kv_to_cache(const float* qkv, long long bs, int cs, const int* lens, int L, int B, int C, float* cache, long long cache_bs,
