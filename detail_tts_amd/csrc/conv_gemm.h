@@ -16,6 +16,7 @@ struct ConvParams {
     long long x_bs = 0;      // batch stride (floats)
     int x_cs = 0;            // channel stride (floats) == allocated T of the input buffer
     const int* len_in = nullptr;   // [B] valid input length per sample (null -> Tin)
+    const int* x_bidx = nullptr;   // optional [B]: input sample index of output sample b (shared inputs across the batch)
     int Tin = 0;
     // prologue: v = act(a*x + d) with (a,d) = pro_ab[b][ci][0..1]; positions outside [0,len) are 0
     const float* pro_ab = nullptr;

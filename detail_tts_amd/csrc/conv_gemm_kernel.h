@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     if (n0 >= nvalid) return;
     const int lin = p.len_in ? p.len_in[b] : p.Tin;
 
-    const float* xb = p.x + (long long)b * p.x_bs;
+    const float* xb = p.x + (long long)(p.x_bidx ? p.x_bidx[b] : b) * p.x_bs;
     const float* ab = p.pro_ab ? p.pro_ab + (long long)b * p.Cin * 2 : nullptr;
     const int tin0 = n0 * p.stride - p.pad;
 

@@ -156,8 +156,11 @@ private:
                          int T, int Ta, hipStream_t s);
     void res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T, int Ta,
                        int step, hipStream_t s);
-    void diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, int B, int T, int step, float* out2,
-                           hipStream_t s);
+    // cbuf0: [B + Nu, C, T] = B conditional code embeddings followed by Nu unconditional inputs (one per distinct length)
+    void diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, const int* lens_i, const int* umap, int B, int Nu,
+                           int T, int step, float* out2, hipStream_t s);
+    struct PairPlan { const int *lens2, *lens_i, *umap; int Nu; };
+    PairPlan plan_pair(const int* lens_host, int B, int T, hipStream_t s);
 
     std::unordered_map<std::string, std::pair<const float*, size_t>> weights_;
     bool bound_ = false;

@@ -375,9 +375,34 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
 
 // One batched (cond | uncond) DiffusionTts.forward: x [B,128,T]; cbuf0 [2B,768,T] = (code_emb | uncond broadcast);
 // out2 [2B,256,T].  lens2 = device lens repeated twice.
-void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, int B, int T, int step, float* out2,
-                              hipStream_t s) {
-    const int C = cfg.diff_channels, B2 = 2 * B, Ta = T;
+// The unconditional branch of the conditioning_timestep_integrator sees a T-constant input (the broadcast
+// unconditioned_embedding), so its output depends only on (timestep, length): it is evaluated once per DISTINCT length in
+// the batch instead of once per utterance (identical values, 3 of 16 layers x half the batch less work).
+Model::PairPlan Model::plan_pair(const int* lens_host, int B, int T, hipStream_t s) {
+    std::vector<int> l2(2 * B), li, um(2 * B), ul;
+    for (int b = 0; b < B; ++b) {
+        const int len = lens_host ? lens_host[b] : T;
+        l2[b] = l2[B + b] = len;
+        li.push_back(len);
+        um[b] = b;
+        int gidx = -1;
+        for (size_t k = 0; k < ul.size(); ++k)
+            if (ul[k] == len) gidx = (int)k;
+        if (gidx < 0) { gidx = (int)ul.size(); ul.push_back(len); }
+        um[B + b] = B + gidx;
+    }
+    for (int v : ul) li.push_back(v);
+    PairPlan pl;
+    pl.Nu = (int)ul.size();
+    pl.lens2 = upload_ints(l2.data(), 2 * B, s);
+    pl.lens_i = upload_ints(li.data(), (int)li.size(), s);
+    pl.umap = upload_ints(um.data(), 2 * B, s);
+    return pl;
+}
+
+void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, const int* lens_i, const int* umap, int B, int Nu,
+                              int T, int step, float* out2, hipStream_t s) {
+    const int C = cfg.diff_channels, B2 = 2 * B, Bi = B + Nu, Ta = T;
     const size_t act = (size_t)B2 * C * Ta;
     float* bufA = ws_.f32(act);
     float* bufB = ws_.f32(act);
@@ -386,14 +411,17 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     float* ab = ws_.f32((size_t)B2 * C * 2);
     const long long bs = (long long)C * Ta;
 
-    auto dlayer = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp) {
-        res_block_fwd(l.rb, in, tmp, mid, ab, lens2, B2, T, Ta, step, s);
-        attention_block(l.at, mid, outp, qkv, tmp, ab, lens2, B2, T, Ta, s);
+    auto dlayer_n = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp, const int* lens, int nb) {
+        res_block_fwd(l.rb, in, tmp, mid, ab, lens, nb, T, Ta, step, s);
+        attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, s);
     };
-    // conditioning_timestep_integrator on the code embeddings (vqvae/diff_model.py:295)
-    dlayer(integ_[0], cbuf0, bufB, bufC, bufA);
-    dlayer(integ_[1], bufA, bufB, bufC, bufA);
-    dlayer(integ_[2], bufA, bufB, bufC, bufA);          // bufA = code path
+    auto dlayer = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp) {
+        dlayer_n(l, in, tmp, mid, outp, lens2, B2);
+    };
+    // conditioning_timestep_integrator on the B code embeddings + Nu unconditional inputs (vqvae/diff_model.py:295)
+    dlayer_n(integ_[0], cbuf0, bufB, bufC, bufA, lens_i, Bi);
+    dlayer_n(integ_[1], bufA, bufB, bufC, bufA, lens_i, Bi);
+    dlayer_n(integ_[2], bufA, bufB, bufC, bufA, lens_i, Bi);          // bufA = code path
     // inp_block + integrating_conv on cat([x, code]) (:296-298) as two accumulating 1x1 GEMMs
     ConvParams p;
     p.B = B;
@@ -438,6 +466,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     r.res_bs = bs;
     r.res_cs = Ta;
     r.res_bmod = B;                                      // both halves share the x-path term
+    r.x_bidx = umap;                                     // uncond rows read the shared per-length integrator output
     run_conv(integ2_, r, s);
     // main stack (:299-309)
     float* cur = bufB;
@@ -482,9 +511,7 @@ void Model::diff_forward(const float* x, const float* code_emb, const int* lens_
     DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
     const int C = cfg.diff_channels, OC = cfg.diff_out_channels;
     ws_.ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 4096);
-    std::vector<int> l2(2 * B);
-    for (int i = 0; i < B; ++i) l2[i] = l2[B + i] = lens_host ? lens_host[i] : T;
-    const int* lens2 = upload_ints(l2.data(), 2 * B, s);
+    const PairPlan pl = plan_pair(lens_host, B, T, s);
     float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
     float* out2 = ws_.f32((size_t)2 * B * OC * T);
     const size_t half = (size_t)B * C * T;
@@ -492,8 +519,8 @@ void Model::diff_forward(const float* x, const float* code_emb, const int* lens_
         DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
     else
         launch_broadcast_channels(uncond_, B, C, T, cbuf0, (long long)C * T, T, s);
-    launch_broadcast_channels(uncond_, B, C, T, cbuf0 + half, (long long)C * T, T, s);
-    diff_forward_pair(x, cbuf0, lens2, B, T, step, out2, s);
+    launch_broadcast_channels(uncond_, pl.Nu, C, T, cbuf0 + half, (long long)C * T, T, s);
+    diff_forward_pair(x, cbuf0, pl.lens2, pl.lens_i, pl.umap, B, pl.Nu, T, step, out2, s);
     const float* src = out2 + (cond_free ? (size_t)B * OC * T : 0);
     DTTS_CHECK_HIP(hipMemcpyAsync(out, src, sizeof(float) * (size_t)B * OC * T, hipMemcpyDeviceToDevice, s));
 }
@@ -506,15 +533,14 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     if (n_steps <= 0 || n_steps > n_steps_) n_steps = n_steps_;
     const size_t per_call = pair_ws_bytes(B, C, T);
     ws_.ensure(per_call + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
-    std::vector<int> l2(2 * B);
-    for (int i = 0; i < B; ++i) l2[i] = l2[B + i] = lens_host ? lens_host[i] : T;
-    const int* lens2 = upload_ints(l2.data(), 2 * B, s);
+    const PairPlan pl = plan_pair(lens_host, B, T, s);
+    const int* lens2 = pl.lens2;
     const int* sids = upload_ints(sample_ids_host, B, s);
     float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
     float* out2 = ws_.f32((size_t)2 * B * OC * T);
     const size_t half = (size_t)B * C * T;
     DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
-    launch_broadcast_channels(uncond_, B, C, T, cbuf0 + half, (long long)C * T, T, s);
+    launch_broadcast_channels(uncond_, pl.Nu, C, T, cbuf0 + half, (long long)C * T, T, s);
     // x_T  (vqvae/model_24k.py:488); per-sample noise is indexed over the sample's own [128, len]
     float* x = mel_out;
     const long long xbs = (long long)MC * T;
@@ -540,7 +566,7 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     for (int k = 0; k < n_steps; ++k) {
         const int i = n_steps_ - 1 - k;
         ws_.rewind(mark);                              // the forward's scratch is re-carved every step
-        diff_forward_pair(x, cbuf0, lens2, B, T, i, out2, s);
+        diff_forward_pair(x, cbuf0, lens2, pl.lens_i, pl.umap, B, pl.Nu, T, i, out2, s);
         const bool last = (k == n_steps - 1);
         launch_diff_update(x, xbs, T, out2, (long long)OC * T, T, lens2, T, B, MC, step_coefs_[i], seed, sids, i,
                            step_noise ? step_noise + (size_t)k * B * MC * T : nullptr, (denorm && last) ? 1 : 0, s);

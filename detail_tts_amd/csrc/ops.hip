@@ -23,6 +23,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // red: >= 4
 }
 
 // ---------------------------------------------------------------------------------------------
+// One pass over the group: shifted sums S1 = sum(x - k), S2 = sum((x - k)^2) with k = first element (no cancellation
+// problem even when |mean| >> std), float4 loads when the rows are 16-byte aligned.
 __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long long x_bs, int x_cs, const int* lens, int T, int C,
                                                         int groups, const float* gamma, const float* beta, float eps,
                                                         const float* ada, int ada_stride, int ada_bs, float* ab_out) {
@@ -32,19 +34,37 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long lon
     const int cpg = C / groups;
     const float* xg = x + (long long)b * x_bs + (long long)(g * cpg) * x_cs;
     const int n = cpg * len;
-    // pass 1: mean
-    float s = 0.f;
-    for (int c = 0; c < cpg; ++c)
-        for (int t = threadIdx.x; t < len; t += blockDim.x) s += xg[(long long)c * x_cs + t];
-    const float mean = block_sum(s, red) / (float)n;
-    // pass 2: centred second moment (the tile is L2-resident)
-    float q = 0.f;
-    for (int c = 0; c < cpg; ++c)
-        for (int t = threadIdx.x; t < len; t += blockDim.x) {
-            const float d = xg[(long long)c * x_cs + t] - mean;
-            q += d * d;
+    const float k = xg[0];
+    float s1 = 0.f, s2 = 0.f;
+    const bool vec = ((x_cs & 3) == 0) && ((reinterpret_cast<unsigned long long>(xg) & 15ull) == 0);
+    if (vec) {
+        const int len4 = len >> 2;
+        for (int c = 0; c < cpg; ++c) {
+            const float4* row = reinterpret_cast<const float4*>(xg + (long long)c * x_cs);
+            for (int t = threadIdx.x; t < len4; t += blockDim.x) {
+                const float4 v = row[t];
+                const float d0 = v.x - k, d1 = v.y - k, d2 = v.z - k, d3 = v.w - k;
+                s1 += (d0 + d1) + (d2 + d3);
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            for (int t = (len4 << 2) + threadIdx.x; t < len; t += blockDim.x) {
+                const float d = xg[(long long)c * x_cs + t] - k;
+                s1 += d;
+                s2 += d * d;
+            }
         }
-    const float var = block_sum(q, red) / (float)n;
+    } else {
+        for (int c = 0; c < cpg; ++c)
+            for (int t = threadIdx.x; t < len; t += blockDim.x) {
+                const float d = xg[(long long)c * x_cs + t] - k;
+                s1 += d;
+                s2 += d * d;
+            }
+    }
+    const float S1 = block_sum(s1, red) / (float)n;
+    const float S2 = block_sum(s2, red) / (float)n;
+    const float mean = k + S1;
+    const float var = fmaxf(S2 - S1 * S1, 0.f);
     const float rstd = rsqrtf(var + eps);
     if (threadIdx.x < cpg) {
         const int c = g * cpg + threadIdx.x;
