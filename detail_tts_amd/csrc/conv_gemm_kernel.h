@@ -219,6 +219,12 @@ void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
 #define DTTS_INSTANTIATE_CONV_TILE(BM, BN, WGM, WGN, BK)                                                                      \
     template <int PRO, int EPI>                                                                                           \
     static void launch_pe_##BM##_##BN##_##BK(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {                   \
+        static size_t lds_attr = 64 * 1024;                                                                               \
+        if (lds > lds_attr) {                                                                                             \
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
+            lds_attr = 160 * 1024;                                                                                        \
+        }                                                                                                                 \
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI>), grid, dim3(256), lds, stream, p);             \
     }                                                                                                                     \
     template <int PRO>                                                                                                    \
@@ -233,7 +239,7 @@ void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
         DTTS_REQUIRE(XW <= XW_MAX, "conv input tile too wide for the staging registers");                                 \
         DTTS_REQUIRE(p.CoutP % BM == 0 && p.CinP % BK == 0, "packed weight padding");                                     \
         const size_t lds = sizeof(float) * (2 * BK * BM + 2 * BK * (XW + 1));                                             \
-        DTTS_REQUIRE(lds <= 64 * 1024, "conv LDS tile");                                                                  \
+        DTTS_REQUIRE(lds <= 160 * 1024, "conv LDS tile");                                                                 \
         dim3 grid(p.CoutP / BM, cdiv(p.Nout, BN), p.B);                                                                   \
         const int pro = p.pro_ab ? (p.pro_act == ACT_SILU ? 1 : 2)                                                        \
                                  : (p.pro_act == ACT_LRELU ? 3 : (p.pro_act == ACT_SILU ? 4 : 0));                        \
