@@ -18,8 +18,15 @@ void launch_vec_layernorm2(const float* x, const float* g1, const float* b1, con
 // `slices` is chosen by the launcher so that the grid fills the chip; scratch must hold slices*B*CoutP floats.
 int gemv_slices(int K, int CoutP);
 void launch_gemv_partial(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices, hipStream_t s);
+// ln_stats (optional) [B][ceil(Cout/64)][2]: per-block (sum, sum of squares) of the produced row, consumed by launch_gemv_partial_ln
 void launch_gemv_finish(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act, const float* res,
-                        int res_stride, float* y, int y_stride, hipStream_t s);
+                        int res_stride, float* y, int y_stride, hipStream_t s, float* ln_stats = nullptr);
+// skinny GEMM whose input rows are LayerNorm'ed on the fly from the producer's partial statistics
+void launch_gemv_partial_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices,
+                            const float* stats, int nblk, const float* gamma, const float* beta, hipStream_t s);
+// fused: y = sum_slices part + bias + res ; hn = LN(y) (optionally two LayerNorms back to back)
+void launch_gemv_finish_res_ln(const float* part, int slices, int B, int C, int CoutP, const float* bias, const float* res, float* y,
+                               const float* g1, const float* b1, const float* g2, const float* b2, float* hn, hipStream_t s);
 // finish variant for c_attn: q -> qbuf[b][C]; k,v -> cache[b] rows [0,C) / [C,2C) at column pos[b]
 void launch_gemv_finish_qkv(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf, float* cache,
                             long long cache_bs, int cache_cs, const int* pos, hipStream_t s);

@@ -81,18 +81,37 @@ int gemv_slices(int K, int CoutP) {
     const int colblocks = cdiv(CoutP, 256);
     int s = 768 / colblocks;
     if (s < 1) s = 1;
+    if (s > 64) s = 64;                       // bounded so the finish stage reads few partials
     if (s > K / 8) s = K / 8 > 0 ? K / 8 : 1;
     return s;
 }
 
-template <int NB>
+// LN != 0: the input rows are LayerNorm'ed on the fly, x' = (x - mean_b) * rstd_b * gamma_i + beta_i, with (mean, rstd) rebuilt
+// from the per-block partial sums (sum, sum of squares) that the producing finish kernel left in `stats[b][nblk][2]`.
+template <int NB, int LN>
 __global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restrict__ W, int K, int CoutP, const float* __restrict__ x,
-                                                          int x_stride, int B, float* __restrict__ part, int rows_per_slice) {
+                                                          int x_stride, int B, float* __restrict__ part, int rows_per_slice,
+                                                          const float* __restrict__ stats, int nblk, const float* __restrict__ gam,
+                                                          const float* __restrict__ bet) {
     const int lane = threadIdx.x;
     const int col = blockIdx.x * 256 + lane * 4;
-    if (col >= CoutP) return;
     const int k0 = blockIdx.y * rows_per_slice;
     const int k1 = min(K, k0 + rows_per_slice);
+    float mean[NB], rstd[NB];
+    if (LN) {   // lane k holds partial k of every row; one wave reduction per row (fixed order -> deterministic)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int bb = b < B ? b : B - 1;
+            float S = 0.f, Q = 0.f;
+            if (lane < nblk) { S = stats[((long long)bb * nblk + lane) * 2]; Q = stats[((long long)bb * nblk + lane) * 2 + 1]; }
+            S = wsum(S);
+            Q = wsum(Q);
+            const float m = S / (float)K;
+            mean[b] = m;
+            rstd[b] = rsqrtf(fmaxf(Q / (float)K - m * m, 0.f) + 1e-5f);
+        }
+    }
+    if (col >= CoutP) return;
     float4 acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,12 +122,18 @@ __global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (long long)u * CoutP);
         wp += 4LL * CoutP;
+        float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (LN) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { gg[u] = gam[i + u]; bb4[u] = bet[i + u]; }
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float* xr = x + (long long)(b < B ? b : B - 1) * x_stride + i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float xv = xr[u];
+                float xv = xr[u];
+                if (LN) xv = (xv - mean[b]) * rstd[b] * gg[u] + bb4[u];
                 acc[b].x += w[u].x * xv; acc[b].y += w[u].y * xv; acc[b].z += w[u].z * xv; acc[b].w += w[u].w * xv;
             }
         }
@@ -118,7 +143,8 @@ __global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restric
         wp += CoutP;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float xv = x[(long long)(b < B ? b : B - 1) * x_stride + i];
+            float xv = x[(long long)(b < B ? b : B - 1) * x_stride + i];
+            if (LN) xv = (xv - mean[b]) * rstd[b] * gam[i] + bet[i];
             acc[b].x += w.x * xv; acc[b].y += w.y * xv; acc[b].z += w.z * xv; acc[b].w += w.w * xv;
         }
     }
@@ -127,15 +153,61 @@ __global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restric
         if (b < B) *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * B + b) * CoutP + col) = acc[b];
 }
 
+template <int LN>
+static void gemv_partial_dispatch(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices,
+                                  const float* stats, int nblk, const float* gam, const float* bet, hipStream_t s) {
+    const int rps = cdiv(K, slices);
+    dim3 grid(cdiv(CoutP, 256), slices);
+    if (B <= 1) hipLaunchKernelGGL((gemv_partial_kernel<1, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
+    else if (B <= 4) hipLaunchKernelGGL((gemv_partial_kernel<4, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
+    else if (B <= 8) hipLaunchKernelGGL((gemv_partial_kernel<8, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
+    else hipLaunchKernelGGL((gemv_partial_kernel<16, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
 void launch_gemv_partial(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices, hipStream_t s) {
     DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && CoutP % 4 == 0, "gemv shape");
     DTTS_REQUIRE((long long)slices * CoutP <= 262144, "gemv partial scratch");
-    const int rps = cdiv(K, slices);
-    dim3 grid(cdiv(CoutP, 256), slices);
-    if (B <= 1) hipLaunchKernelGGL(gemv_partial_kernel<1>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
-    else if (B <= 4) hipLaunchKernelGGL(gemv_partial_kernel<4>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
-    else if (B <= 8) hipLaunchKernelGGL(gemv_partial_kernel<8>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
-    else hipLaunchKernelGGL(gemv_partial_kernel<16>, grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps);
+    gemv_partial_dispatch<0>(W, K, CoutP, x, x_stride, B, part, slices, nullptr, 0, nullptr, nullptr, s);
+}
+
+void launch_gemv_partial_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices,
+                            const float* stats, int nblk, const float* gamma, const float* beta, hipStream_t s) {
+    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && CoutP % 4 == 0, "gemv shape");
+    DTTS_REQUIRE((long long)slices * CoutP <= 262144, "gemv partial scratch");
+    gemv_partial_dispatch<1>(W, K, CoutP, x, x_stride, B, part, slices, stats, nblk, gamma, beta, s);
+}
+
+// y[b] = sum_slices part + bias + res[b];  hn[b] = LayerNorm(y[b])  — one 256-thread block per row (C <= 1024)
+__global__ __launch_bounds__(256) void gemv_finish_res_ln_kernel(const float* part, int slices, int B, int C, int CoutP,
+                                                                 const float* bias, const float* res, float* y, const float* g1,
+                                                                 const float* b1, const float* g2, const float* b2, float* hn) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float v[4];
+    const int n_per = (C + 255) / 256;
+    for (int i = 0; i < n_per; ++i) {
+        const int c = tid + i * 256;
+        float a = 0.f;
+        if (c < C) {
+            a = bias[c] + res[(long long)b * C + c];
+            for (int sl = 0; sl < slices; ++sl) a += part[((long long)sl * B + b) * CoutP + c];
+            y[(long long)b * C + c] = a;
+        }
+        v[i] = a;
+    }
+    block_ln_256(v, n_per, C, g1, b1, red);
+    if (g2) block_ln_256(v, n_per, C, g2, b2, red);
+    for (int i = 0; i < n_per; ++i) {
+        const int c = tid + i * 256;
+        if (c < C) hn[(long long)b * C + c] = v[i];
+    }
+}
+
+void launch_gemv_finish_res_ln(const float* part, int slices, int B, int C, int CoutP, const float* bias, const float* res, float* y,
+                               const float* g1, const float* b1, const float* g2, const float* b2, float* hn, hipStream_t s) {
+    DTTS_REQUIRE(C <= 1024, "finish_res_ln width");
+    hipLaunchKernelGGL(gemv_finish_res_ln_kernel, dim3(B), dim3(256), 0, s, part, slices, B, C, CoutP, bias, res, y, g1, b1, g2, b2, hn);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -150,22 +222,34 @@ __device__ __forceinline__ float finish_sum(const float* part, int slices, int B
 }
 
 __global__ __launch_bounds__(256) void gemv_finish_kernel(const float* part, int slices, int B, int Cout, int CoutP, const float* bias,
-                                                          int act, const float* res, int res_stride, float* y, int y_stride) {
+                                                          int act, const float* res, int res_stride, float* y, int y_stride,
+                                                          float* stats) {
     __shared__ float red[256];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y;
     const int colc = col < CoutP ? col : CoutP - 1;
     float v = finish_sum(part, slices, B, CoutP, b, colc, red);
-    if (threadIdx.x >= 64 || col >= Cout) return;
-    if (bias) v += bias[col];
-    v = act_apply(v, act, 0.f);
-    if (res) v += res[(long long)b * res_stride + col];
-    y[(long long)b * y_stride + col] = v;
+    if (threadIdx.x >= 64) return;
+    const bool ok = col < Cout;
+    if (ok) {
+        if (bias) v += bias[col];
+        v = act_apply(v, act, 0.f);
+        if (res) v += res[(long long)b * res_stride + col];
+        y[(long long)b * y_stride + col] = v;
+    } else v = 0.f;
+    if (stats) {            // per-block partial sums for the consumer's fused LayerNorm
+        const float s1 = wsum(v), s2 = wsum(v * v);
+        if (threadIdx.x == 0) {
+            float* st = stats + ((long long)b * gridDim.x + blockIdx.x) * 2;
+            st[0] = s1;
+            st[1] = s2;
+        }
+    }
 }
 
 void launch_gemv_finish(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act, const float* res,
-                        int res_stride, float* y, int y_stride, hipStream_t s) {
+                        int res_stride, float* y, int y_stride, hipStream_t s, float* ln_stats) {
     hipLaunchKernelGGL(gemv_finish_kernel, dim3(cdiv(Cout, 64), B), dim3(256), 0, s, part, slices, B, Cout, CoutP, bias, act, res,
-                       res_stride, y, y_stride);
+                       res_stride, y, y_stride, ln_stats);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -208,9 +292,13 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const float* qbuf
     for (int c = 0; c < D; ++c) q[c] = qbuf[(long long)b * C + h * D + c] * scale;
     float mx = -INFINITY;
     for (int s = tid; s < n; s += 256) {
-        float a = 0.f;
+        float kv[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) a += q[c] * kp[(long long)c * cap + s];
+        for (int c = 0; c < D; ++c) kv[c] = kp[(long long)c * cap + s];      // D independent coalesced loads in flight
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { a0 += q[c] * kv[c]; a1 += q[c + 1] * kv[c + 1]; a2 += q[c + 2] * kv[c + 2]; a3 += q[c + 3] * kv[c + 3]; }
+        const float a = (a0 + a1) + (a2 + a3);
         sc[s] = a;
         mx = fmaxf(mx, a);
     }
@@ -231,8 +319,16 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const float* qbuf
     l = red[0] + red[1] + red[2] + red[3];
     // PV: wave g takes keys g, g+4, ...; lanes = channels (token-major V rows are contiguous)
     float o = 0.f;
-    if (lane < D)
-        for (int s = wave; s < n; s += 4) o += sc[s] * vp[(long long)s * C + lane];
+    if (lane < D) {
+        float o4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = wave;
+        for (; s + 28 < n; s += 32) {          // 8 keys in flight per lane
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o4[u] += sc[s + 4 * u] * vp[(long long)(s + 4 * u) * C + lane];
+        }
+        for (; s < n; s += 4) o4[0] += sc[s] * vp[(long long)s * C + lane];
+        o = ((o4[0] + o4[1]) + (o4[2] + o4[3])) + ((o4[4] + o4[5]) + (o4[6] + o4[7]));
+    }
     if (lane < D) part[wave][lane] = o;
     __syncthreads();
     if (tid < D) out[(long long)b * C + h * D + tid] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / l;

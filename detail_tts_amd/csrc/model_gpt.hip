@@ -166,6 +166,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     float* lat = ws_.f32((size_t)B * C);
     float* logits = ws_.f32((size_t)B * VP);
     float* part = ws_.f32((size_t)B * PART_FLOATS);
+    float* lnst = ws_.f32((size_t)B * 64 * 2);
     unsigned char* seen = static_cast<unsigned char*>(ws_.raw((size_t)B * V));
     int* finished = ws_.i32(B);
     int* codes = ws_.i32((size_t)B * G);
@@ -243,9 +244,9 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     sp.C = C;
     sp.n_unfinished = nullptr;
 
-    auto head_and_sample = [&](const float* hidden, int step, float* x_next) {
+    // lat = final_norm(ln_f(hidden)) must already be in `lat` (fused into the producing kernel)
+    auto head_and_sample = [&](int step, float* x_next) {
         // lm_head = (final_norm, mel_head) applied to ln_f(h)   (gpt/model.py:41, 173)
-        launch_vec_layernorm2(hidden, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s);
         hipLaunchKernelGGL(store_column_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, lat, C, latents_cm, (long long)C * lat_stride,
                            lat_stride, step);
         const int sl = gemv_slices(C, VP);
@@ -255,7 +256,8 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         sp.x_next = x_next;
         launch_sampler(sp, s);
     };
-    head_and_sample(xa, 0, xb);
+    launch_vec_layernorm2(xa, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s);
+    head_and_sample(0, xb);
 
     std::vector<int> fin(B, 0);
     int steps_done = 1;
@@ -269,26 +271,29 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         }
         const int* pos = pos_tab + (size_t)t * B;
         const int* klen = klen_tab + (size_t)t * B;
+        const int nblk = cdiv(C, 64);
+        // the sampler wrote x (next input embedding) without LN statistics: one small LN for layer 0
+        launch_vec_layernorm(x, gpt_layers_[0].ln1_g, gpt_layers_[0].ln1_b, hn, B, C, s);
         for (int l = 0; l < NL; ++l) {
             const GptLayerW& w = gpt_layers_[l];
             float* cache = kv + (size_t)l * kv_layer;
-            launch_vec_layernorm(x, w.ln1_g, w.ln1_b, hn, B, C, s);
             int sl = gemv_slices(C, w.attn.CoutP);
-            launch_gemv_partial(w.attn.w, C, w.attn.CoutP, hn, C, B, part, sl, s);
+            if (l == 0) launch_gemv_partial(w.attn.w, C, w.attn.CoutP, hn, C, B, part, sl, s);
+            else launch_gemv_partial_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, sl, lnst, nblk, w.ln1_g, w.ln1_b, s);
             launch_gemv_finish_qkv(part, sl, B, C, w.attn.CoutP, w.attn.b, qb, cache, kv_bs, cap, pos, s);
             launch_decode_attention(qb, cache, kv_bs, cap, klen, B, H, D, ab, s);
             sl = gemv_slices(C, w.proj.CoutP);
             launch_gemv_partial(w.proj.w, C, w.proj.CoutP, ab, C, B, part, sl, s);
-            launch_gemv_finish(part, sl, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s);
-            launch_vec_layernorm(y, w.ln2_g, w.ln2_b, hn, B, C, s);
+            launch_gemv_finish(part, sl, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);      // y = x + attn ; stats for ln_2
             sl = gemv_slices(C, w.fc.CoutP);
-            launch_gemv_partial(w.fc.w, C, w.fc.CoutP, hn, C, B, part, sl, s);
+            launch_gemv_partial_ln(w.fc.w, C, w.fc.CoutP, y, C, B, part, sl, lnst, nblk, w.ln2_g, w.ln2_b, s);
             launch_gemv_finish(part, sl, B, 4 * C, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, nullptr, 0, mb, 4 * C, s);
             sl = gemv_slices(4 * C, w.fc2.CoutP);
             launch_gemv_partial(w.fc2.w, 4 * C, w.fc2.CoutP, mb, 4 * C, B, part, sl, s);
-            launch_gemv_finish(part, sl, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s);
+            launch_gemv_finish(part, sl, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s, lnst);        // x = y + mlp ; stats for next ln_1
         }
-        head_and_sample(x, t, y);
+        launch_vec_layernorm2(x, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s);
+        head_and_sample(t, y);
         std::swap(x, y);
         steps_done = t + 1;
     }
