@@ -14,8 +14,12 @@ constexpr int XW_MAX = 64 * XCOLS;
 
 // PRO: 0 raw input | 1 affine + SiLU | 2 affine only | 3 leaky-relu (no affine) | 4 SiLU (no affine)
 // EPI: 0 linear (bias, per-sample rows, scale, residual, polyphase scatter) | 1 + generic activation | 2 gated pair
-template <int BM, int BN, int WGM, int WGN, int BK, int PRO, int EPI>
+// KWT: 0 = generic (runtime KW / stride / dilation) | 1, 3 = compile-time tap count with stride 1, dilation 1 (the diffusion convs)
+template <int BM, int BN, int WGM, int WGN, int BK, int PRO, int EPI, int KWT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    const int KW = KWT > 0 ? KWT : p.KW;
+    const int stride = KWT > 0 ? 1 : p.stride;
+    const int dil = KWT > 0 ? 1 : p.dil;
     constexpr int XR = BK / 4;                        // channel rows staged per wave
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -26,7 +30,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int WLOADS = WV4 > 0 ? WV4 : 1;
 
     extern __shared__ float smem[];
-    const int XW = (BN - 1) * p.stride + (p.KW - 1) * p.dil + 1;
+    const int XW = (BN - 1) * stride + (KW - 1) * dil + 1;
     const int XWP = XW + 1;                            // row pitch
     float* Ws = smem;                                  // [2][BK][BM]
     float* Xs = smem + 2 * BK * BM;                    // [2][BK][XWP]
@@ -43,10 +47,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
     const float* xb = p.x + (long long)(p.x_bidx ? p.x_bidx[b] : b) * p.x_bs;
     const float* ab = p.pro_ab ? p.pro_ab + (long long)b * p.Cin * 2 : nullptr;
-    const int tin0 = n0 * p.stride - p.pad;
+    const int tin0 = n0 * stride - p.pad;
 
     const int nCb = p.CinP / BK;
-    const int S = nCb * p.KW;
+    const int S = nCb * KW;
 
     float xreg[XR * XCOLS];
 
@@ -136,14 +140,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     for (int s = 0; s < S; ++s) {
         const bool has_next = (s + 1) < S;
         int ntap = tap + 1, ncb = cb;
-        if (ntap == p.KW) { ntap = 0; ncb = cb + 1; }
+        if (ntap == KW) { ntap = 0; ncb = cb + 1; }
         const bool newx = has_next && (ncb != cb);
         if (has_next && !(p.ablate & 1)) load_w(ncb, ntap, (s + 1) & 1);
         if (newx && !(p.ablate & 1)) load_x(ncb);
 
         const float* wq = Ws + (s & 1) * BK * BM + lhi * BM + wm0 + l31;
-        const float* xq = Xs + (cb & 1) * BK * XWP + lhi * XWP + (wn0 + l31) * p.stride + tap * p.dil;
-        const int xw2 = 2 * XWP, nstep = 32 * p.stride;
+        const float* xq = Xs + (cb & 1) * BK * XWP + lhi * XWP + (wn0 + l31) * stride + tap * dil;
+        const int xw2 = 2 * XWP, nstep = 32 * stride;
         float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
@@ -216,16 +220,22 @@ template <int BM, int BN, int WGM, int WGN, int BK>
 void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
 
 // one translation unit per tile shape instantiates the PRO x EPI grid
-#define DTTS_INSTANTIATE_CONV_TILE(BM, BN, WGM, WGN, BK)                                                                      \
+#define DTTS_INSTANTIATE_CONV_TILE(BM, BN, WGM, WGN, BK, FAST)                                                                      \
     template <int PRO, int EPI>                                                                                           \
     static void launch_pe_##BM##_##BN##_##BK(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {                   \
         static size_t lds_attr = 64 * 1024;                                                                               \
         if (lds > lds_attr) {                                                                                             \
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI>), \
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI, 0>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
             lds_attr = 160 * 1024;                                                                                        \
         }                                                                                                                 \
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI>), grid, dim3(256), lds, stream, p);             \
+        constexpr bool FASTPATH = (FAST) && EPI == 0 && PRO <= 2;                                                         \
+        if (FASTPATH && p.stride == 1 && p.dil == 1 && p.KW == 1 && lds <= 64 * 1024)                                    \
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI, FASTPATH ? 1 : 0>), grid, dim3(256), lds, stream, p); \
+        else if (FASTPATH && p.stride == 1 && p.dil == 1 && p.KW == 3 && lds <= 64 * 1024)                               \
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI, FASTPATH ? 3 : 0>), grid, dim3(256), lds, stream, p); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI, 0>), grid, dim3(256), lds, stream, p);   \
     }                                                                                                                     \
     template <int PRO>                                                                                                    \
     static void launch_p_##BM##_##BN##_##BK(const ConvParams& p, int epi, dim3 grid, size_t lds, hipStream_t stream) {           \

@@ -64,6 +64,7 @@ class SynthesizerTrn:
                                               betas=get_named_beta_schedule("linear", TRAINED_DIFFUSION_STEPS),
                                               conditioning_free=True, conditioning_free_k=COND_FREE_K)
         self.rt.timestep_map = list(self.infer_diffuser.timestep_map)
+        self.stage_ms = None          # set to {} to collect per-stage hipEvent timings of the next infer() call
 
     def eval(self):
         return self
@@ -92,6 +93,15 @@ class SynthesizerTrn:
         sample_ids = list(range(B)) if sample_ids is None else list(sample_ids)
         texts = [text[b, : int(tl[b])].cpu().numpy().astype(np.int32) for b in range(B)]
         rl = [int(v) for v in rl]
+        ev = []
+
+        def mark(name):
+            if self.stage_ms is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(self.device))
+                ev.append((name, e))
+
+        mark("start")
         # ---- stage A: codes + latents (:782-799)
         if forced_codes is None:
             codes, ncodes, lat = self.rt.gpt_generate(refer, rl, texts, seed, sample_ids, max_generate_length=max_generate_length,
@@ -104,13 +114,21 @@ class SynthesizerTrn:
         else:
             n = [len(c) for c in forced_codes]
             lat = self.rt.gpt_latents(refer, rl, texts, forced_codes)
+        mark("gpt")
         # ---- stage B (:802-804)
         cond = self.rt.diff_conditioning(refer, rl)
         code_emb = self.rt.diff_timestep_independent(lat, cond, n)
+        mark("diff_cond")
         lens_t = [4 * v for v in n]
         mel = self.rt.diff_sample(code_emb, seed, sample_ids, lens=lens_t, denorm=True)
+        mark("diff_sample")
         # ---- stage C (:805-809)
         wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
+        mark("vocoder")
+        if self.stage_ms is not None:
+            torch.cuda.synchronize(self.device)
+            for (_, a), (nm, b) in zip(ev[:-1], ev[1:]):
+                self.stage_ms[nm] = self.stage_ms.get(nm, 0.0) + a.elapsed_time(b)
         if return_lengths:
             return wav, [1024 * v for v in n]
         return wav
