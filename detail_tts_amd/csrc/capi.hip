@@ -45,6 +45,12 @@ void dtts_default_config(dtts_config* c) {
     for (int i = 0; i < 3; ++i) { c->resblock_kernels[i] = rk[i]; c->resblock_dilations[i] = rd[i]; }
 }
 
+int dtts_set_option(dtts_handle* h, const char* key, int value) {
+    DTTS_API_BEGIN
+    h->m->set_option(key, value);
+    DTTS_API_END(h)
+}
+
 int dtts_profile_enable(int on) {
     dtts::Profiler::get().reset();
     dtts::Profiler::get().on = on != 0;

@@ -129,6 +129,10 @@ public:
     void op_philox_normal(float* out, int n, int B, unsigned long long seed, const int* sample_ids_host, int stage, int step,
                           hipStream_t s);
 
+    void set_option(const std::string& key, int value) {
+        if (key == "two_streams") opt_two_streams_ = value != 0;
+        else throw Error(-1, "unknown option '" + key + "'");
+    }
     std::string last_error;
     dtts_config cfg;
     int device;
@@ -189,6 +193,11 @@ private:
     PackedConv mel_head_;
     const float *lnf_g_ = nullptr, *lnf_b_ = nullptr, *fin_g_ = nullptr, *fin_b_ = nullptr;
     const float *text_emb_ = nullptr, *mel_emb_ = nullptr, *text_pos_ = nullptr, *mel_pos_ = nullptr;
+
+    bool opt_two_streams_ = true;
+    hipStream_t s2_ = nullptr;            // second stream of the two-stream diffusion forward
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    const int* umap_local_ = nullptr;     // [B] uncond sample -> index of its length group
 
     Arena ws_;        // per-call activations
     Arena persist_;   // tables built at bind time

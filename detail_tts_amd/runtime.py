@@ -81,6 +81,9 @@ class Runtime:
                                         n, self._stream())
         self._rc(rc)
 
+    def set_option(self, key, value):
+        self._rc(self.lib.dtts_set_option(self.h, key.encode(), int(value)))
+
     def profile_enable(self, on=True):
         self.lib.dtts_profile_enable(1 if on else 0)
 

@@ -154,6 +154,9 @@ int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* le
  * mel [B,128,T] -> g [B,768] */
 int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const int* lens, int B, int T, float* g_out, void* stream);
 
+/* Runtime options: "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams. */
+int dtts_set_option(dtts_handle* h, const char* key, int value);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch hipEvent profiling of the MFMA kernels (conv GEMM, flash attention), recorded on the launch stream.
  * enable(1) resets the totals; report() synchronises and returns the number of entries written. */
