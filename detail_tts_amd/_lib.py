@@ -33,7 +33,7 @@ class DttsGptOptions(C.Structure):
 
 
 class DttsKernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("launches", C.c_longlong), ("total_ms", C.c_double), ("flops", C.c_double),
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_longlong), ("total_ms", C.c_double), ("union_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
 
 

@@ -66,6 +66,7 @@ int dtts_profile_report(dtts_kernel_stat* out, int max_entries) {
         std::strncpy(out[n].name, st.name.c_str(), sizeof(out[n].name) - 1);
         out[n].launches = st.launches;
         out[n].total_ms = st.ms;
+        out[n].union_ms = st.union_ms;
         out[n].flops = st.flops;
         out[n].bytes = st.bytes;
         ++n;

@@ -2,6 +2,7 @@
 // instrumented launch is bracketed by two hipEvents recorded on the launch stream; durations are summed per kernel
 // tag when the report is read.  Disabled (the default) it costs one branch per launch.
 #pragma once
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -14,6 +15,8 @@ struct ProfStat {
     std::string name;
     long long launches = 0;
     double ms = 0.0, flops = 0.0, bytes = 0.0;
+    double union_ms = 0.0;     // length of the union of the launch intervals (== ms when launches never overlap)
+    std::vector<std::pair<float, float>> spans;
 };
 
 class Profiler {
@@ -25,6 +28,10 @@ public:
     bool on = false;
     void begin(const char* tag, double flops, double bytes, hipStream_t s) {
         if (!on) return;
+        if (!base_) {
+            (void)hipEventCreate(&base_);
+            (void)hipEventRecord(base_, s);
+        }
         hipEvent_t a = take(), b = take();
         recs_.push_back({tag, flops, bytes, a, b});
         (void)hipEventRecord(a, s);
@@ -37,9 +44,11 @@ public:
     void collect() {
         for (auto& r : recs_) {
             (void)hipEventSynchronize(r.stop);
-            float ms = 0.f;
+            float ms = 0.f, t0 = 0.f;
             (void)hipEventElapsedTime(&ms, r.start, r.stop);
+            (void)hipEventElapsedTime(&t0, base_, r.start);
             ProfStat& st = stats_[r.tag];
+            st.spans.push_back({t0, t0 + ms});
             st.name = r.tag;
             st.launches += 1;
             st.ms += ms;
@@ -53,11 +62,29 @@ public:
     void reset() {
         collect();
         stats_.clear();
+        if (base_) (void)hipEventDestroy(base_);
+        base_ = nullptr;
     }
     std::vector<ProfStat> report() {
         collect();
         std::vector<ProfStat> v;
-        for (auto& kv : stats_) v.push_back(kv.second);
+        for (auto& kv : stats_) {
+            ProfStat st = kv.second;
+            std::sort(st.spans.begin(), st.spans.end());
+            double u = 0.0;
+            float cur0 = 0.f, cur1 = -1.f;
+            for (auto& sp : st.spans) {
+                if (cur1 < cur0 || sp.first > cur1) {
+                    if (cur1 >= cur0) u += cur1 - cur0;
+                    cur0 = sp.first;
+                    cur1 = sp.second;
+                } else if (sp.second > cur1) cur1 = sp.second;
+            }
+            if (cur1 >= cur0) u += cur1 - cur0;
+            st.union_ms = u;
+            st.spans.clear();
+            v.push_back(st);
+        }
         return v;
     }
 
@@ -77,6 +104,7 @@ private:
         (void)hipEventCreate(&e);
         return e;
     }
+    hipEvent_t base_ = nullptr;
     std::vector<Rec> recs_;
     std::vector<hipEvent_t> pool_;
     std::map<std::string, ProfStat> stats_;

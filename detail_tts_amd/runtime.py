@@ -90,7 +90,7 @@ class Runtime:
     def profile_report(self):
         arr = (_lib.DttsKernelStat * 64)()
         n = self.lib.dtts_profile_report(arr, 64)
-        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops,
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, union_ms=arr[i].union_ms, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(n)]
 
     def rebind(self):

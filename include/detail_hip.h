@@ -164,6 +164,7 @@ typedef struct dtts_kernel_stat {
     char name[64];
     long long launches;
     double total_ms;    /* sum of per-launch hipEvent durations */
+    double union_ms;    /* length of the union of the launch intervals (launches on two streams may overlap) */
     double flops;       /* algorithmic FLOPs of those launches */
     double bytes;       /* algorithmic bytes (inputs + outputs + weights once) */
 } dtts_kernel_stat;
