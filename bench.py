@@ -83,7 +83,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("DTTS_BENCH_BACKEND", "nccl")          # "gloo" + DTTS_BENCH_ONE_GPU=1: dry-run of the N>1 path on one GPU
+        if os.environ.get("DTTS_BENCH_ONE_GPU") == "1":
+            local = 0
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 

@@ -97,11 +97,11 @@ def attention_block(P, p, x, heads):
     qkv = qkv.reshape(B * heads, 3 * ch, T)
     q, k, v = qkv[:, :ch], qkv[:, ch:2 * ch], qkv[:, 2 * ch:]
     scale = F32(1.0 / math.sqrt(math.sqrt(ch)))
-    w = np.einsum("bct,bcs->bts", q * scale, k * scale).astype(F32)
+    w = np.matmul((q * scale).transpose(0, 2, 1), k * scale).astype(F32)            # "bct,bcs->bts"
     bias = rel_bias(P[p + ".relative_pos_embeddings.relative_attention_bias.weight"], T, ch ** 0.5)
     w = (w.reshape(B, heads, T, T) + bias[None]).reshape(B * heads, T, T)
     w = ops.softmax(w, -1)
-    a = np.einsum("bts,bcs->bct", w, v).astype(F32).reshape(B, C, T)
+    a = np.matmul(v, w.transpose(0, 2, 1)).astype(F32).reshape(B, C, T)               # "bts,bcs->bct"
     return x + ops.conv1d(a, P[p + ".proj_out.weight"], P[p + ".proj_out.bias"])
 
 

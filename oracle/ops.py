@@ -60,12 +60,13 @@ def linear(x, w, b=None):
 
 
 def group_norm(x, groups, gamma, beta, eps=1e-5):
-    """torch.nn.GroupNorm on [B,C,T] (biased variance)."""
+    """torch.nn.GroupNorm on [B,C,T] (biased variance); statistics in float64, apply in float32."""
     B, C, T = x.shape
-    xg = x.reshape(B, groups, -1).astype(np.float64)
-    mean = xg.mean(-1, keepdims=True)
-    var = xg.var(-1, keepdims=True)
-    y = ((xg - mean) / np.sqrt(var + eps)).reshape(B, C, T)
+    xg = x.reshape(B, groups, -1)
+    mean = xg.mean(-1, keepdims=True, dtype=np.float64)
+    var = np.square(xg - mean.astype(F32)).mean(-1, keepdims=True, dtype=np.float64)
+    rstd = (1.0 / np.sqrt(var + eps)).astype(F32)
+    y = ((xg - mean.astype(F32)) * rstd).reshape(B, C, T)
     return (y * gamma[None, :, None] + beta[None, :, None]).astype(F32)
 
 
@@ -95,7 +96,7 @@ def layer_norm_channels(x, gamma, beta, eps=1e-5):
 
 
 def sigmoid(x):
-    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
+    return (1.0 / (1.0 + np.exp(-np.asarray(x, F32)))).astype(F32)
 
 
 def silu(x):
@@ -119,11 +120,11 @@ def leaky_relu(x, slope):
 
 
 def softmax(x, axis=-1):
-    x64 = x.astype(np.float64)
-    m = x64.max(axis=axis, keepdims=True)
-    m = np.where(np.isfinite(m), m, 0.0)
-    e = np.exp(x64 - m)
-    return (e / e.sum(axis=axis, keepdims=True)).astype(F32)
+    x = np.asarray(x, F32)
+    m = x.max(axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, F32(0))
+    e = np.exp(x - m)
+    return (e / e.sum(axis=axis, keepdims=True, dtype=np.float64).astype(F32)).astype(F32)
 
 
 def sequence_mask(lengths, max_len):
