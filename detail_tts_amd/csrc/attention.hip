@@ -44,9 +44,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // 1-D grid, XCD-aware: the query blocks of one (sample, head) share K/V -> adjacent logical ids -> same XCD / L2
+    const int nqb = (p.T + QPB - 1) / QPB;
+    const int Lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = Lid % nqb, hb = Lid / nqb;
+    const int h = hb % p.H, b = hb / p.H;
     const int len = p.lens ? p.lens[b] : p.T;
-    const int q0 = blockIdx.x * QPB;
+    const int q0 = qb * QPB;
     if (q0 >= len) return;
 
     const float* base = p.qkv + (long long)b * p.bs;
@@ -255,7 +259,7 @@ static void launch_d(const AttnParams& p, dim3 grid, size_t lds, hipStream_t str
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream) {
     DTTS_REQUIRE(p.B > 0 && p.H > 0 && p.T > 0, "empty attention");
-    dim3 grid(cdiv(p.T, QPB), p.H, p.B);
+    dim3 grid(cdiv(p.T, QPB) * p.H * p.B);
     const char* tag = p.D == 48 ? "flash_attn_kernel<48>" : p.D == 64 ? "flash_attn_kernel<64>" : p.D == 96 ? "flash_attn_kernel<96>" : "flash_attn_kernel<192>";
     const double pairs = (double)p.B * p.H * (double)p.T * p.T * (p.causal ? 0.5 : 1.0);
     ProfScope ps(tag, 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);

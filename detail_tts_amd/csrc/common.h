@@ -70,6 +70,13 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
+// XCD-aware block remap (block i runs on XCD i % 8 on MI355X; used for L2 locality only, never for correctness):
+// returns a logical block id such that each XCD owns one contiguous range of logical ids.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int i, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = i & 7, j = i >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
 }  // namespace dtts

@@ -38,9 +38,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.z;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid, XCD-aware: all M-tiles of one (sample, N-tile) are adjacent logical ids, so the blocks that share an input
+    // tile run on the same XCD and hit its L2 (the weights, 2-7 MB, are read by every XCD anyway)
+    const int mtiles = p.CoutP / BM, ntiles = (p.Nout + BN - 1) / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L % mtiles, nb = L / mtiles;
+    const int b = nb / ntiles;
+    const int m0 = mt * BM;
+    const int n0 = (nb - b * ntiles) * BN;
     const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
     if (n0 >= nvalid) return;
     const int lin = p.len_in ? p.len_in[b] : p.Tin;
@@ -250,7 +255,7 @@ void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
         DTTS_REQUIRE(p.CoutP % BM == 0 && p.CinP % BK == 0, "packed weight padding");                                     \
         const size_t lds = sizeof(float) * (2 * BK * BM + 2 * BK * (XW + 1));                                             \
         DTTS_REQUIRE(lds <= 160 * 1024, "conv LDS tile");                                                                 \
-        dim3 grid(p.CoutP / BM, cdiv(p.Nout, BN), p.B);                                                                   \
+        dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);                                                               \
         const int pro = p.pro_ab ? (p.pro_act == ACT_SILU ? 1 : 2)                                                        \
                                  : (p.pro_act == ACT_LRELU ? 3 : (p.pro_act == ACT_SILU ? 4 : 0));                        \
         DTTS_REQUIRE(p.pro_ab ? (p.pro_act == ACT_SILU || p.pro_act == ACT_NONE)                                          \
