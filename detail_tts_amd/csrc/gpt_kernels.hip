@@ -111,29 +111,39 @@ __global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restric
             rstd[b] = rsqrtf(fmaxf(Q / (float)K - m * m, 0.f) + 1e-5f);
         }
     }
-    if (col >= CoutP) return;
+    // LN: normalise this slice's input rows once into LDS (rows_per_slice <= 64), then stream the weights
+    __shared__ float xs[LN ? NB : 1][LN ? 64 : 1];
+    if (LN) {
+        const int nrow = k1 - k0;
+        for (int e = lane; e < NB * nrow; e += 64) {
+            const int b = e / nrow, i = e - b * nrow;
+            const int bb = b < B ? b : B - 1;
+            // mean/rstd live in registers indexed by the compile-time row id: select without dynamic indexing
+            float m = 0.f, r = 0.f;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (q == b) { m = mean[q]; r = rstd[q]; }
+            xs[b][i] = (x[(long long)bb * x_stride + k0 + i] - m) * r * gam[k0 + i] + bet[k0 + i];
+        }
+        __syncthreads();
+    }
     float4 acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* wp = W + (long long)k0 * CoutP + col;
     int i = k0;
+    if (col < CoutP) {
     for (; i + 4 <= k1; i += 4) {
         float4 w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (long long)u * CoutP);
         wp += 4LL * CoutP;
-        float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (LN) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { gg[u] = gam[i + u]; bb4[u] = bet[i + u]; }
-        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float* xr = x + (long long)(b < B ? b : B - 1) * x_stride + i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                float xv = xr[u];
-                if (LN) xv = (xv - mean[b]) * rstd[b] * gg[u] + bb4[u];
+                const float xv = LN ? xs[b][i - k0 + u] : xr[u];
                 acc[b].x += w[u].x * xv; acc[b].y += w[u].y * xv; acc[b].z += w[u].z * xv; acc[b].w += w[u].w * xv;
             }
         }
@@ -143,11 +153,12 @@ __global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restric
         wp += CoutP;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            float xv = x[(long long)(b < B ? b : B - 1) * x_stride + i];
-            if (LN) xv = (xv - mean[b]) * rstd[b] * gam[i] + bet[i];
+            const float xv = LN ? xs[b][i - k0] : x[(long long)(b < B ? b : B - 1) * x_stride + i];
             acc[b].x += w.x * xv; acc[b].y += w.y * xv; acc[b].z += w.z * xv; acc[b].w += w.w * xv;
         }
     }
+    }
+    if (col >= CoutP) return;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
         if (b < B) *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * B + b) * CoutP + col) = acc[b];
@@ -175,6 +186,7 @@ void launch_gemv_partial_ln(const float* W, int K, int CoutP, const float* x, in
                             const float* stats, int nblk, const float* gamma, const float* beta, hipStream_t s) {
     DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && CoutP % 4 == 0, "gemv shape");
     DTTS_REQUIRE((long long)slices * CoutP <= 262144, "gemv partial scratch");
+    DTTS_REQUIRE(cdiv(K, slices) <= 64, "LN prologue slice too long");
     gemv_partial_dispatch<1>(W, K, CoutP, x, x_stride, B, part, slices, stats, nblk, gamma, beta, s);
 }
 
