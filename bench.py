@@ -163,8 +163,19 @@ def main():
         # The cond / uncond halves of every diffusion forward run on two HIP streams, so two launches of this kernel are usually
         # co-resident: the chip-level rate is flops / (union of the launch intervals); avg_launch_us is the raw per-launch mean.
         ach = dom["flops"] / (dom["union_ms"] * 1e-3) / 1e12
+        # HBM-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
+        # same kernel at the bench's per-launch shapes; bench.py cannot attach rocprof to itself).  Launch mix of one diffusion
+        # layer: in_layers 1x1, out_layers k3, qkv 1x1 (M=2304), proj 1x1.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+            mix = ["768->768 k1", "768->768 k3", "768->2304 k1", "768->768 k1"]
+            traffic = round(sum((tj[k]["fetch_MB"] + tj[k]["write_MB"]) for k in mix) / len(mix) * 1e6)
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": dom["launches"],
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
                 "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                 "busy_share_of_timed_region": round(dom["union_ms"] * 1e-3 / dt, 3),
                 "overlap": round(dom["total_ms"] / max(dom["union_ms"], 1e-9), 3),
