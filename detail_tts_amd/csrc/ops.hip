@@ -39,7 +39,22 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long lon
     const bool vec = ((x_cs & 3) == 0) && ((reinterpret_cast<unsigned long long>(xg) & 15ull) == 0);
     if (vec) {
         const int len4 = len >> 2;
-        for (int c = 0; c < cpg; ++c) {
+        // 8 rows per pass: 8 independent 16-byte loads in flight per thread
+        int c = 0;
+        for (; c + 8 <= cpg; c += 8) {
+            for (int t = threadIdx.x; t < len4; t += blockDim.x) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(xg + (long long)(c + u) * x_cs)[t];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float d0 = v[u].x - k, d1 = v[u].y - k, d2 = v[u].z - k, d3 = v[u].w - k;
+                    s1 += (d0 + d1) + (d2 + d3);
+                    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+        }
+        for (; c < cpg; ++c) {
             const float4* row = reinterpret_cast<const float4*>(xg + (long long)c * x_cs);
             for (int t = threadIdx.x; t < len4; t += blockDim.x) {
                 const float4 v = row[t];
@@ -47,12 +62,13 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long lon
                 s1 += (d0 + d1) + (d2 + d3);
                 s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
+        }
+        for (int cc = 0; cc < cpg; ++cc)
             for (int t = (len4 << 2) + threadIdx.x; t < len; t += blockDim.x) {
-                const float d = xg[(long long)c * x_cs + t] - k;
+                const float d = xg[(long long)cc * x_cs + t] - k;
                 s1 += d;
                 s2 += d * d;
             }
-        }
     } else {
         for (int c = 0; c < cpg; ++c)
             for (int t = threadIdx.x; t < len; t += blockDim.x) {
