@@ -192,3 +192,27 @@ def test_sampler_varlen_batch_equals_single(rt, weights):
     for b, L in enumerate(lens):
         xs = host(rt.diff_sample(dev(ce[b:b + 1, :, :L]), 99, [11 + b], n_steps=2, denorm=True))
         assert maxabs(xb[b, :, :L], xs[0]) < 1e-4, b
+
+
+def test_tiny_and_ragged_lengths(rt, weights):
+    """T = 4 (one code), and lengths that are not multiples of any tile."""
+    from oracle import diffusion as D
+    rs = np.random.RandomState(8)
+    sched = D.make_schedule()
+    for T in (4, 68, 132):
+        x = rs.randn(1, 128, T).astype(np.float32)
+        ce = rs.randn(1, 768, T).astype(np.float32)
+        out = host(rt.diff_forward(dev(x), 33, dev(ce)))
+        ref = D.diffusion_forward(weights, x, [sched["timestep_map"][33]], ce)
+        assert maxabs(out, ref) < 3e-4, T
+
+
+def test_errors_are_reported_not_crashes(rt):
+    from detail_tts_amd.runtime import DttsError
+    x = torch.zeros(1, 128, 8, device="cuda")
+    with pytest.raises(DttsError):
+        rt.diff_forward(x, 50, torch.zeros(1, 768, 8, device="cuda"))          # step out of range
+    with pytest.raises(DttsError):
+        rt.diff_forward(x.cpu(), 1, None)                                        # host tensor
+    with pytest.raises(DttsError):
+        rt.op_attention_block("diffusion.layers.99.attn", torch.zeros(1, 768, 8, device="cuda"))

@@ -55,3 +55,21 @@ def test_load_model_surface():
     m = load_model("vqvae", "synthetic:0", None, "cuda:0")
     assert hasattr(m, "infer") and hasattr(m, "infer_flowvae") and hasattr(m.gpt, "inference_speech_tortoise")
     assert hasattr(m.diffusion, "get_conditioning") and hasattr(m.dec, "forward")
+
+
+def test_full_size_batch_invariance_and_determinism(model):
+    """BASELINE full size (10 s prompt, 234 codes -> T = 936): an utterance inside a batch of 3 equals the same utterance
+    alone (same seed / stream id), and a repeated run is bit-identical (no atomics, fixed reduction orders)."""
+    rs = np.random.RandomState(5)
+    B = 3
+    refer = torch.from_numpy((rs.randn(B, 128, 936) * 2 - 5).astype(np.float32))
+    text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, 60)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+    kw = dict(seed=77, max_generate_length=235, suppress_eos=True, return_lengths=True)
+    wav, lens = model.infer(text, torch.full((B,), 61), refer, torch.full((B,), 936), batch=True, sample_ids=[40, 41, 42], **kw)
+    assert lens == [234 * 1024] * B and torch.isfinite(wav).all()
+    wav2, _ = model.infer(text, torch.full((B,), 61), refer, torch.full((B,), 936), batch=True, sample_ids=[40, 41, 42], **kw)
+    assert torch.equal(wav, wav2)
+    alone, _ = model.infer(text[1:2], torch.tensor([61]), refer[1:2], torch.tensor([936]), batch=True, sample_ids=[41], **kw)
+    diff = (wav[1] - alone[0]).double()
+    assert float(diff.pow(2).mean().sqrt()) < 1e-5, float(diff.abs().max())
+    assert float(wav[1].double().pow(2).mean().sqrt()) > 1e-3

@@ -71,3 +71,25 @@ def test_generate_batch_varlen_vs_oracle(rt, weights, top_k):
                                top_k=top_k or None, return_latents=True)
         assert np.array_equal(codes[b, :ref.shape[1]], ref[0]), (b, codes[b], ref)
         assert maxabs(host(lat)[b, :, :ref.shape[1]], rlat[0].T) < 2e-4
+
+
+def test_early_stop_rows_are_padded_and_latched(rt, golden):
+    """A row that draws the stop token keeps emitting 8193 (HF pad) while the other rows continue; ncodes counts the stop."""
+    g = golden("gpt_forced")
+    refer = np.repeat(g["refer"], 2, 0)
+    forced = [np.array([11, 22, 8193, 5, 6, 7]), np.array([1, 2, 3, 4, 5, 6])]
+    codes, ncodes, _ = rt.gpt_generate(dev(refer), None, [g["text"][0], g["text"][0]], 1, [0, 1], max_generate_length=6,
+                                       forced_codes=forced)
+    assert codes[0].tolist() == [11, 22, 8193, 8193, 8193, 8193] and ncodes[0] == 3
+    assert codes[1].tolist() == [1, 2, 3, 4, 5, 6] and ncodes[1] == 6
+
+
+def test_single_token_and_limits(rt, golden):
+    g = golden("gpt_forced")
+    codes, ncodes, lat = rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], 3, [9], max_generate_length=1)
+    assert codes.shape == (1, 1) and ncodes[0] == 1 and torch.isfinite(lat).all()
+    from detail_tts_amd.runtime import DttsError
+    with pytest.raises(DttsError):
+        rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], 3, [9], max_generate_length=5000)      # > max_mel_tokens
+    with pytest.raises(DttsError):
+        rt.gpt_generate(dev(np.repeat(g["refer"], 17, 0)), None, [g["text"][0]] * 17, 3, list(range(17)), max_generate_length=2)

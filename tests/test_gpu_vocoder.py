@@ -71,3 +71,21 @@ def test_vocoder_varlen_batch_vs_oracle(rt, weights):
         got = wav[b, 0, :256 * L]
         assert rms(got, ref) < 1e-4, (b, rms(got, ref))
         assert np.all(wav[b, 0, 256 * L:] == 0)
+
+
+def test_vocoder_rejects_bad_length(rt):
+    from detail_tts_amd.runtime import DttsError
+    with pytest.raises(DttsError):
+        rt.vocoder(torch.zeros(1, 128, 42, device="cuda"), 0, [0])              # T % 4 != 0 (model_24k.py:851)
+
+
+def test_generator_long_input_halo_consistency(rt, weights):
+    """Chunk invariance: the generator is purely convolutional, so the middle of a long input equals the same frames
+    synthesised inside a shorter window with a 16-frame halo (SURVEY App. B receptive field)."""
+    rs = np.random.RandomState(12)
+    z = rs.randn(1, 192, 160).astype(np.float32)
+    g = rs.randn(1, 768).astype(np.float32) * 0.1
+    full = host(rt.generator(dev(z), dev(g)))[0, 0]
+    part = host(rt.generator(dev(z[:, :, 40:120]), dev(g)))[0, 0]
+    a, b = full[(40 + 16) * 256:(120 - 16) * 256], part[16 * 256:(80 - 16) * 256]
+    assert maxabs(a, b) < 1e-5
