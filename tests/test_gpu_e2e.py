@@ -73,3 +73,19 @@ def test_full_size_batch_invariance_and_determinism(model):
     diff = (wav[1] - alone[0]).double()
     assert float(diff.pow(2).mean().sqrt()) < 1e-5, float(diff.abs().max())
     assert float(wav[1].double().pow(2).mean().sqrt()) > 1e-3
+
+
+def test_load_model_from_reference_style_checkpoint(tmp_path, weights):
+    """prepare/load_infer.py:21-26: a torch checkpoint holding the state dict under 'G' (weight-norm g/v pairs, alias and
+    training-only keys present) loads into the same packed weights as the folded dict."""
+    from detail_tts_amd.prepare.load_infer import load_model
+    from detail_tts_amd.weights import synthetic_state_dict
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(0).items()}
+    sd["gpt.inference_model.transformer.ln_f.weight"] = sd["gpt.gpt.ln_f.weight"].clone()       # alias key (ignored)
+    sd["enc_q.pre.weight"] = torch.zeros(4, 4, 1)                                               # training-only key (ignored)
+    path = str(tmp_path / "model-0.pt")
+    torch.save({"step": 1, "epoch": 0, "G": sd}, path)
+    m = load_model("vqvae", path, None, "cuda:0")
+    from detail_tts_amd.vqvae.model_24k import SynthesizerTrn
+    ref = SynthesizerTrn(weights, folded=True)
+    assert torch.equal(m.rt.blob, ref.rt.blob)

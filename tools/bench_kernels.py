@@ -31,5 +31,12 @@ for i, (cin, cout, k, pad) in enumerate(shapes):
         print(f"conv {cin:4d}->{cout:4d} k{k} B{B} T{T}: {st['name']:32s} {st['total_ms']/st['launches']*1e3:8.1f} us  {st['flops']/st['total_ms']/1e9:6.1f} TFLOP/s")
     r.profile_enable(False)
 if os.environ.get("ATTN", "1") == "1":
-    from detail_tts_amd.weights import select_inference_params, synthetic_state_dict
-    W = select_inference_params(synthetic_state_dict(0, only_prefixes=["diffusion.layers.3."]))
+    from detail_tts_amd.weights import select_inference_params, synthetic_state_dict, fold_weight_norm
+    W = fold_weight_norm(synthetic_state_dict(0, only_prefixes=["diffusion."]))
+    rt = Runtime(W, folded=True, parts=("diffusion",))
+    x = torch.randn(B, 768, T, device="cuda")
+    for _ in range(3): rt.op_attention_block("diffusion.layers.3.attn", x)
+    rt.profile_enable(True)
+    for _ in range(10): rt.op_attention_block("diffusion.layers.3.attn", x)
+    for st in rt.profile_report():
+        print(f"attention block B{B} T{T}: {st['name']:32s} {st['total_ms']/st['launches']*1e3:8.1f} us  {st['flops']/st['total_ms']/1e9:6.1f} TFLOP/s")
