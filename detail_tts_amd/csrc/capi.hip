@@ -45,6 +45,13 @@ void dtts_default_config(dtts_config* c) {
     for (int i = 0; i < 3; ++i) { c->resblock_kernels[i] = rk[i]; c->resblock_dilations[i] = rd[i]; }
 }
 
+int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
+                   int B, float* mel_out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->vq_decode(codes, ncodes, nmax, refer, refer_lens, Tr, B, mel_out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_set_option(dtts_handle* h, const char* key, int value) {
     DTTS_API_BEGIN
     h->m->set_option(key, value);

@@ -120,6 +120,9 @@ public:
                  float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s);
     void generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
     void op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
+    // ---- VQ decode path (infer_gpt)
+    void vq_decode(const int* codes_host, const int* ncodes_host, int nmax, const float* refer, const int* refer_lens_host, int Tr,
+                   int B, float* mel_out, hipStream_t s);
     // ---- unit ops used by the parity tests
     void op_attention_block(const char* prefix, const float* x, const int* lens_host, int B, int C, int T, float* y, hipStream_t s);
     void op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y, hipStream_t s);
@@ -147,6 +150,7 @@ private:
     void build_diffusion(hipStream_t s);
     void build_vocoder();
     void build_gpt();
+    void build_vq();
     void gpt_prefill_layers(float* x, const int* lens, int B, int L, float* kv_cache, long long kv_layer_stride, long long kv_bs,
                             int kv_cs, hipStream_t s);
     MelStyleW mel_style_w(const std::string& prefix, int n_mel, int hidden, int out) const;
@@ -198,6 +202,12 @@ private:
     hipStream_t s2_ = nullptr;            // second stream of the two-stream diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     const int* umap_local_ = nullptr;     // [B] uncond sample -> index of its length group
+
+    // vq decode path
+    bool has_vq_ = false;
+    MelStyleW vq_ref_enc_;
+    PackedConv vq_up1_, vq_up2_, vq_out_;
+    const float *vq_table_ = nullptr, *vq_ln_g_ = nullptr, *vq_ln_b_ = nullptr;
 
     Arena ws_;        // per-call activations
     Arena persist_;   // tables built at bind time

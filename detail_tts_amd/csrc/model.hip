@@ -118,6 +118,8 @@ void Model::bind_weights(const void* blob, size_t nbytes, const char* const* nam
     if (has_vocoder_) build_vocoder();
     has_gpt_ = weights_.count("gpt.mel_head.wp") != 0;
     if (has_gpt_) build_gpt();
+    has_vq_ = weights_.count("quantizer.table") != 0;
+    if (has_vq_) build_vq();
     bound_ = true;
 }
 

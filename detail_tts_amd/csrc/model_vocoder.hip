@@ -429,4 +429,80 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     generator(zc, g, l.data(), B, T, wav, s);
 }
 
+// ------------------------------------------------------------------------------------------ VQ decode path
+__global__ void vq_gather_kernel(const float* table, const int* codes, int code_stride, const int* ncodes, const float* g, int C, int nmax,
+                                 float* out) {
+    // out[b][c][t] = table[codes[b][t]][c] + g[b][c]      (quantizer.decode + g_vq, vqvae/model_24k.py:828, 841)
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= ncodes[b]) return;
+    const int code = codes[(long long)b * code_stride + t];
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        out[((long long)b * C + c) * nmax + t] = table[(long long)code * C + c] + g[(long long)b * C + c];
+}
+
+void Model::build_vq() {
+    const int inter = cfg.inter_channels, C = 4 * inter;
+    vq_table_ = W("quantizer.table", (size_t)8192 * C);
+    vq_ln_g_ = W("vq_dec.1.weight", C);
+    vq_ln_b_ = W("vq_dec.1.bias", C);
+    vq_up1_ = conv("vq_dec.3", C, 2 * (2 * inter), 2);          // ConvTranspose1d(k3,s2,p1,op1) as 2 phases x 2 taps
+    vq_up2_ = conv("vq_dec.5", 2 * inter, 2 * inter, 2);
+    vq_out_ = conv("vq_dec.7", inter, cfg.mel_channels, 3);
+    vq_ref_enc_ = mel_style_w("vq_ref_enc", cfg.mel_channels, 128, C);
+}
+
+// infer_gpt's decode: recon = vq_dec(quantizer.decode(codes) + vq_ref_enc(refer * mask, mask))   (vqvae/model_24k.py:828-845)
+void Model::vq_decode(const int* codes_host, const int* ncodes_host, int nmax, const float* refer, const int* refer_lens_host, int Tr,
+                      int B, float* mel_out, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vq_, "vq weights not bound");
+    const int inter = cfg.inter_channels, C = 4 * inter;
+    std::vector<int> n1(B), n2(B), n4(B), rl(B);
+    for (int b = 0; b < B; ++b) {
+        n1[b] = ncodes_host ? ncodes_host[b] : nmax;
+        DTTS_REQUIRE(n1[b] >= 1 && n1[b] <= nmax, "ncodes");
+        for (int t = 0; t < n1[b]; ++t)
+            DTTS_REQUIRE(codes_host[(size_t)b * nmax + t] >= 0 && codes_host[(size_t)b * nmax + t] < 8192, "code outside the 8192-entry codebook");
+        n2[b] = 2 * n1[b];
+        n4[b] = 4 * n1[b];
+        rl[b] = refer_lens_host ? refer_lens_host[b] : Tr;
+    }
+    ws_.ensure(sizeof(float) * ((size_t)2 * B * C * nmax + (size_t)B * 2 * inter * 2 * nmax + (size_t)B * inter * 4 * nmax + (size_t)B * C) +
+               sizeof(int) * (size_t)B * nmax + sizeof(float) * ((size_t)5 * B * 128 * Tr + (size_t)B * C * Tr) + 65536);
+    float* g = ws_.f32((size_t)B * C);
+    float* lat = ws_.f32((size_t)B * C * nmax);
+    float* ln = ws_.f32((size_t)B * C * nmax);
+    float* u1 = ws_.f32((size_t)B * 2 * inter * 2 * nmax);
+    float* u2 = ws_.f32((size_t)B * inter * 4 * nmax);
+    int* dcodes = ws_.i32((size_t)B * nmax);
+    DTTS_CHECK_HIP(hipMemcpyAsync(dcodes, codes_host, sizeof(int) * (size_t)B * nmax, hipMemcpyHostToDevice, s));
+    DTTS_CHECK_HIP(hipStreamSynchronize(s));
+    const int* d1 = upload_ints(n1.data(), B, s);
+    const int* d2 = upload_ints(n2.data(), B, s);
+    const int* d4 = upload_ints(n4.data(), B, s);
+    const int* drl = upload_ints(rl.data(), B, s);
+    {
+        const size_t m = ws_.mark();
+        mel_style(vq_ref_enc_, refer, drl, rl.data(), B, Tr, g, s);
+        ws_.rewind(m);
+    }
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(nmax, B), dim3(256), 0, s, vq_table_, dcodes, nmax, d1, g, C, nmax, lat);
+    DTTS_CHECK_HIP(hipGetLastError());
+    launch_ln_channels(lat, nullptr, (long long)C * nmax, nmax, d1, nmax, B, C, vq_ln_g_, vq_ln_b_, 1e-5f, ln, (long long)C * nmax, nmax, s);
+    ConvParams p = cp(ln, C, u1, 2 * inter, B, nmax, nmax, d1);
+    p.phases = 2;
+    p.epi_act = ACT_SILU;
+    p.y_bs = (long long)2 * inter * 2 * nmax;
+    p.y_cs = 2 * nmax;
+    run_conv(vq_up1_, p, s);
+    p = cp(u1, 2 * inter, u2, inter, B, 2 * nmax, 2 * nmax, d2);
+    p.phases = 2;
+    p.epi_act = ACT_SILU;
+    p.y_bs = (long long)inter * 4 * nmax;
+    p.y_cs = 4 * nmax;
+    run_conv(vq_up2_, p, s);
+    p = cp(u2, inter, mel_out, cfg.mel_channels, B, 4 * nmax, 4 * nmax, d4);
+    p.pad = 1;
+    run_conv(vq_out_, p, s);
+}
+
 }  // namespace dtts

@@ -63,12 +63,12 @@ def gate_perm(n_rows):
     return perm
 
 
-def convtranspose_as_phases(w, stride, padding):
-    """w [Cin, Cout, k] -> (w_eq [stride*Cout, Cin, KW], pad) for the phase decomposition."""
+def convtranspose_as_phases(w, stride, padding, output_padding=0):
+    """w [Cin, Cout, k] -> (w_eq [stride*Cout, Cin, KW], pad) for the phase decomposition (output length T*stride)."""
     w = np.asarray(w, F32)
     cin, cout, k = w.shape
-    if k - stride != 2 * padding:
-        raise ValueError("only ConvTranspose1d with output length == T*stride (k - s == 2p, as in Generator.ups) is supported")
+    if k - stride + output_padding != 2 * padding:
+        raise ValueError("only ConvTranspose1d whose output length is T*stride (k - s + output_padding == 2p) is supported")
     dmin = -((k - 1 - padding) // stride)           # ceil((p-k+1)/s)
     dmax = (stride - 1 + padding) // stride
     kw = dmax - dmin + 1
@@ -265,6 +265,21 @@ def pack_gpt(pk, P, cfg):
         pk.add(n, P[n])
 
 
+def pack_vq(pk, P, cfg):
+    """infer_gpt's decode path: quantizer.decode -> + vq_ref_enc -> vq_dec  (vqvae/model_24k.py:828-845)."""
+    emb = P["quantizer.vq.layers.0._codebook.embed"].astype(np.float64)
+    wo = P["quantizer.vq.layers.0.project_out.weight"].astype(np.float64)
+    # EuclideanCodebook.dequantize + project_out folded into one [bins, 768] lookup table (core_vq.py:188-190, 298-301)
+    pk.add("quantizer.table", (emb @ wo.T + P["quantizer.vq.layers.0.project_out.bias"]).astype(F32))
+    pk.add("vq_dec.1.weight", P["vq_dec.1.weight"])
+    pk.add("vq_dec.1.bias", P["vq_dec.1.bias"])
+    for i in (3, 5):
+        weq, _pad = convtranspose_as_phases(P[f"vq_dec.{i}.weight"], 2, 1, output_padding=1)
+        pk.conv(f"vq_dec.{i}", weq, np.tile(P[f"vq_dec.{i}.bias"], 2))
+    pk.conv("vq_dec.7", P["vq_dec.7.weight"], P["vq_dec.7.bias"])
+    _mel_style(pk, P, "vq_ref_enc")
+
+
 def pack_all(P, cfg=None, parts=("diffusion",)):
     """P: folded fp32 dict (weights.select_inference_params). Returns a Packer."""
     cfg = load_config(cfg)
@@ -275,4 +290,6 @@ def pack_all(P, cfg=None, parts=("diffusion",)):
         pack_vocoder(pk, P, cfg)
     if "gpt" in parts:
         pack_gpt(pk, P, cfg)
+    if "vq" in parts:
+        pack_vq(pk, P, cfg)
     return pk

@@ -34,7 +34,7 @@ def _check(t, name):
         raise DttsError(f"{name}: expected a contiguous float32 CUDA tensor")
 
 
-ALL_PARTS = ("diffusion", "gpt", "vocoder")
+ALL_PARTS = ("diffusion", "gpt", "vocoder", "vq")
 
 
 class Runtime:
@@ -237,6 +237,21 @@ class Runtime:
         li = _ints(lens)
         self._rc(self.lib.dtts_op_mel_style(self.h, which.encode(), _ptr(mel), li[0] if li else None, B, T, _ptr(out), self._stream()))
         return out
+
+    def vq_decode(self, codes_list, refer, refer_lens=None):
+        """infer_gpt's decode: list of int arrays (codes without the stop token) + refer [B,128,Tr] -> mel cuda [B,128,4*nmax]"""
+        _check(refer, "refer")
+        B, _, Tr = refer.shape
+        nn = np.array([len(c) for c in codes_list], np.int32)
+        nmax = int(nn.max())
+        codes = np.zeros((B, nmax), np.int32)
+        for b, c in enumerate(codes_list):
+            codes[b, :len(c)] = np.asarray(c, np.int32)
+        rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
+        mel = torch.zeros((B, self.cfg["data"]["n_mel_channels"], 4 * nmax), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_vq_decode(self.h, codes.ctypes.data_as(_lib.c_int_p), nn.ctypes.data_as(_lib.c_int_p), nmax, _ptr(refer), rl[0], Tr, B,
+                                         _ptr(mel), self._stream()))
+        return mel
 
     # ------------------------------------------------------------------ unit ops
     def op_attention_block(self, prefix, x, lens=None):

@@ -133,6 +133,36 @@ class SynthesizerTrn:
             return wav, [1024 * v for v in n]
         return wav
 
+    def infer_gpt(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
+                  forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False):
+        """vqvae/model_24k.py:811-847: GPT codes -> quantizer.decode + vq_ref_enc -> vq_dec -> infer_flowvae (no diffusion)."""
+        text = torch.as_tensor(text)
+        refer = torch.as_tensor(refer)
+        tl = torch.as_tensor(text_length).reshape(-1).tolist()
+        rl = [int(v) for v in torch.as_tensor(refer_lengths).reshape(-1).tolist()]
+        if not batch:
+            text, refer, tl, rl = text[:1], refer[:1], tl[:1], rl[:1]
+            if forced_codes is not None:
+                forced_codes = forced_codes[:1]
+        B = text.shape[0]
+        refer = refer.to(self.device, torch.float32).contiguous()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        sample_ids = list(range(B)) if sample_ids is None else list(sample_ids)
+        if forced_codes is None:
+            texts = [text[b, : int(tl[b])].cpu().numpy().astype(np.int32) for b in range(B)]
+            codes, ncodes, _ = self.rt.gpt_generate(refer, rl, texts, seed, sample_ids, max_generate_length=max_generate_length,
+                                                    top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
+                                                    repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
+            code_list = [codes[b, : int(ncodes[b]) - 1] for b in range(B)]          # codes[:, :-1]  (:828)
+        else:
+            code_list = [np.asarray(c) for c in forced_codes]
+        if min(len(c) for c in code_list) < 1:
+            raise ValueError("an utterance produced no mel codes (the reference substitutes zeros here, model_24k.py:833-834)")
+        mel = self.rt.vq_decode(code_list, refer, rl)
+        lens_t = [4 * len(c) for c in code_list]
+        return self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
+
     def infer_flowvae(self, y, y_lengths, data=None, noise_scale=NOISE_SCALE, *, batch=False, seed=0, sample_ids=None):
         """vqvae/model_24k.py:848-863"""
         y = torch.as_tensor(y)

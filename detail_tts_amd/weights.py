@@ -224,6 +224,20 @@ def inference_param_spec(cfg=None) -> "OrderedDict[str, tuple]":
     spec["gpt.final_norm.bias"] = ((md,), K_NB)
     spec["gpt.mel_head.weight"] = ((g["number_mel_codes"], md), K_W)
     spec["gpt.mel_head.bias"] = ((g["number_mel_codes"],), K_B)
+
+    # ---- VQ decode path of infer_gpt / infer_vqvae (vqvae/model_24k.py:811-847, 610-624)
+    spec["quantizer.vq.layers.0._codebook.embed"] = ((v["vq_bins"], 8), K_UNCOND)
+    spec["quantizer.vq.layers.0.project_out.weight"] = ((4 * inter, 8), K_W)
+    spec["quantizer.vq.layers.0.project_out.bias"] = ((4 * inter,), K_B)
+    spec["vq_dec.1.weight"] = ((4 * inter,), K_NG)
+    spec["vq_dec.1.bias"] = ((4 * inter,), K_NB)
+    spec["vq_dec.3.weight"] = ((4 * inter, 2 * inter, 3), K_W)            # ConvTranspose1d [in, out, k]
+    spec["vq_dec.3.bias"] = ((2 * inter,), K_B)
+    spec["vq_dec.5.weight"] = ((2 * inter, inter, 3), K_W)
+    spec["vq_dec.5.bias"] = ((inter,), K_B)
+    spec["vq_dec.7.weight"] = ((n_mel, inter, 3), K_W)
+    spec["vq_dec.7.bias"] = ((n_mel,), K_B)
+    _mel_style_encoder(spec, "vq_ref_enc", n_mel, 128, 4 * inter)
     return spec
 
 

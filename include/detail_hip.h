@@ -154,6 +154,12 @@ int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* le
  * mel [B,128,T] -> g [B,768] */
 int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const int* lens, int B, int T, float* g_out, void* stream);
 
+/* ---- VQ decode path of infer_gpt ---------------------------------------------------------------- */
+/* recon = vq_dec(quantizer.decode(codes) + vq_ref_enc(refer*mask, mask))  (vqvae/model_24k.py:828-845).
+ * codes HOST int32 [B][nmax] (< 8192, stop token already dropped), ncodes HOST [B], refer DEVICE [B,128,Tr] -> mel_out DEVICE [B,128,4*nmax] */
+int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
+                   int B, float* mel_out, void* stream);
+
 /* Runtime options: "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams. */
 int dtts_set_option(dtts_handle* h, const char* key, int value);
 

@@ -258,6 +258,20 @@ def main():
     g.inference_speech_tortoise = orig
     save("e2e_forced", refer=refer, text=text, codes=codes, wav=wav_e2e, seed=np.array(SEED_N), sample_id=np.array(5))
 
+    # ---- 10. infer_gpt's VQ decode path (vqvae/model_24k.py:811-847) with forced codes -----------------------
+    vq_codes = rs.randint(0, 8192, size=(1, 9)).astype(np.int64)
+    vq_codes_t = torch.from_numpy(vq_codes)
+    rmask = commons.sequence_mask(rl, refer_t.size(2)).unsqueeze(1).float()
+    latent = m.quantizer.decode(vq_codes_t.unsqueeze(0))
+    g_vq = m.vq_ref_enc(refer_t * rmask, rmask)
+    recon = m.vq_dec(latent + g_vq)
+    g.inference_speech_tortoise = lambda *a, **k: torch.cat([vq_codes_t, torch.tensor([[g.stop_mel_token]])], 1)
+    with philox_rng(sample_id=6):
+        wav_vq = m.infer_gpt(text_t, torch.tensor([text.shape[1]]), refer_t, rl)
+    g.inference_speech_tortoise = orig
+    save("vq_path", refer=refer, codes=vq_codes, latent=latent, g_vq=g_vq, recon=recon, wav=wav_vq, seed=np.array(SEED_N),
+         sample_id=np.array(6))
+
 
 if __name__ == "__main__":
     main()

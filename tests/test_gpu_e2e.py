@@ -89,3 +89,26 @@ def test_load_model_from_reference_style_checkpoint(tmp_path, weights):
     from detail_tts_amd.vqvae.model_24k import SynthesizerTrn
     ref = SynthesizerTrn(weights, folded=True)
     assert torch.equal(m.rt.blob, ref.rt.blob)
+
+
+def test_infer_gpt_forced_codes_vs_reference_golden(model, golden):
+    """SynthesizerTrn.infer_gpt (vqvae/model_24k.py:811-847: no diffusion, VQ decoder -> flow-VAE) vs the reference's waveform."""
+    g = golden("vq_path")
+    text = torch.zeros((1, 4), dtype=torch.int32)
+    wav = model.infer_gpt(text, torch.tensor([4]), torch.from_numpy(g["refer"]), torch.tensor([g["refer"].shape[2]]),
+                          seed=int(g["seed"]), sample_ids=[int(g["sample_id"])], forced_codes=[g["codes"][0]]).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    assert rms(wav, g["wav"]) < 1e-3
+
+
+def test_infer_gpt_free_sampling_vs_oracle(model, weights):
+    from oracle import gpt as G, vq
+    rs = np.random.RandomState(34)
+    refer = (rs.randn(1, 128, 44) * 2 - 5).astype(np.float32)
+    text = np.concatenate([rs.randint(3, 255, 7), [0]]).astype(np.int32)
+    wav = model.infer_gpt(torch.from_numpy(text[None]), torch.tensor([8]), torch.from_numpy(refer), torch.tensor([44]), seed=99,
+                          sample_ids=[12], max_generate_length=6, suppress_eos=True).cpu().numpy()
+    codes = G.generate(weights, refer, np.array([44]), text[None].astype(np.int64), 99, [12], 6, suppress_eos=True)
+    ref = vq.infer_gpt_from_codes(weights, codes[0, :-1], refer[0], 99, 12)
+    assert wav.shape[2] == ref.shape[0]
+    assert rms(wav[0, 0], ref) < 1e-3

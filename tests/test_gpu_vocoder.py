@@ -89,3 +89,39 @@ def test_generator_long_input_halo_consistency(rt, weights):
     part = host(rt.generator(dev(z[:, :, 40:120]), dev(g)))[0, 0]
     a, b = full[(40 + 16) * 256:(120 - 16) * 256], part[16 * 256:(80 - 16) * 256]
     assert maxabs(a, b) < 1e-5
+
+
+# ---------------------------------------------------------------------------- infer_gpt's VQ decode path
+@pytest.fixture(scope="module")
+def rt_vq(weights):
+    from detail_tts_amd.runtime import Runtime
+    return Runtime(weights, folded=True, parts=("vocoder", "vq"))
+
+
+def test_vq_decode_golden(rt_vq, golden):
+    g = golden("vq_path")
+    mel = host(rt_vq.vq_decode([g["codes"][0]], dev(g["refer"])))
+    assert mel.shape == g["recon"].shape
+    assert maxabs(mel, g["recon"]) < 2e-4, maxabs(mel, g["recon"])
+    wav = host(rt_vq.vocoder(dev(mel), int(g["seed"]), [int(g["sample_id"])]))
+    assert rms(wav, g["wav"]) < 1e-4
+
+
+def test_vq_decode_varlen_batch_vs_oracle(rt_vq, weights):
+    from oracle import vq
+    rs = np.random.RandomState(21)
+    refer = (rs.randn(2, 128, 50) * 2 - 5).astype(np.float32)
+    rl = [50, 37]
+    codes = [rs.randint(0, 8192, size=23), rs.randint(0, 8192, size=14)]
+    mel = host(rt_vq.vq_decode(codes, dev(refer), rl))
+    assert mel.shape == (2, 128, 92)
+    for b in range(2):
+        ref = vq.vq_decode_mel(weights, codes[b][None], refer[b:b + 1, :, :rl[b]], [rl[b]])[0]
+        assert maxabs(mel[b, :, :4 * len(codes[b])], ref) < 2e-4, b
+        assert np.all(mel[b, :, 4 * len(codes[b]):] == 0)
+
+
+def test_vq_decode_rejects_out_of_codebook(rt_vq):
+    from detail_tts_amd.runtime import DttsError
+    with pytest.raises(DttsError):
+        rt_vq.vq_decode([np.array([5, 8192])], torch.zeros(1, 128, 20, device="cuda"))      # start/stop tokens are not codebook rows

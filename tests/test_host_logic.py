@@ -34,7 +34,9 @@ def test_weight_spec_counts():
     from detail_tts_amd.weights import folded_param_names, inference_param_spec
     spec = inference_param_spec()
     n = sum(int(np.prod(s)) for s, _ in spec.values())
-    assert abs(n - 266.355e6) < 1e4           # 266.35 M unique inference parameters
+    assert abs(n - 268.136e6) < 1e4           # 266.35 M for infer + 1.78 M for infer_gpt's VQ decode path
+    n_vq = sum(int(np.prod(s)) for k, (s, _) in spec.items() if k.startswith(("quantizer.", "vq_dec.", "vq_ref_enc.")))
+    assert abs(n - n_vq - 266.355e6) < 1e4
     assert len(folded_param_names()) == len(spec) - sum(k.endswith(".weight_v") for k in spec)
 
 
@@ -99,6 +101,29 @@ def test_convtranspose_phase_decomposition_against_oracle():
         y = rows.reshape(2, s, cout, nq).transpose(0, 2, 3, 1).reshape(2, cout, nq * s)
         assert y.shape == ref.shape
         np.testing.assert_allclose(y, ref, atol=1e-4)
+
+
+def test_vq_dec_upsample_phases_against_oracle():
+    """ConvTranspose1d(k3, s2, p1, output_padding 1) of vq_dec (vqvae/model_24k.py:613-618) = 2 phases x 2 taps, no padding,
+    N = T outputs per phase with the input read as zero past its end."""
+    from detail_tts_amd.packing import convtranspose_as_phases, pack_conv
+    from oracle import vq
+    rs = np.random.RandomState(4)
+    w, b = rs.randn(9, 5, 3).astype(np.float32), rs.randn(5).astype(np.float32)
+    x = rs.randn(2, 9, 11).astype(np.float32)
+    weq, pad = convtranspose_as_phases(w, 2, 1, output_padding=1)
+    assert weq.shape == (10, 9, 2) and pad == 0
+    wp, bp = pack_conv(weq, np.tile(b, 2))
+    rows = _packed_conv_ref(np.pad(x, ((0, 0), (0, 0), (0, 1))), wp, bp, 10, 2, 0)          # [B, 2*cout, T]
+    y = rows.reshape(2, 2, 5, 11).transpose(0, 2, 3, 1).reshape(2, 5, 22)
+    ref = vq.conv_transpose1d_op(x, w, b, 2, 1, 1)
+    torch = pytest.importorskip("torch")
+    tref = torch.nn.functional.conv_transpose1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=2, padding=1,
+                                                output_padding=1).numpy()
+    np.testing.assert_allclose(ref, tref, atol=1e-5)
+    np.testing.assert_allclose(y, ref, atol=1e-4)
+    with pytest.raises(ValueError):
+        convtranspose_as_phases(w, 2, 1)                                                     # output length != 2T
 
 
 def test_gate_perm_and_bias_table():

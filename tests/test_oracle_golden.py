@@ -149,3 +149,19 @@ def test_end_to_end_forced_codes(weights, golden):
     assert wav.shape == ref.shape
     rms = float(np.sqrt(np.mean((wav - ref) ** 2)))
     assert rms < 1e-3, rms          # north_star tolerance on the 24 kHz waveform
+
+
+def test_vq_decode_path(weights, golden):
+    """infer_gpt's decode (vqvae/model_24k.py:828-845): quantizer.decode -> + vq_ref_enc -> vq_dec -> infer_flowvae."""
+    from oracle import vq
+    g = golden("vq_path")
+    assert maxabs(vq.quantizer_decode(weights, g["codes"]), g["latent"]) < 1e-5
+    T = g["refer"].shape[2]
+    assert maxabs(G.mel_style_encoder(weights, "vq_ref_enc", g["refer"], [T]), g["g_vq"]) < 1e-4
+    mel = vq.vq_decode_mel(weights, g["codes"], g["refer"], [T])
+    assert mel.shape == g["recon"].shape
+    assert maxabs(mel, g["recon"]) < 1e-4
+    wav = vq.infer_gpt_from_codes(weights, g["codes"][0], g["refer"][0], int(g["seed"]), int(g["sample_id"]))
+    ref = g["wav"][0, 0]
+    assert wav.shape == ref.shape
+    assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-3
