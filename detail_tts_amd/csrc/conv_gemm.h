@@ -48,6 +48,10 @@ struct ConvParams {
     int Nout = 0;                  // number of GEMM columns per sample (max)
     int phases = 1;                // ConvTranspose: packed row = ph*Cout + co, t_out = n*phases + ph
     int B = 0;
+    // split-precision path (conv_x3.h): pre-split operands; when both are set launch_conv_x3 is used instead
+    const void* w3 = nullptr;
+    const void* x3 = nullptr;
+    int x3_tp = 0;
     int ablate = 0;                // experiments only (DTTS_CONV_ABLATE): 1 skip global loads, 2 skip LDS stores, 4 skip barriers
 };
 

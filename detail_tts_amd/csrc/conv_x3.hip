@@ -1,0 +1,232 @@
+// Split-precision (3 x bf16) conv GEMM for gfx950 — see conv_x3.h.
+//
+// 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA 32x32x16 tiles x 6 products = 24 MFMAs per
+// K-step.  LDS: 2 stages x (W tile 12 KiB + X tile 12 KiB) = 48 KiB -> 3 workgroups per CU.  Per K-step a wave issues 6 LDS-DMA
+// loads (1 KiB each; waves 0,1 fetch W, waves 2,3 fetch X), 12 ds_read_b128 and 24 MFMAs behind ONE barrier.
+#include "conv_x3.h"
+#include "prof.h"
+
+namespace dtts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int BM = 128, BN = 128, TILE = 6 * 128 * 16, NSTAGE = 2;
+
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_f(unsigned h) { return __uint_as_float(h << 16); }
+// v = p0 + p1 + p2 with every partial difference exact in fp32
+__device__ __forceinline__ void split3(float v, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = bf16_rne(v);
+    const float r1 = v - bf16_f(p0);
+    p1 = bf16_rne(r1);
+    const float r2 = r1 - bf16_f(p1);
+    p2 = bf16_rne(r2);
+}
+__device__ __forceinline__ void split8(const float* v, uint4& q0, uint4& q1, uint4& q2) {
+    unsigned a[8], b[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(v[e], a[e], b[e], c[e]);
+    q0 = make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16));
+    q1 = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+    q2 = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ wp, int C8, int CoutP, uint4* __restrict__ out) {
+    const int m = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, tap = blockIdx.z;
+    if (m >= CoutP) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = wp[((long long)tap * C8 * 8 + c8 * 8 + e) * CoutP + m];
+    uint4 q0, q1, q2;
+    split8(v, q0, q1, q2);
+    uint4* o = out + ((long long)(tap * C8 + c8) * 3) * CoutP + m;
+    o[0] = q0;
+    o[CoutP] = q1;
+    o[2 * (long long)CoutP] = q2;
+}
+
+template <int ACT, bool AB>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long x_bs, int x_cs,
+                                                          const float* __restrict__ ab, const int* __restrict__ lens, int T, int C8,
+                                                          int Tp, uint4* __restrict__ out) {
+    const int tp = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, b = blockIdx.z;
+    if (tp >= Tp) return;
+    const int t = tp - X3_HALO, len = lens ? lens[b] : T;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
+    if (t >= 0 && t < len) {
+        const float* xr = x + (long long)b * x_bs + (long long)(c8 * 8) * x_cs + t;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xr[(long long)e * x_cs];
+        if (AB) {
+            const float* abr = ab + ((long long)b * C8 + c8) * 16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = abr[2 * e] * v[e] + abr[2 * e + 1];
+        }
+        if (ACT == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * __frcp_rn(1.f + __expf(-v[e]));
+        }
+        split8(v, q0, q1, q2);
+    }
+    uint4* o = out + ((long long)(b * C8 + c8) * 3) * Tp + tp;
+    o[0] = q0;
+    o[Tp] = q1;
+    o[2 * (long long)Tp] = q2;
+}
+
+template <int EPI>   // 0: bias (+ residual); 1: + activation / out_scale
+__global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
+    const int mtiles = p.CoutP / BM, ntiles = (p.Nout + BN - 1) / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L % mtiles, nb = L / mtiles;
+    const int b = nb / ntiles;
+    const int m0 = mt * BM, n0 = (nb - b * ntiles) * BN;
+    const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
+    if (n0 >= nvalid) return;
+    const int C8 = p.Cin >> 3, c16n = p.Cin >> 4, nks = p.KW * c16n, Tp = p.x3_tp;
+    const int bin = p.x_bidx ? p.x_bidx[b] : b;
+
+    const int operand = wave >> 1;                     // waves 0,1 fetch the W tile, waves 2,3 the X tile
+    const uint4* gbase = operand ? static_cast<const uint4*>(p.x3) + (long long)bin * C8 * 3 * Tp + n0 + (X3_HALO - p.pad)
+                                 : static_cast<const uint4*>(p.w3) + m0;
+    const long long rowlen = operand ? Tp : p.CoutP;   // chunks per (c8, plane) run
+    const long long tapstride = operand ? 1 : (long long)C8 * 3 * p.CoutP;
+    auto issue = [&](int ks, int stage) {
+        const int tap = ks / c16n, c16 = ks - tap * c16n;
+        unsigned char* lbase = smem + stage * 2 * TILE + operand * TILE;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int j = (wave & 1) * 6 + i, kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
+            const uint4* g = gbase + tap * tapstride + ((long long)(2 * c16 + h) * 3 + pl) * rowlen + rh * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lbase + kind * 2048 + rh * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    for (int ks = 0; ks < nks; ++ks) {
+        // the loads of stage ks were issued one whole K-step ago; the barrier also orders the previous step's ds_reads of the
+        // stage that is refilled next (WAR)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(min(ks + 1, nks - 1), (ks + 1) & 1);     // the last step refetches itself into the idle stage: branch-free
+        const unsigned char* As = smem + (ks & 1) * 2 * TILE + lhi * 2048;
+        const unsigned char* Bs = As + TILE;
+        bf16x8 a[2][3], bb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * 4096 + (wm0 + i * 32 + l31) * 16);
+                bb[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * 4096 + (wn0 + i * 32 + l31) * 16);
+            }
+        // smallest terms first
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
+
+    // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* yb = p.y + (long long)b * p.y_bs;
+    const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn0 + j * 32 + l31;
+            if (n >= nvalid) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[row];
+                if (EPI == 1) v = act_apply(v, p.epi_act, p.epi_slope) * p.out_scale;
+                if (rb) v += p.res_scale * rb[(long long)row * p.res_cs + n];
+                yb[(long long)row * p.y_cs + n] = v;
+            }
+        }
+}
+}  // namespace
+
+void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* out, hipStream_t s) {
+    DTTS_REQUIRE(CinP % 16 == 0 && CoutP % 128 == 0, "split_weights: padding");
+    hipLaunchKernelGGL(split_weights_kernel, dim3(cdiv(CoutP, 256), CinP / 8, KW), dim3(256), 0, s, wp, CinP / 8, CoutP,
+                       static_cast<uint4*>(out));
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* ab, int act, const int* lens, int T, int B, int C,
+                         void* out, hipStream_t s) {
+    DTTS_REQUIRE(C % 16 == 0, "split_planes: channels must be a multiple of 16");
+    DTTS_REQUIRE(act == ACT_NONE || act == ACT_SILU, "split_planes: activation");
+    const int Tp = x3_tp(T);
+    const dim3 grid(cdiv(Tp, 256), C / 8, B);
+    uint4* o = static_cast<uint4*>(out);
+    const double n = (double)B * C * T;
+    ProfScope ps("split_planes_kernel", 0.0, n * 10.0, s);
+    if (ab) {
+        if (act == ACT_SILU) hipLaunchKernelGGL((split_planes_kernel<ACT_SILU, true>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
+        else hipLaunchKernelGGL((split_planes_kernel<ACT_NONE, true>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
+    } else {
+        if (act == ACT_SILU) hipLaunchKernelGGL((split_planes_kernel<ACT_SILU, false>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
+        else hipLaunchKernelGGL((split_planes_kernel<ACT_NONE, false>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
+    }
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+void launch_conv_x3(const ConvParams& p, hipStream_t s) {
+    DTTS_REQUIRE(p.w3 && p.x3 && p.y && p.x3_tp > 0, "conv_x3: operands");
+    DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
+    DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3: channel padding");
+    DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
+    DTTS_REQUIRE(p.pad <= X3_HALO && p.KW - 1 - p.pad <= X3_HALO, "conv_x3: halo");
+    DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
+    static bool attr = false;
+    constexpr size_t lds = (size_t)NSTAGE * 2 * TILE;
+    if (!attr) {
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);
+    const double cols = (double)p.B * p.Nout;
+    const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 6x this in bf16
+    const double bytes = 6.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 6.0 * (double)p.Cout * p.Cin * p.KW;
+    {
+        ProfScope ps("conv_x3_kernel<128,128>", flops, bytes, s);
+        if (p.epi_act != ACT_NONE || p.out_scale != 1.f) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), lds, s, p);
+    }
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace dtts

@@ -20,6 +20,7 @@ struct PackedConv {
     const float* w = nullptr;
     const float* b = nullptr;   // padded to CoutP, packed row order (may be null)
     int Cin = 0, CinP = 0, Cout = 0, CoutP = 0, KW = 1;
+    const void* w3 = nullptr;   // split-precision copy [KW][Cin/8][3][CoutP][8 bf16] (conv_x3.h), hot diffusion convs only
 };
 
 static inline int packed_cout(int cout) { return cout > 64 ? round_up(cout, 128) : (cout > 32 ? 64 : 32); }
@@ -134,6 +135,7 @@ public:
 
     void set_option(const std::string& key, int value) {
         if (key == "two_streams") opt_two_streams_ = value != 0;
+        else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -160,10 +162,12 @@ private:
 
     // building blocks on [B, C, T] buffers (all lens are device pointers)
     void run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const;
+    // xs: scratch for the split-precision input planes (x3_bytes(B, C, T)); null -> exact fp32 MFMA path
     void attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens, int B,
-                         int T, int Ta, hipStream_t s);
+                         int T, int Ta, hipStream_t s, void* xs = nullptr);
     void res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T, int Ta,
-                       int step, hipStream_t s);
+                       int step, hipStream_t s, void* xs = nullptr);
+    bool use_x3() const;
     // cbuf0: [B + Nu, C, T] = B conditional code embeddings followed by Nu unconditional inputs (one per distinct length)
     void diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, const int* lens_i, const int* umap, int B, int Nu,
                            int T, int step, float* out2, hipStream_t s);
@@ -199,6 +203,8 @@ private:
     const float *text_emb_ = nullptr, *mel_emb_ = nullptr, *text_pos_ = nullptr, *mel_pos_ = nullptr;
 
     bool opt_two_streams_ = true;
+    bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
+    Arena w3_;                            // split-precision weight copies
     hipStream_t s2_ = nullptr;            // second stream of the two-stream diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     const int* umap_local_ = nullptr;     // [B] uncond sample -> index of its length group

@@ -1,5 +1,6 @@
 // Model runtime: weight lookup, workspace, diffusion-stage orchestration (see model.h).
 #include "model.h"
+#include "conv_x3.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -147,6 +148,12 @@ void Model::run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const {
     p.Cout = pc.Cout;
     p.CoutP = pc.CoutP;
     p.KW = pc.KW;
+    if (p.x3) {
+        DTTS_REQUIRE(pc.w3, "conv has no split-precision weights");
+        p.w3 = pc.w3;
+        launch_conv_x3(p, s);
+        return;
+    }
     launch_conv_gemm(p, s);
 }
 
@@ -279,12 +286,40 @@ void Model::build_diffusion(hipStream_t s) {
     for (auto& l : integ_) emb_of(l.rb);
     for (auto& l : layers_) emb_of(l.rb);
     for (auto& r : tail_) emb_of(r);
+
+    // ---- split-precision (3 x bf16) copies of the trunk's conv weights (conv_x3.h)
+    std::vector<PackedConv*> hot = {&inp_block_, &integ1_, &integ2_, &out_conv_};
+    auto add_layer = [&](DiffLayerW& l) {
+        hot.push_back(&l.rb.c1);
+        hot.push_back(&l.rb.c2);
+        hot.push_back(&l.at.qkv);
+        hot.push_back(&l.at.proj);
+    };
+    for (auto& l : integ_) add_layer(l);
+    for (auto& l : layers_) add_layer(l);
+    for (auto& r : tail_) { hot.push_back(&r.c1); hot.push_back(&r.c2); }
+    size_t total = 0;
+    for (PackedConv* pc : hot) {
+        DTTS_REQUIRE(pc->Cin == pc->CinP && pc->CoutP % 128 == 0, "trunk conv not eligible for the split-precision path");
+        total += (size_t)pc->KW * pc->CinP * pc->CoutP * 6 + 256;
+    }
+    w3_.ensure(total + 4096);
+    for (PackedConv* pc : hot) {
+        void* dst = w3_.raw((size_t)pc->KW * pc->CinP * pc->CoutP * 6);
+        launch_split_weights(pc->w, pc->KW, pc->CinP, pc->CoutP, dst, s);
+        pc->w3 = dst;
+    }
+}
+
+bool Model::use_x3() const {
+    static const bool env_on = []() { const char* v = getenv("DTTS_CONV_X3"); return !(v && v[0] == '0'); }();
+    return env_on && opt_conv_x3_;
 }
 
 // ------------------------------------------------------------------------------ building blocks
 // AttentionBlock (vqvae/utils/diff_util.py:209-215): y = x + proj(attn(qkv(GN(x))))
 void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens,
-                            int B, int T, int Ta, hipStream_t s) {
+                            int B, int T, int Ta, hipStream_t s, void* xs) {
     const int C = w.C, D = C / w.H;
     const long long bs = (long long)C * Ta;
     int groups = 32;
@@ -303,6 +338,11 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     p.y = qkv;
     p.y_bs = 3 * bs;
     p.y_cs = Ta;
+    if (xs && w.qkv.w3) {
+        launch_split_planes(x, bs, Ta, ab, ACT_NONE, lens, T, B, C, xs, s);
+        p.x3 = xs;
+        p.x3_tp = x3_tp(T);
+    }
     run_conv(w.qkv, p, s);
     AttnParams a;
     a.qkv = qkv;
@@ -338,12 +378,17 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     q.res = x;
     q.res_bs = bs;
     q.res_cs = Ta;
+    if (xs && w.proj.w3) {
+        launch_split_planes(att, bs, Ta, nullptr, ACT_NONE, lens, T, B, C, xs, s);
+        q.x3 = xs;
+        q.x3_tp = x3_tp(T);
+    }
     run_conv(w.proj, q, s);
 }
 
 // diffusion ResBlock (vqvae/diff_model.py:106-119): y = x + conv3(SiLU(AdaGN(conv1(SiLU(GN(x))))))
 void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T,
-                          int Ta, int step, hipStream_t s) {
+                          int Ta, int step, hipStream_t s, void* xs) {
     const int C = cfg.diff_channels;
     const long long bs = (long long)C * Ta;
     int groups = 32;
@@ -363,6 +408,12 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
     p.y = h1;
     p.y_bs = bs;
     p.y_cs = Ta;
+    const bool x3 = xs && w.c1.w3 && w.c2.w3;
+    if (x3) {
+        launch_split_planes(x, bs, Ta, ab, ACT_SILU, lens, T, B, C, xs, s);
+        p.x3 = xs;
+        p.x3_tp = x3_tp(T);
+    }
     run_conv(w.c1, p, s);
     const float* ada = ss_table_ + (size_t)w.index * 2 * C * n_steps_ + step;
     launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s);
@@ -373,6 +424,7 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
     q.res = x;
     q.res_bs = bs;
     q.res_cs = Ta;
+    if (x3) launch_split_planes(h1, bs, Ta, ab, ACT_SILU, lens, T, B, C, xs, s);
     run_conv(w.c2, q, s);
 }
 
@@ -422,6 +474,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     }
     int groups = 32;
     while (C % groups) groups /= 2;
+    const bool x3 = use_x3();
 
     // shared x path: inp_block + the x-half of integrating_conv (+ bias) on the B samples (vqvae/diff_model.py:296-298)
     float* xin = ws_.f32((size_t)B * C * Ta);
@@ -431,9 +484,21 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         p.x_bs = (long long)cfg.mel_channels * T;
         p.x_cs = T;
         p.pad = 1;
-        run_conv(inp_block_, p, s);
         ConvParams q = cp(xin, C, xpath, C, B, T, Ta, lens2);
-        run_conv(integ1_, q, s);
+        if (x3) {
+            void* xs0 = ws_.raw(x3_bytes(B, C, T));
+            launch_split_planes(x, p.x_bs, T, nullptr, ACT_NONE, lens2, T, B, cfg.mel_channels, xs0, s);
+            p.x3 = xs0;
+            p.x3_tp = x3_tp(T);
+            run_conv(inp_block_, p, s);
+            launch_split_planes(xin, bs, Ta, nullptr, ACT_NONE, lens2, T, B, C, xs0, s);
+            q.x3 = xs0;
+            q.x3_tp = x3_tp(T);
+            run_conv(integ1_, q, s);
+        } else {
+            run_conv(inp_block_, p, s);
+            run_conv(integ1_, q, s);
+        }
     }
     struct Half {
         hipStream_t st;
@@ -461,9 +526,10 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* bufC = ws_.f32(act);
         float* qkv = ws_.f32(3 * act);
         float* ab = ws_.f32((size_t)B * C * 2);
+        void* xs = x3 ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
         auto dlayer_n = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp, const int* lens, int nb) {
-            res_block_fwd(l.rb, in, tmp, mid, ab, lens, nb, T, Ta, step, st);
-            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, st);
+            res_block_fwd(l.rb, in, tmp, mid, ab, lens, nb, T, Ta, step, st, xs);
+            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, st, xs);
         };
         // conditioning_timestep_integrator (vqvae/diff_model.py:295): B code embeddings | Nu unconditional inputs
         dlayer_n(integ_[0], hf.cin, bufB, bufC, bufA, hf.lens_integ, nbi);
@@ -475,6 +541,11 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         r.res_bs = bs;
         r.res_cs = Ta;
         r.x_bidx = hf.xmap;
+        if (x3) {
+            launch_split_planes(bufA, bs, Ta, nullptr, ACT_NONE, hf.lens_integ, T, nbi, C, xs, st);
+            r.x3 = xs;
+            r.x3_tp = x3_tp(T);
+        }
         run_conv(integ2_, r, st);
         // main stack (:299-309)
         float* cur = bufB;
@@ -482,7 +553,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* t2 = bufC;
         for (auto& l : layers_) dlayer_n(l, cur, t1, t2, cur, lens2, B);   // output back into `cur` (x is dead after the residual add)
         for (auto& rb : tail_) {
-            res_block_fwd(rb, cur, t1, t2, ab, lens2, B, T, Ta, step, st);
+            res_block_fwd(rb, cur, t1, t2, ab, lens2, B, T, Ta, step, st, xs);
             std::swap(cur, t2);
         }
         // out: GN, SiLU, conv k3 (:312)
@@ -493,6 +564,11 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         o.pad = 1;
         o.y_bs = (long long)OC * T;
         o.y_cs = T;
+        if (x3) {
+            launch_split_planes(cur, bs, Ta, ab, ACT_SILU, lens2, T, B, C, xs, st);
+            o.x3 = xs;
+            o.x3_tp = x3_tp(T);
+        }
         run_conv(out_conv_, o, st);
     }
     if (two_streams) {
@@ -503,7 +579,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
 
 static size_t pair_ws_bytes(int B, int C, int T) {
     const size_t act = (size_t)B * C * T;
-    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C)) + 16 * 256;
+    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C)) + 3 * x3_bytes(B, C, T) + 20 * 256;
 }
 
 // ------------------------------------------------------------------------------ stage entry points
@@ -682,14 +758,19 @@ void Model::op_attention_block(const char* prefix, const float* x, const int* le
     DTTS_REQUIRE(bound_, "weights not bound");
     AttnBlockW w = attn_block(prefix, C, cfg.diff_heads);
     const size_t act = (size_t)B * C * T;
-    ws_.ensure(sizeof(float) * (4 * act + (size_t)2 * B * C) + 8192);
+    ws_.ensure(sizeof(float) * (4 * act + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
     float* qkv = ws_.f32(3 * act);
     float* att = ws_.f32(act);
     float* ab = ws_.f32((size_t)2 * B * C);
-    attention_block(w, x, y, qkv, att, ab, dl, B, T, T, s);
+    // the trunk's blocks take the split-precision path exactly as inside diff_forward
+    for (auto* grp : {&integ_, &layers_})
+        for (auto& dl2 : *grp)
+            if (dl2.at.qkv.w == w.qkv.w) w = dl2.at;
+    void* xs = (use_x3() && w.qkv.w3) ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
+    attention_block(w, x, y, qkv, att, ab, dl, B, T, T, s, xs);
 }
 
 void Model::op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y,
@@ -707,13 +788,14 @@ void Model::op_resblock(const char* prefix, const float* x, const int* lens_host
     for (size_t i = 0; i < tail_.size(); ++i) check(tail_[i], "diffusion.layers." + std::to_string(layers_.size() + i));
     DTTS_REQUIRE(found, "unknown resblock prefix");
     const size_t act = (size_t)B * C * T;
-    ws_.ensure(sizeof(float) * (act + (size_t)2 * B * C) + 8192);
+    ws_.ensure(sizeof(float) * (act + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
     float* h1 = ws_.f32(act);
     float* ab = ws_.f32((size_t)2 * B * C);
-    res_block_fwd(*found, x, h1, y, ab, dl, B, T, T, step, s);
+    void* xs = use_x3() ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
+    res_block_fwd(*found, x, h1, y, ab, dl, B, T, T, step, s, xs);
 }
 
 // Generic conv entry for parity tests.  In phases mode (ConvTranspose1d) Cout is the real channel count per phase,

@@ -1,0 +1,177 @@
+// Microbenchmark: fp32-accurate implicit-GEMM conv on the bf16 MFMA pipe with PRE-SPLIT operands (a = a0 + a1 + a2, bf16 each).
+//   Y[b][m][n] = sum_tap sum_c W[tap][m][c] * X[b][c][n + tap - pad]
+// Both operands live in HBM as 16-byte chunks of 8 consecutive channels of one plane:
+//   Wp [tap][C/8][3][M ][8 bf16]      Xp [b][C/8][3][Tp][8 bf16]   (Tp = padded time axis with a zero halo)
+// so a K-step (16 channels) of a 128-row tile is 6 "kinds" (plane, k-half) x 128 rows x 16 B = 12 KiB, every kind a contiguous
+// 2 KiB run in HBM *and* in LDS: the whole tile is moved by global_load_lds (no VGPR staging), and a ds_read_b128 of
+// (kind, row = lane&31) is bank-conflict-free.  3-stage pipeline, one barrier per K-step, 24 MFMA 32x32x16 per wave per K-step.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+constexpr int BM = 128, BN = 128, TILE = 6 * 128 * 16;
+
+template <int NSTAGE, int NTERMS, int XCD>
+__global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M,
+                                               int C8, int taps, int Tp, int T, int xoff) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (XCD) {      // blocks that share an X tile (all M tiles of one (n, b)) run on the same XCD / L2
+        const int nwg = gridDim.x * gridDim.y * gridDim.z, lin = (bz * gridDim.y + by) * gridDim.x + bx;
+        const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        bx = v % gridDim.x; by = (v / gridDim.x) % gridDim.y; bz = v / (gridDim.x * gridDim.y);
+    }
+    const int m0 = bx * BM, n0 = by * BN, b = bz;
+    const int c16n = C8 / 2, nks = taps * c16n;
+    const int operand = wave >> 1;                     // waves 0,1 fetch the W tile, waves 2,3 the X tile
+    const uint4* gbase = operand ? Xp + (size_t)b * C8 * 3 * Tp + n0 + xoff : Wp + m0;
+    const long long rowlen = operand ? Tp : M;         // chunks per (c8, plane) run
+    const long long tapstride = operand ? 1 : (long long)C8 * 3 * M;
+
+    auto issue = [&](int ks, int stage) {
+        const int tap = ks / c16n, c16 = ks - tap * c16n;
+        unsigned char* lbase = smem + stage * 2 * TILE + operand * TILE;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int j = (wave & 1) * 6 + i, kind = j >> 1, p = kind >> 1, h = kind & 1, rh = j & 1;
+            const uint4* g = gbase + tap * tapstride + ((long long)(2 * c16 + h) * 3 + p) * rowlen + rh * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lbase + kind * 2048 + rh * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    f16v acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int s = 0; s < NSTAGE - 1; ++s) issue(min(s, nks - 1), s);
+    for (int ks = 0; ks < nks; ++ks) {
+        // stage ks has landed once at most the (NSTAGE-2) younger stages' 6 loads each are still in flight
+        if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(min(ks + NSTAGE - 1, nks - 1), (ks + NSTAGE - 1) % NSTAGE);
+        const unsigned char* As = smem + (ks % NSTAGE) * 2 * TILE + lhi * 2048;
+        const unsigned char* Bs = As + TILE;
+        bf8 a[2][3], bb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = *reinterpret_cast<const bf8*>(As + p * 4096 + (wm0 + i * 32 + l31) * 16);
+                bb[i][p] = *reinterpret_cast<const bf8*>(Bs + p * 4096 + (wn0 + i * 32 + l31) * 16);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (NTERMS >= 6) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], acc[i][j], 0, 0, 0);
+                }
+                if (NTERMS >= 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* yb = Y + (long long)b * M * T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, n = n0 + wn0 + j * 32 + l31;
+                if (n < T) yb[(long long)row * T + n] = acc[i][j][r];
+            }
+}
+
+static unsigned short h_bf16(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+static float h_f(unsigned short h) { unsigned u = ((unsigned)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+static void split3(float v, unsigned short* p) {
+    p[0] = h_bf16(v); const float r1 = v - h_f(p[0]);
+    p[1] = h_bf16(r1); const float r2 = r1 - h_f(p[1]);
+    p[2] = h_bf16(r2);
+}
+
+template <int NS, int NT, int XCD>
+void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int T, int Tp, int B, const std::vector<float>& hw,
+         const std::vector<float>& hx, const char* name) {
+    const int pad = taps / 2, halo = 1;
+    dim3 grid(M / BM, (T + BN - 1) / BN, B);
+    const size_t lds = (size_t)NS * 2 * TILE;
+    (void)hipFuncSetAttribute((const void*)gemm_x3<NS, NT, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_x3<NS, NT, XCD>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
+    (void)hipDeviceSynchronize();
+    std::vector<float> hy((size_t)M * T);
+    (void)hipMemcpy(hy.data(), Y + (size_t)(B - 1) * M * T, hy.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0, scale = 0;
+    const float* xb = hx.data() + (size_t)(B - 1) * C * T;
+    for (int m = 0; m < M; m += 37)
+        for (int n = 0; n < T; n += 53) {
+            double ref = 0;
+            for (int tap = 0; tap < taps; ++tap) {
+                const int t = n + tap - pad;
+                if (t < 0 || t >= T) continue;
+                for (int c = 0; c < C; ++c) ref += (double)hw[((size_t)tap * M + m) * C + c] * (double)xb[(size_t)c * T + t];
+            }
+            maxerr = fmax(maxerr, fabs(ref - hy[(size_t)m * T + n]));
+            scale = fmax(scale, fabs(ref));
+        }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_x3<NS, NT, XCD>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double fl = 2.0 * M * C * taps * (double)T * B * reps;
+    printf("%-30s taps %d B %2d  max err %.3e (rel %.2e)  %7.1f us/launch  %6.1f TFLOP/s fp32-equivalent\n", name, taps, B, maxerr,
+           maxerr / scale, ms / reps * 1e3, fl / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    const int M = 768, C = 768, T = 936, B = 16, Tp = 8 * 128 + 2;
+    for (int taps : {1, 3}) {
+        std::vector<float> hw((size_t)taps * M * C), hx((size_t)B * C * T);
+        srand(1);
+        for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.036f;
+        for (auto& v : hx) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 1.7f;
+        std::vector<unsigned short> wp((size_t)taps * (C / 8) * 3 * M * 8), xp((size_t)B * (C / 8) * 3 * Tp * 8, 0);
+        unsigned short pl[3];
+        for (int tap = 0; tap < taps; ++tap)
+            for (int m = 0; m < M; ++m)
+                for (int c = 0; c < C; ++c) {
+                    split3(hw[((size_t)tap * M + m) * C + c], pl);
+                    for (int p = 0; p < 3; ++p) wp[((((size_t)tap * (C / 8) + c / 8) * 3 + p) * M + m) * 8 + c % 8] = pl[p];
+                }
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < C; ++c)
+                for (int t = 0; t < T; ++t) {
+                    split3(hx[((size_t)b * C + c) * T + t], pl);
+                    for (int p = 0; p < 3; ++p) xp[((((size_t)b * (C / 8) + c / 8) * 3 + p) * Tp + t + 1) * 8 + c % 8] = pl[p];
+                }
+        uint4 *Wp, *Xp; float* Y;
+        (void)hipMalloc(&Wp, wp.size() * 2); (void)hipMalloc(&Xp, xp.size() * 2); (void)hipMalloc(&Y, (size_t)B * M * T * 4);
+        (void)hipMemcpy(Wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+        (void)hipMemcpy(Xp, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
+        run<3, 6, 0>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 3 stages");
+        run<2, 6, 0>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 2 stages");
+        run<2, 6, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 2 stages, xcd");
+        run<3, 6, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 3 stages, xcd");
+        run<2, 6, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 8, hw, hx, "x3 6 products, 2 stages, xcd");
+        run<2, 3, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x2 3 products, 2 stages, xcd");
+        run<2, 1, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x1 1 product,  2 stages, xcd");
+        (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
+    }
+    return 0;
+}
