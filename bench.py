@@ -23,6 +23,7 @@ N_CODES = 234            # forced utterance length: 234 codes -> 936 mel frames 
 T_REF = 936              # 10 s prompt
 L_TEXT = 60
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (no sparsity)
 
 
 def cpu_baseline(W, seed=1234):
@@ -156,25 +157,34 @@ def main():
     total_audio = audio_per_utt * B * world * args.steps
     value = total_audio / dt
     # dominant kernel = the conv-GEMM instantiation with the largest total time
-    convs = [p for p in prof if p["name"].startswith("conv_gemm")]
+    convs = [p for p in prof if p["name"].startswith("conv_")]
     dom = max(convs, key=lambda p: p["total_ms"]) if convs else None
     roof = None
     if dom:
         # The cond / uncond halves of every diffusion forward run on two HIP streams, so two launches of this kernel are usually
         # co-resident: the chip-level rate is flops / (union of the launch intervals); avg_launch_us is the raw per-launch mean.
         ach = dom["flops"] / (dom["union_ms"] * 1e-3) / 1e12
+        x3 = dom["name"].startswith("conv_x3")
+        # conv_x3 computes every fp32 product as 6 bf16 MFMA products (3 x bf16 split operands, detail_tts_amd/csrc/conv_x3.h):
+        # the matrix pipe executes 6x the fp32-equivalent flops the profiler counts, and its roofline is the dense bf16 peak.
+        peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
+        fp32_equiv = ach
+        if x3:
+            ach *= 6.0
         # HBM-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
         # same kernel at the bench's per-launch shapes; bench.py cannot attach rocprof to itself).  Launch mix of one diffusion
         # layer: in_layers 1x1, out_layers k3, qkv 1x1 (M=2304), proj 1x1.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_x3_traffic.json" if x3 else "r01_pmc_conv_traffic.json")))
             mix = ["768->768 k1", "768->768 k3", "768->2304 k1", "768->768 k1"]
             traffic = round(sum((tj[k]["fetch_MB"] + tj[k]["write_MB"]) for k in mix) / len(mix) * 1e6)
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic,
+                "arithmetic": "bf16 MFMA x 6 products per fp32 product (fp32-exact split), fp32 accumulate" if x3 else "fp32 MFMA",
+                "fp32_equivalent_tflops": round(fp32_equiv, 2),
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
                 "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                 "busy_share_of_timed_region": round(dom["union_ms"] * 1e-3 / dt, 3),

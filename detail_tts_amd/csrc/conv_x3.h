@@ -23,6 +23,11 @@ void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* ou
 // x [B][C][T] fp32 (strides) -> x3; v = act(a*x + d) with (a, d) = ab[b][c][0..1] (ab may be null); zero outside [0, len[b])
 void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* ab, int act, const int* lens, int T, int B, int C,
                          void* out, hipStream_t s);
+// GroupNorm (statistics + affine, optional AdaGN (1 + scale, shift) from `ada`) + activation + split in one pass; arguments as
+// launch_gn_coeffs (ops.h)
+void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
+                            const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs, int act,
+                            void* out, hipStream_t s);
 // uses p.w3 / p.x3 / p.x3_tp (+ the epilogue fields of ConvParams); stride 1, dilation 1, pad <= X3_HALO, no gate / phases / badd
 void launch_conv_x3(const ConvParams& p, hipStream_t s);
 

@@ -4,6 +4,7 @@
 // K-step.  LDS: 2 stages x (W tile 12 KiB + X tile 12 KiB) = 48 KiB -> 3 workgroups per CU.  Per K-step a wave issues 6 LDS-DMA
 // loads (1 KiB each; waves 0,1 fetch W, waves 2,3 fetch X), 12 ds_read_b128 and 24 MFMAs behind ONE barrier.
 #include "conv_x3.h"
+#include <cstdlib>
 #include "prof.h"
 
 namespace dtts {
@@ -14,27 +15,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 constexpr int BM = 128, BN = 128, TILE = 6 * 128 * 16, NSTAGE = 2;
 
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ float bf16_f(unsigned h) { return __uint_as_float(h << 16); }
-// v = p0 + p1 + p2 with every partial difference exact in fp32
-__device__ __forceinline__ void split3(float v, unsigned& p0, unsigned& p1, unsigned& p2) {
-    p0 = bf16_rne(v);
-    const float r1 = v - bf16_f(p0);
-    p1 = bf16_rne(r1);
-    const float r2 = r1 - bf16_f(p1);
-    p2 = bf16_rne(r2);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two elements at a time on the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even): 3 converts, 4 unpacks, 2 packed subs
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
+    const f32x2 v = {x, y};
+    const bf16x2 p0 = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(p0, f32x2);
+    const bf16x2 p1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(p1, f32x2);
+    const bf16x2 p2 = __builtin_convertvector(r2, bf16x2);
+    w0 = __builtin_bit_cast(unsigned, p0);
+    w1 = __builtin_bit_cast(unsigned, p1);
+    w2 = __builtin_bit_cast(unsigned, p2);
 }
 __device__ __forceinline__ void split8(const float* v, uint4& q0, uint4& q1, uint4& q2) {
-    unsigned a[8], b[8], c[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) split3(v[e], a[e], b[e], c[e]);
-    q0 = make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16));
-    q1 = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
-    q2 = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+    split_pair(v[0], v[1], q0.x, q1.x, q2.x);
+    split_pair(v[2], v[3], q0.y, q1.y, q2.y);
+    split_pair(v[4], v[5], q0.z, q1.z, q2.z);
+    split_pair(v[6], v[7], q0.w, q1.w, q2.w);
 }
 
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ wp, int C8, int CoutP, uint4* __restrict__ out) {
@@ -81,10 +80,112 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     o[2 * (long long)Tp] = q2;
 }
 
+// GroupNorm statistics + affine (+ AdaGN scale/shift) + activation + split in ONE kernel: a workgroup owns one (sample, group),
+// reduces its cpg x len slab (shifted single-pass sums, as gn_coeffs_kernel), then re-reads the slab (L2-resident, <= 100 KB)
+// and writes the group's cpg/8 chunk rows of the three planes.
+template <int ACT>
+__global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __restrict__ x, long long x_bs, int x_cs,
+                                                              const int* __restrict__ lens, int T, int C, int groups,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              const float* __restrict__ ada, int ada_stride, int ada_bs, int Tp,
+                                                              uint4* __restrict__ out) {
+    __shared__ float red[2][16];
+    __shared__ float sa[64], sd[64];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int len = lens ? lens[b] : T;
+    const int cpg = C / groups;
+    const float* xg = x + (long long)b * x_bs + (long long)(g * cpg) * x_cs;
+    const float k = xg[0];
+    float s1 = 0.f, s2 = 0.f;
+    const bool vec = ((x_cs & 3) == 0) && ((reinterpret_cast<unsigned long long>(xg) & 15ull) == 0);
+    if (vec) {
+        const int len4 = len >> 2, n4 = cpg * len4;
+        for (int i0 = tid; i0 < n4; i0 += 4 * nthr) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nthr, ic = i < n4 ? i : 0;
+                const int row = ic / len4, t4 = ic - row * len4;
+                v[u] = reinterpret_cast<const float4*>(xg + (long long)row * x_cs)[t4];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * nthr >= n4) continue;
+                const float d0 = v[u].x - k, d1 = v[u].y - k, d2 = v[u].z - k, d3 = v[u].w - k;
+                s1 += (d0 + d1) + (d2 + d3);
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        const int rem = len - (len4 << 2);
+        for (int i = tid; i < cpg * rem; i += nthr) {
+            const int row = i / rem, t = (len4 << 2) + (i - row * rem);
+            const float d = xg[(long long)row * x_cs + t] - k;
+            s1 += d;
+            s2 += d * d;
+        }
+    } else {
+        for (int i = tid; i < cpg * len; i += nthr) {
+            const int row = i / len, t = i - row * len;
+            const float d = xg[(long long)row * x_cs + t] - k;
+            s1 += d;
+            s2 += d * d;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    float S1 = 0.f, S2 = 0.f;
+    for (int i = 0; i < (nthr >> 6); ++i) { S1 += red[0][i]; S2 += red[1][i]; }
+    const float n = (float)(cpg * len);
+    S1 /= n;
+    S2 /= n;
+    const float mean = k + S1, var = fmaxf(S2 - S1 * S1, 0.f), rstd = rsqrtf(var + eps);
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        float a = rstd * gamma[c];
+        float d = beta[c] - mean * a;
+        if (ada) {
+            const float* ad = ada + (long long)b * ada_bs;
+            const float sc = 1.f + ad[(long long)c * ada_stride], sh = ad[(long long)(C + c) * ada_stride];
+            a *= sc;
+            d = d * sc + sh;
+        }
+        sa[tid] = a;
+        sd[tid] = d;
+    }
+    __syncthreads();
+    const int c8n = cpg >> 3, C8 = C >> 3;
+    // every workgroup of a (sample, group) computes the statistics (the slab is L2-resident); the split work is divided among them
+    for (int item = blockIdx.z * nthr + tid; item < c8n * Tp; item += nthr * gridDim.z) {
+        const int c8l = item / Tp, tp = item - c8l * Tp, t = tp - X3_HALO;
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        if (t >= 0 && t < len) {
+            const float* xr = xg + (long long)(c8l * 8) * x_cs + t;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xr[(long long)e * x_cs];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = sa[c8l * 8 + e] * v[e] + sd[c8l * 8 + e];
+                if (ACT == ACT_SILU) v[e] = v[e] * __frcp_rn(1.f + __expf(-v[e]));
+            }
+            split8(v, q0, q1, q2);
+        }
+        uint4* o = out + ((long long)(b * C8 + g * c8n + c8l) * 3) * Tp + tp;
+        o[0] = q0;
+        o[Tp] = q1;
+        o[2 * (long long)Tp] = q2;
+    }
+}
+
 template <int EPI>   // 0: bias (+ residual); 1: + activation / out_scale
 __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
     const int mtiles = p.CoutP / BM, ntiles = (p.Nout + BN - 1) / BN;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -97,19 +198,25 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     const int bin = p.x_bidx ? p.x_bidx[b] : b;
 
     const int operand = wave >> 1;                     // waves 0,1 fetch the W tile, waves 2,3 the X tile
-    const uint4* gbase = operand ? static_cast<const uint4*>(p.x3) + (long long)bin * C8 * 3 * Tp + n0 + (X3_HALO - p.pad)
-                                 : static_cast<const uint4*>(p.w3) + m0;
+    const uint4* gbase = (operand ? static_cast<const uint4*>(p.x3) + (long long)bin * C8 * 3 * Tp + n0 + (X3_HALO - p.pad)
+                                  : static_cast<const uint4*>(p.w3) + m0) + lane;
     const long long rowlen = operand ? Tp : p.CoutP;   // chunks per (c8, plane) run
     const long long tapstride = operand ? 1 : (long long)C8 * 3 * p.CoutP;
-    auto issue = [&](int ks, int stage) {
-        const int tap = ks / c16n, c16 = ks - tap * c16n;
-        unsigned char* lbase = smem + stage * 2 * TILE + operand * TILE;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int j = (wave & 1) * 6 + i, kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
-            const uint4* g = gbase + tap * tapstride + ((long long)(2 * c16 + h) * 3 + pl) * rowlen + rh * 64 + lane;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lbase + kind * 2048 + rh * 1024), 16, 0, 0);
+    // The 6 LDS-DMA loads a wave owes per K-step are issued ONE AT A TIME between groups of 4 MFMAs: issued as a burst, the
+    // 72 loads of a CU's 12 waves queue on the texture-address path while every MFMA pipe idles, and the co-resident
+    // workgroups fall into lock-step (load phase, then MFMA phase): measured 161 -> 190 TFLOP/s fp32-equivalent.
+    int ks_n = 0, tap_n = 0, c16_n = 0;                // the K-step being fetched
+    auto issue_one = [&](int i, int stage) {
+        const int j = (wave & 1) * 6 + i, kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
+        const uint4* g = gbase + tap_n * tapstride + ((long long)(2 * c16_n + h) * 3 + pl) * rowlen + rh * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(smem + stage * 2 * TILE + operand * TILE + kind * 2048 + rh * 1024),
+                                         16, 0, 0);
+    };
+    auto advance = [&]() {                             // the last step refetches itself into the idle stage: branch-free tail
+        if (ks_n + 1 < nks) {
+            ++ks_n;
+            if (++c16_n == c16n) { c16_n = 0; ++tap_n; }
         }
     };
 
@@ -122,35 +229,38 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_one(i, 0);
+    advance();
     for (int ks = 0; ks < nks; ++ks) {
-        // the loads of stage ks were issued one whole K-step ago; the barrier also orders the previous step's ds_reads of the
-        // stage that is refilled next (WAR)
+        // the barrier also orders the previous step's ds_reads of the stage that is refilled next (WAR)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(min(ks + 1, nks - 1), (ks + 1) & 1);     // the last step refetches itself into the idle stage: branch-free
+        const int nst = (ks + 1) & 1;
         const unsigned char* As = smem + (ks & 1) * 2 * TILE + lhi * 2048;
         const unsigned char* Bs = As + TILE;
         bf16x8 a[2][3], bb[2][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int i = 0; i < 2; ++i) {
                 a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * 4096 + (wm0 + i * 32 + l31) * 16);
                 bb[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * 4096 + (wn0 + i * 32 + l31) * 16);
             }
-        // smallest terms first
+        // term-major: one cross product over the wave's 4 accumulators per group, smallest terms first
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 6; ++t) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_one(t, nst);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        advance();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
 
@@ -200,6 +310,25 @@ void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* 
         if (act == ACT_SILU) hipLaunchKernelGGL((split_planes_kernel<ACT_SILU, false>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
         else hipLaunchKernelGGL((split_planes_kernel<ACT_NONE, false>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
     }
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
+                            const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs, int act,
+                            void* out, hipStream_t s) {
+    DTTS_REQUIRE(C % groups == 0 && (C / groups) % 8 == 0 && C / groups <= 64, "gn_split_planes: group size");
+    DTTS_REQUIRE(act == ACT_NONE || act == ACT_SILU, "gn_split_planes: activation");
+    const int Tp = x3_tp(T);
+    uint4* o = static_cast<uint4*>(out);
+    ProfScope ps("gn_split_planes_kernel", 0.0, (double)B * C * T * 14.0, s);
+    static const int ns = []() { const char* v = getenv("DTTS_GN_SPLIT_NS"); return v ? atoi(v) : 1; }();
+    static const int nt = []() { const char* v = getenv("DTTS_GN_SPLIT_NT"); return v ? atoi(v) : 1024; }();
+    if (act == ACT_SILU)
+        hipLaunchKernelGGL(gn_split_planes_kernel<ACT_SILU>, dim3(groups, B, ns), dim3(nt), 0, s, x, x_bs, x_cs, lens, T, C, groups, gamma,
+                           beta, eps, ada, ada_stride, ada_bs, Tp, o);
+    else
+        hipLaunchKernelGGL(gn_split_planes_kernel<ACT_NONE>, dim3(groups, B, ns), dim3(nt), 0, s, x, x_bs, x_cs, lens, T, C, groups, gamma,
+                           beta, eps, ada, ada_stride, ada_bs, Tp, o);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

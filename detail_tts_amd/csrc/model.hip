@@ -324,7 +324,9 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     const long long bs = (long long)C * Ta;
     int groups = 32;
     while (C % groups) groups /= 2;
-    launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ab, s);
+    const bool x3 = xs && w.qkv.w3 && w.proj.w3;
+    if (x3) launch_gn_split_planes(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ACT_NONE, xs, s);
+    else launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ab, s);
     ConvParams p;
     p.B = B;
     p.Tin = T;
@@ -338,8 +340,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     p.y = qkv;
     p.y_bs = 3 * bs;
     p.y_cs = Ta;
-    if (xs && w.qkv.w3) {
-        launch_split_planes(x, bs, Ta, ab, ACT_NONE, lens, T, B, C, xs, s);
+    if (x3) {
         p.x3 = xs;
         p.x3_tp = x3_tp(T);
     }
@@ -378,7 +379,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     q.res = x;
     q.res_bs = bs;
     q.res_cs = Ta;
-    if (xs && w.proj.w3) {
+    if (x3) {
         launch_split_planes(att, bs, Ta, nullptr, ACT_NONE, lens, T, B, C, xs, s);
         q.x3 = xs;
         q.x3_tp = x3_tp(T);
@@ -393,7 +394,9 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
     const long long bs = (long long)C * Ta;
     int groups = 32;
     while (C % groups) groups /= 2;
-    launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ab, s);
+    const bool x3 = xs && w.c1.w3 && w.c2.w3;
+    if (x3) launch_gn_split_planes(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, s);
+    else launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ab, s);
     ConvParams p;
     p.B = B;
     p.Tin = T;
@@ -408,15 +411,14 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
     p.y = h1;
     p.y_bs = bs;
     p.y_cs = Ta;
-    const bool x3 = xs && w.c1.w3 && w.c2.w3;
     if (x3) {
-        launch_split_planes(x, bs, Ta, ab, ACT_SILU, lens, T, B, C, xs, s);
         p.x3 = xs;
         p.x3_tp = x3_tp(T);
     }
     run_conv(w.c1, p, s);
     const float* ada = ss_table_ + (size_t)w.index * 2 * C * n_steps_ + step;
-    launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s);
+    if (x3) launch_gn_split_planes(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ACT_SILU, xs, s);
+    else launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s);
     ConvParams q = p;
     q.x = h1;
     q.pad = 1;
@@ -424,7 +426,6 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
     q.res = x;
     q.res_bs = bs;
     q.res_cs = Ta;
-    if (x3) launch_split_planes(h1, bs, Ta, ab, ACT_SILU, lens, T, B, C, xs, s);
     run_conv(w.c2, q, s);
 }
 
@@ -557,7 +558,8 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
             std::swap(cur, t2);
         }
         // out: GN, SiLU, conv k3 (:312)
-        launch_gn_coeffs(cur, bs, Ta, lens2, T, B, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
+        if (x3) launch_gn_split_planes(cur, bs, Ta, lens2, T, B, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
+        else launch_gn_coeffs(cur, bs, Ta, lens2, T, B, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
         ConvParams o = cp(cur, C, hf.out, OC, B, T, Ta, lens2);
         o.pro_ab = ab;
         o.pro_act = ACT_SILU;
@@ -565,7 +567,6 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         o.y_bs = (long long)OC * T;
         o.y_cs = T;
         if (x3) {
-            launch_split_planes(cur, bs, Ta, ab, ACT_SILU, lens2, T, B, C, xs, st);
             o.x3 = xs;
             o.x3_tp = x3_tp(T);
         }

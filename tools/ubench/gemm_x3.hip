@@ -15,13 +15,16 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 constexpr int BM = 128, BN = 128, TILE = 6 * 128 * 16;
 
-template <int NSTAGE, int NTERMS, int XCD>
+// SCHED: 0 = all 6 LDS-DMA loads of the next stage right after the barrier (burst); 1 = one load after every group of 4 MFMAs
+// (term-major MFMA order: each group is one cross product over the wave's 4 accumulators), order pinned with sched_barrier
+template <int TM, int SCHED>
 __global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M,
                                                int C8, int taps, int Tp, int T, int xoff) {
+    static_assert(TM == 2, "128x128 only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (XCD) {      // blocks that share an X tile (all M tiles of one (n, b)) run on the same XCD / L2
+    {
         const int nwg = gridDim.x * gridDim.y * gridDim.z, lin = (bz * gridDim.y + by) * gridDim.x + bx;
         const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
         const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
@@ -30,58 +33,71 @@ __global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, con
     const int m0 = bx * BM, n0 = by * BN, b = bz;
     const int c16n = C8 / 2, nks = taps * c16n;
     const int operand = wave >> 1;                     // waves 0,1 fetch the W tile, waves 2,3 the X tile
-    const uint4* gbase = operand ? Xp + (size_t)b * C8 * 3 * Tp + n0 + xoff : Wp + m0;
-    const long long rowlen = operand ? Tp : M;         // chunks per (c8, plane) run
+    const uint4* gbase = (operand ? Xp + (size_t)b * C8 * 3 * Tp + n0 + xoff : Wp + m0) + lane;
+    const long long rowlen = operand ? Tp : M;
     const long long tapstride = operand ? 1 : (long long)C8 * 3 * M;
-
-    auto issue = [&](int ks, int stage) {
-        const int tap = ks / c16n, c16 = ks - tap * c16n;
-        unsigned char* lbase = smem + stage * 2 * TILE + operand * TILE;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int j = (wave & 1) * 6 + i, kind = j >> 1, p = kind >> 1, h = kind & 1, rh = j & 1;
-            const uint4* g = gbase + tap * tapstride + ((long long)(2 * c16 + h) * 3 + p) * rowlen + rh * 64 + lane;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lbase + kind * 2048 + rh * 1024), 16, 0, 0);
-        }
+    int ks_n = 0, tap_n = 0, c16_n = 0;                 // next stage to fetch
+    auto issue_one = [&](int i, int stage) {
+        const int j = (wave & 1) * 6 + i, kind = j >> 1, p = kind >> 1, h = kind & 1, rh = j & 1;
+        const uint4* g = gbase + tap_n * tapstride + ((long long)(2 * c16_n + h) * 3 + p) * rowlen + rh * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(smem + stage * 2 * TILE + operand * TILE + kind * 2048 + rh * 1024), 16, 0, 0);
     };
-
+    auto advance = [&]() {
+        if (ks_n + 1 < nks) { ++ks_n; if (++c16_n == c16n) { c16_n = 0; ++tap_n; } }
+    };
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     f16v acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int s = 0; s < NSTAGE - 1; ++s) issue(min(s, nks - 1), s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_one(i, 0);
+    advance();
+    constexpr int NST = SCHED == 3 ? 3 : 2;
+    if (NST == 3) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_one(i, 1);
+        advance();
+    }
     for (int ks = 0; ks < nks; ++ks) {
-        // stage ks has landed once at most the (NSTAGE-2) younger stages' 6 loads each are still in flight
-        if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (NST == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(min(ks + NSTAGE - 1, nks - 1), (ks + NSTAGE - 1) % NSTAGE);
-        const unsigned char* As = smem + (ks % NSTAGE) * 2 * TILE + lhi * 2048;
+        const int nst = (ks + NST - 1) % NST;
+        if (SCHED == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) issue_one(i, nst);
+        }
+        const unsigned char* As = smem + (ks % NST) * 2 * TILE + lhi * 2048;
         const unsigned char* Bs = As + TILE;
         bf8 a[2][3], bb[2][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int i = 0; i < 2; ++i) {
                 a[i][p] = *reinterpret_cast<const bf8*>(As + p * 4096 + (wm0 + i * 32 + l31) * 16);
                 bb[i][p] = *reinterpret_cast<const bf8*>(Bs + p * 4096 + (wn0 + i * 32 + l31) * 16);
             }
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 6; ++t) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (NTERMS >= 6) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], acc[i][j], 0, 0, 0);
-                }
-                if (NTERMS >= 3) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
-                }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
+            if (SCHED == 1 || SCHED == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_one(t, nst);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (SCHED == 2 && t < 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_one(2 * t, nst);
+                issue_one(2 * t + 1, nst);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        advance();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* yb = Y + (long long)b * M * T;
@@ -104,14 +120,14 @@ static void split3(float v, unsigned short* p) {
     p[2] = h_bf16(r2);
 }
 
-template <int NS, int NT, int XCD>
+template <int TM, int SCHED>
 void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int T, int Tp, int B, const std::vector<float>& hw,
          const std::vector<float>& hx, const char* name) {
     const int pad = taps / 2, halo = 1;
-    dim3 grid(M / BM, (T + BN - 1) / BN, B);
-    const size_t lds = (size_t)NS * 2 * TILE;
-    (void)hipFuncSetAttribute((const void*)gemm_x3<NS, NT, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gemm_x3<NS, NT, XCD>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
+    dim3 grid(M / (64 * TM), (T + BN - 1) / BN, B);
+    const size_t lds = (size_t)(SCHED == 3 ? 3 : 2) * (6 * 64 * TM * 16 + 6 * 128 * 16);
+    (void)hipFuncSetAttribute((const void*)gemm_x3<TM, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_x3<TM, SCHED>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
     (void)hipDeviceSynchronize();
     std::vector<float> hy((size_t)M * T);
     (void)hipMemcpy(hy.data(), Y + (size_t)(B - 1) * M * T, hy.size() * 4, hipMemcpyDeviceToHost);
@@ -131,7 +147,7 @@ void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_x3<NS, NT, XCD>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_x3<TM, SCHED>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double fl = 2.0 * M * C * taps * (double)T * B * reps;
@@ -164,13 +180,12 @@ int main() {
         (void)hipMalloc(&Wp, wp.size() * 2); (void)hipMalloc(&Xp, xp.size() * 2); (void)hipMalloc(&Y, (size_t)B * M * T * 4);
         (void)hipMemcpy(Wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(Xp, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
-        run<3, 6, 0>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 3 stages");
-        run<2, 6, 0>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 2 stages");
-        run<2, 6, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 2 stages, xcd");
-        run<3, 6, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x3 6 products, 3 stages, xcd");
-        run<2, 6, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 8, hw, hx, "x3 6 products, 2 stages, xcd");
-        run<2, 3, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x2 3 products, 2 stages, xcd");
-        run<2, 1, 1>(Wp, Xp, Y, M, C, taps, T, Tp, B, hw, hx, "x1 1 product,  2 stages, xcd");
+        for (int bb : {16, 8}) {
+            run<2, 0>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 burst");
+            run<2, 1>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 1 DMA per 4 MFMA");
+            run<2, 2>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 2 DMA after groups 0-2");
+            run<2, 3>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 1 per 4, 3 stages vmcnt(6)");
+        }
         (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
     }
     return 0;
