@@ -15,12 +15,12 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 constexpr int BM = 128, BN = 128, TILE = 6 * 128 * 16;
 
-// SCHED: 0 = all 6 LDS-DMA loads of the next stage right after the barrier (burst); 1 = one load after every group of 4 MFMAs
-// (term-major MFMA order: each group is one cross product over the wave's 4 accumulators), order pinned with sched_barrier
-template <int TM, int SCHED>
-__global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M,
-                                               int C8, int taps, int Tp, int T, int xoff) {
-    static_assert(TM == 2, "128x128 only");
+// WM: waves along M (2 -> 128x128 block, 4 waves; 4 -> 256x128 block, 8 waves).  One LDS-DMA load after every group of 4 MFMAs.
+// RD: 0 = all fragment reads up front; 1 = the first term's operands first, the rest behind the first MFMA group
+template <int WM, int RD>
+__global__ __launch_bounds__(WM * 128) void gemm_x3(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M,
+                                                    int C8, int taps, int Tp, int T, int xoff) {
+    constexpr int BMk = 64 * WM, ATILE = 6 * BMk * 16, BTILE = 6 * 128 * 16, STAGE = ATILE + BTILE, ARH = BMk / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -30,18 +30,24 @@ __global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, con
         const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
         bx = v % gridDim.x; by = (v / gridDim.x) % gridDim.y; bz = v / (gridDim.x * gridDim.y);
     }
-    const int m0 = bx * BM, n0 = by * BN, b = bz;
+    const int m0 = bx * BMk, n0 = by * BN, b = bz;
     const int c16n = C8 / 2, nks = taps * c16n;
-    const int operand = wave >> 1;                     // waves 0,1 fetch the W tile, waves 2,3 the X tile
+    // DMA ownership: WM=2: waves 0,1 -> A (6 each), 2,3 -> B (6 each);  WM=4: waves 0..5 -> A (4 each), 6,7 -> B (6 each)
+    const int nA = WM == 2 ? 2 : 6;
+    const int operand = wave >= nA;
+    const int cnt = operand ? 6 : (WM == 2 ? 6 : 4);
+    const int jbase = operand ? (wave - nA) * 6 : wave * cnt;
     const uint4* gbase = (operand ? Xp + (size_t)b * C8 * 3 * Tp + n0 + xoff : Wp + m0) + lane;
     const long long rowlen = operand ? Tp : M;
     const long long tapstride = operand ? 1 : (long long)C8 * 3 * M;
-    int ks_n = 0, tap_n = 0, c16_n = 0;                 // next stage to fetch
+    int ks_n = 0, tap_n = 0, c16_n = 0;
     auto issue_one = [&](int i, int stage) {
-        const int j = (wave & 1) * 6 + i, kind = j >> 1, p = kind >> 1, h = kind & 1, rh = j & 1;
+        if (i >= cnt) return;
+        const int j = jbase + i;
+        const int kind = operand ? j >> 1 : j / ARH, rh = operand ? j & 1 : j % ARH, p = kind >> 1, h = kind & 1;
         const uint4* g = gbase + tap_n * tapstride + ((long long)(2 * c16_n + h) * 3 + p) * rowlen + rh * 64;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(smem + stage * 2 * TILE + operand * TILE + kind * 2048 + rh * 1024), 16, 0, 0);
+        unsigned char* l = smem + stage * STAGE + (operand ? ATILE + kind * 2048 : kind * (BMk * 16)) + rh * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     };
     auto advance = [&]() {
         if (ks_n + 1 < nks) { ++ks_n; if (++c16_n == c16n) { c16_n = 0; ++tap_n; } }
@@ -52,31 +58,25 @@ __global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, con
 #pragma unroll
     for (int i = 0; i < 6; ++i) issue_one(i, 0);
     advance();
-    constexpr int NST = SCHED == 3 ? 3 : 2;
-    if (NST == 3) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) issue_one(i, 1);
-        advance();
-    }
     for (int ks = 0; ks < nks; ++ks) {
-        if (NST == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int nst = (ks + NST - 1) % NST;
-        if (SCHED == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) issue_one(i, nst);
-        }
-        const unsigned char* As = smem + (ks % NST) * 2 * TILE + lhi * 2048;
-        const unsigned char* Bs = As + TILE;
+        const int nst = (ks + 1) & 1;
+        const unsigned char* As = smem + (ks & 1) * STAGE + lhi * (BMk * 16);
+        const unsigned char* Bs = smem + (ks & 1) * STAGE + ATILE + lhi * 2048;
         bf8 a[2][3], bb[2][3];
+        auto lda = [&](int i, int p) { a[i][p] = *reinterpret_cast<const bf8*>(As + p * (2 * BMk * 16) + (wm0 + i * 32 + l31) * 16); };
+        auto ldb = [&](int j, int p) { bb[j][p] = *reinterpret_cast<const bf8*>(Bs + p * 4096 + (wn0 + j * 32 + l31) * 16); };
+        if (RD == 0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i][p] = *reinterpret_cast<const bf8*>(As + p * 4096 + (wm0 + i * 32 + l31) * 16);
-                bb[i][p] = *reinterpret_cast<const bf8*>(Bs + p * 4096 + (wn0 + i * 32 + l31) * 16);
-            }
+            for (int p = 0; p < 3; ++p) { lda(0, p); lda(1, p); ldb(0, p); ldb(1, p); }
+        } else {
+            lda(0, 2); lda(1, 2); ldb(0, 0); ldb(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lda(0, 1); lda(1, 1); ldb(0, 1); ldb(1, 1);
+            lda(0, 0); lda(1, 0); ldb(0, 2); ldb(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -85,17 +85,9 @@ __global__ __launch_bounds__(256) void gemm_x3(const uint4* __restrict__ Wp, con
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
-            if (SCHED == 1 || SCHED == 3) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_one(t, nst);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (SCHED == 2 && t < 3) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_one(2 * t, nst);
-                issue_one(2 * t + 1, nst);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_one(t, nst);
+            __builtin_amdgcn_sched_barrier(0);
         }
         advance();
     }
@@ -120,14 +112,14 @@ static void split3(float v, unsigned short* p) {
     p[2] = h_bf16(r2);
 }
 
-template <int TM, int SCHED>
-void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int T, int Tp, int B, const std::vector<float>& hw,
+template <int WM, int RD>
+void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int T, int Tp, int B, int nstream, const std::vector<float>& hw,
          const std::vector<float>& hx, const char* name) {
     const int pad = taps / 2, halo = 1;
-    dim3 grid(M / (64 * TM), (T + BN - 1) / BN, B);
-    const size_t lds = (size_t)(SCHED == 3 ? 3 : 2) * (6 * 64 * TM * 16 + 6 * 128 * 16);
-    (void)hipFuncSetAttribute((const void*)gemm_x3<TM, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gemm_x3<TM, SCHED>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
+    dim3 grid(M / (64 * WM), (T + BN - 1) / BN, B);
+    const size_t lds = (size_t)2 * (6 * 64 * WM * 16 + 6 * 128 * 16);
+    (void)hipFuncSetAttribute((const void*)gemm_x3<WM, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_x3<WM, RD>), grid, dim3(WM * 128), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
     (void)hipDeviceSynchronize();
     std::vector<float> hy((size_t)M * T);
     (void)hipMemcpy(hy.data(), Y + (size_t)(B - 1) * M * T, hy.size() * 4, hipMemcpyDeviceToHost);
@@ -144,15 +136,21 @@ void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int
             maxerr = fmax(maxerr, fabs(ref - hy[(size_t)m * T + n]));
             scale = fmax(scale, fabs(ref));
         }
+    hipStream_t st[2]; (void)hipStreamCreate(&st[0]); (void)hipStreamCreate(&st[1]);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_x3<TM, SCHED>), grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
-    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    for (int i = 0; i < reps; ++i)
+        for (int k = 0; k < nstream; ++k)
+            hipLaunchKernelGGL((gemm_x3<WM, RD>), grid, dim3(WM * 128), lds, nstream > 1 ? st[k] : 0, Wp, Xp + (size_t)k * B * (C / 8) * 3 * Tp,
+                               Y + (size_t)k * B * M * T, M, C / 8, taps, Tp, T, halo - pad);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-    const double fl = 2.0 * M * C * taps * (double)T * B * reps;
-    printf("%-30s taps %d B %2d  max err %.3e (rel %.2e)  %7.1f us/launch  %6.1f TFLOP/s fp32-equivalent\n", name, taps, B, maxerr,
-           maxerr / scale, ms / reps * 1e3, fl / (ms * 1e-3) / 1e12);
+    const double fl = 2.0 * M * C * taps * (double)T * B * reps * nstream;
+    printf("%-28s taps %d B %2d x%d stream  max err %.3e (rel %.2e)  %7.1f us/launch-set  %6.1f TFLOP/s fp32-equivalent\n", name, taps, B, nstream,
+           maxerr, maxerr / scale, ms / reps * 1e3, fl / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -180,12 +178,16 @@ int main() {
         (void)hipMalloc(&Wp, wp.size() * 2); (void)hipMalloc(&Xp, xp.size() * 2); (void)hipMalloc(&Y, (size_t)B * M * T * 4);
         (void)hipMemcpy(Wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(Xp, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
-        for (int bb : {16, 8}) {
-            run<2, 0>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 burst");
-            run<2, 1>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 1 DMA per 4 MFMA");
-            run<2, 2>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 2 DMA after groups 0-2");
-            run<2, 3>(Wp, Xp, Y, M, C, taps, T, Tp, bb, hw, hx, "128x128 1 per 4, 3 stages vmcnt(6)");
-        }
+        run<2, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "128x128");
+        run<2, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "128x128 staggered reads");
+        run<4, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "256x128 8 waves");
+        run<4, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "256x128 8 waves staggered");
+        run<2, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "128x128");
+        run<4, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "256x128 8 waves");
+        run<2, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "128x128");
+        run<2, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "128x128 staggered reads");
+        run<4, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "256x128 8 waves");
+        run<4, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "256x128 8 waves staggered");
         (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
     }
     return 0;
