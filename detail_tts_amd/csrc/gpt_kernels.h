@@ -31,6 +31,19 @@ void launch_gemv_finish_res_ln(const float* part, int slices, int B, int C, int 
 void launch_gemv_finish_qkv(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf, float* cache,
                             long long cache_bs, int cache_cs, const int* pos, hipStream_t s);
 
+// Decode GEMV, workgroup form (8 waves x 16 rows x 256 columns, one partial per 128 input rows): K % 128 == 0, B <= 8.
+// part[slice][b][col] with slice = K/128 (gemv_block_slices); consumed by launch_gemv_finish or by a *_parts / attention prologue.
+int gemv_block_slices(int K);
+void launch_gemv_block(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, hipStream_t s);
+void launch_gemv_block_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, const float* stats,
+                          int nblk, const float* gamma, const float* beta, hipStream_t s);
+// input = act(sum_slices parts_in[sl][b][k] + in_bias[k]): the previous GEMV's finish folded into this one's prologue
+void launch_gemv_block_parts(const float* W, int K, int CoutP, const float* parts_in, int in_slices, int in_stride, const float* in_bias,
+                             int in_act, int B, float* part, hipStream_t s);
+// single-query attention with c_attn's finish folded in (sums the qkv partials of its head, appends k/v to the cache)
+void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* bias, float* cache, long long cache_bs,
+                                 int cache_cs, const int* pos, const int* klen, int B, int H, int D, float* out, hipStream_t s);
+
 // single-query attention against the KV cache: cache[b] = [2C][cap] (k rows then v rows), len[b] keys (incl. the new one)
 void launch_decode_attention(const float* qbuf, const float* cache, long long cache_bs, int cache_cs, const int* klen, int B, int H,
                              int D, float* out, hipStream_t s);

@@ -190,6 +190,150 @@ void launch_gemv_partial_ln(const float* W, int K, int CoutP, const float* x, in
     gemv_partial_dispatch<1>(W, K, CoutP, x, x_stride, B, part, slices, stats, nblk, gamma, beta, s);
 }
 
+// ------------------------------------------------------------------------------------------ block GEMV (decode)
+// One 512-thread workgroup = 8 waves x 16 weight rows x 256 columns: every lane issues its 16 float4 weight loads up front
+// (16 KiB per wave, >= 768 waves per GEMV -> > 8 MiB in flight, what HBM needs), the 8 waves' partial sums are combined through
+// LDS, and a workgroup leaves ONE partial per 128 input rows (K/128 slices instead of K/64 one-wave slices: 8x less partial
+// traffic, no 1-wave workgroups).  The input prologue folds what used to be separate kernels:
+//   GP_PLAIN  x[b][k] as is
+//   GP_LN     LayerNorm on the fly from the producer's per-block (sum, sum sq) statistics
+//   GP_PARTS  x[b][k] = act(sum_slices parts[sl][b][k] + bias[k])      (the previous GEMV's finish: c_fc -> gelu -> c_proj)
+enum { GP_PLAIN = 0, GP_LN = 1, GP_PARTS = 2 };
+struct GemvIn {
+    const float* x = nullptr;
+    int x_stride = 0;
+    const float* stats = nullptr;
+    int nblk = 0;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const float* parts = nullptr;
+    int in_slices = 0, in_stride = 0, in_act = 0;
+    const float* in_bias = nullptr;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict__ W, int K, int CoutP, GemvIn in, int B,
+                                                         float* __restrict__ part) {
+    constexpr int NB = 8, RPW = 16, RB = 128;
+    __shared__ __attribute__((aligned(16))) float xs[NB][RB];
+    __shared__ float4 red[8][4][64];
+    __shared__ float smr[NB][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = blockIdx.x * 256 + lane * 4;
+    const int k0 = blockIdx.y * RB;
+    const bool cok = col < CoutP;
+    // weights first: 16 independent 16-byte loads per lane stay in flight across the prologue
+    float4 w[RPW];
+    {
+        const float* wp = W + (long long)(k0 + wave * RPW) * CoutP + (cok ? col : 0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) w[r] = *reinterpret_cast<const float4*>(wp + (long long)r * CoutP);
+    }
+    if (PRO == GP_LN) {
+        // wave b rebuilds (mean, rstd) of row b from the producer's per-block partial sums (fixed order -> deterministic)
+        const int bb = wave < B ? wave : B - 1;
+        float S = 0.f, Q = 0.f;
+        if (lane < in.nblk) { S = in.stats[((long long)bb * in.nblk + lane) * 2]; Q = in.stats[((long long)bb * in.nblk + lane) * 2 + 1]; }
+        S = wsum(S);
+        Q = wsum(Q);
+        const float m = S / (float)K;
+        if (lane == 0) { smr[wave][0] = m; smr[wave][1] = rsqrtf(fmaxf(Q / (float)K - m * m, 0.f) + 1e-5f); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e0 = 0; e0 < NB * RB; e0 += 512) {
+        const int e = e0 + tid, b = e >> 7, i = e & 127, bb = b < B ? b : B - 1, k = k0 + i;
+        float v;
+        if (PRO == GP_PARTS) {
+            v = in.in_bias ? in.in_bias[k] : 0.f;
+            for (int sl = 0; sl < in.in_slices; ++sl) v += in.parts[((long long)sl * B + bb) * in.in_stride + k];
+            v = act_apply(v, in.in_act, 0.f);
+        } else {
+            v = in.x[(long long)bb * in.x_stride + k];
+            if (PRO == GP_LN) v = (v - smr[b][0]) * smr[b][1] * in.gamma[k] + in.beta[k];
+        }
+        xs[b][i] = v;
+    }
+    __syncthreads();
+    float4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < RPW / 4; ++q)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[b][wave * RPW + 4 * q]);      // LDS broadcast
+            const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 ww = w[4 * q + u];
+                acc[b].x += ww.x * xe[u]; acc[b].y += ww.y * xe[u]; acc[b].z += ww.z * xe[u]; acc[b].w += ww.w * xe[u];
+            }
+        }
+    // combine the 8 waves (rows) through LDS, 4 batch rows per round; wave order fixed -> deterministic
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) red[wave][b][lane] = acc[h * 4 + b];
+        __syncthreads();
+        if (tid < 256) {
+            const int b = tid >> 6, l = tid & 63;
+            float4 t = red[0][b][l];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) {
+                const float4 u = red[wv][b][l];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            const int bo = h * 4 + b, c = blockIdx.x * 256 + l * 4;
+            if (bo < B && c < CoutP) *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * B + bo) * CoutP + c) = t;
+        }
+    }
+}
+
+static void gemv_block_launch(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
+    DTTS_REQUIRE(B >= 1 && B <= 8 && K % 128 == 0 && CoutP % 4 == 0, "gemv_block shape");
+    DTTS_REQUIRE((long long)(K / 128) * CoutP * B <= 8LL * 262144, "gemv partial scratch");
+    const dim3 grid(cdiv(CoutP, 256), K / 128);
+    if (pro == GP_PLAIN) hipLaunchKernelGGL(gemv_block_kernel<GP_PLAIN>, grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else if (pro == GP_LN) hipLaunchKernelGGL(gemv_block_kernel<GP_LN>, grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else hipLaunchKernelGGL(gemv_block_kernel<GP_PARTS>, grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+int gemv_block_slices(int K) { return K / 128; }
+
+void launch_gemv_block(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, hipStream_t s) {
+    GemvIn in;
+    in.x = x;
+    in.x_stride = x_stride;
+    gemv_block_launch(GP_PLAIN, W, K, CoutP, in, B, part, s);
+}
+
+void launch_gemv_block_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, const float* stats,
+                          int nblk, const float* gamma, const float* beta, hipStream_t s) {
+    DTTS_REQUIRE(nblk <= 64, "LN statistics blocks");
+    GemvIn in;
+    in.x = x;
+    in.x_stride = x_stride;
+    in.stats = stats;
+    in.nblk = nblk;
+    in.gamma = gamma;
+    in.beta = beta;
+    gemv_block_launch(GP_LN, W, K, CoutP, in, B, part, s);
+}
+
+void launch_gemv_block_parts(const float* W, int K, int CoutP, const float* parts_in, int in_slices, int in_stride, const float* in_bias,
+                             int in_act, int B, float* part, hipStream_t s) {
+    GemvIn in;
+    in.parts = parts_in;
+    in.in_slices = in_slices;
+    in.in_stride = in_stride;
+    in.in_bias = in_bias;
+    in.in_act = in_act;
+    gemv_block_launch(GP_PARTS, W, K, CoutP, in, B, part, s);
+}
+
 // y[b] = sum_slices part + bias + res[b];  hn[b] = LayerNorm(y[b])  — one 256-thread block per row (C <= 1024)
 __global__ __launch_bounds__(256) void gemv_finish_res_ln_kernel(const float* part, int slices, int B, int C, int CoutP,
                                                                  const float* bias, const float* res, float* y, const float* g1,
@@ -351,6 +495,93 @@ void launch_decode_attention(const float* qbuf, const float* cache, long long ca
     DTTS_REQUIRE(D == 48, "decode attention head dim");
     hipLaunchKernelGGL(decode_attention_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, qbuf, cache, cache_bs, cache_cs,
                        klen, H, out);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+// Same attention with c_attn's finish folded in: the workgroup of (head, sample) sums the qkv GEMV partials of its own 3*D
+// columns (+ bias), appends k and v to the cache for the later steps and uses them from LDS for this one.
+template <int D>
+__global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* __restrict__ part, int slices, int B, int CoutP,
+                                                                   const float* __restrict__ bias, float* cache, long long cache_bs,
+                                                                   int cap, const int* pos, const int* klen, int H, float* out) {
+    extern __shared__ float sc[];            // [cap] scores / probabilities
+    __shared__ float red[4];
+    __shared__ float part_o[4][D];
+    __shared__ float qkv_s[3][D];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = H * D;
+    const int n = klen[b];                   // keys including the new one (at column pos[b] == n - 1)
+    float* cb = cache + (long long)b * cache_bs;
+    if (tid < 3 * D) {
+        const int which = tid / D, c = tid - which * D, col = which * C + h * D + c;
+        float v = bias[col];
+        for (int sl = 0; sl < slices; ++sl) v += part[((long long)sl * B + b) * CoutP + col];
+        qkv_s[which][c] = v;
+        if (which == 1) cb[(long long)(h * D + c) * cap + pos[b]] = v;
+        else if (which == 2) cb[(long long)C * cap + (long long)pos[b] * C + h * D + c] = v;
+    }
+    __syncthreads();
+    const float* kp = cb + (long long)(h * D) * cap;       // K [C][cap]
+    const float* vp = cb + (long long)C * cap + h * D;      // V [cap][C]
+    float q[D];
+    const float scale = rsqrtf((float)D);
+#pragma unroll
+    for (int c = 0; c < D; ++c) q[c] = qkv_s[0][c] * scale;
+    float mx = -INFINITY;
+    const int nc = n - 1;                     // cached keys; the new key / value come from LDS
+    for (int s = tid; s < n; s += 256) {
+        float kv[D];
+        if (s < nc) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) kv[c] = kp[(long long)c * cap + s];
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) kv[c] = qkv_s[1][c];
+        }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { a0 += q[c] * kv[c]; a1 += q[c + 1] * kv[c + 1]; a2 += q[c + 2] * kv[c + 2]; a3 += q[c + 3] * kv[c + 3]; }
+        const float a = (a0 + a1) + (a2 + a3);
+        sc[s] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wmax(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float l = 0.f;
+    for (int s = tid; s < n; s += 256) {
+        const float pr = expf(sc[s] - mx);
+        sc[s] = pr;
+        l += pr;
+    }
+    l = wsum(l);
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    l = red[0] + red[1] + red[2] + red[3];
+    float o = 0.f;
+    if (lane < D) {
+        float o4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = wave;
+        for (; s + 28 < nc; s += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o4[u] += sc[s + 4 * u] * vp[(long long)(s + 4 * u) * C + lane];
+        }
+        for (; s < nc; s += 4) o4[0] += sc[s] * vp[(long long)s * C + lane];
+        if ((nc & 3) == wave) o4[1] += sc[nc] * qkv_s[2][lane];       // the key just produced, in the wave that owns column nc
+        o = ((o4[0] + o4[1]) + (o4[2] + o4[3])) + ((o4[4] + o4[5]) + (o4[6] + o4[7]));
+    }
+    if (lane < D) part_o[wave][lane] = o;
+    __syncthreads();
+    if (tid < D) out[(long long)b * C + h * D + tid] = (part_o[0][tid] + part_o[1][tid] + part_o[2][tid] + part_o[3][tid]) / l;
+}
+
+void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* bias, float* cache, long long cache_bs,
+                                 int cache_cs, const int* pos, const int* klen, int B, int H, int D, float* out, hipStream_t s) {
+    DTTS_REQUIRE(D == 48, "decode attention head dim");
+    hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, part, slices, B, CoutP, bias,
+                       cache, cache_bs, cache_cs, pos, klen, H, out);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -149,7 +149,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     const int VP = mel_head_.CoutP;
     const size_t PART_FLOATS = 262144;     // >= slices * CoutP for every decode GEMV (see gemv_slices)
     const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * C * Lp + (size_t)B * (7 * C + 4 * C + VP) +
-                                         (size_t)B * PART_FLOATS) +
+                                         (size_t)2 * B * PART_FLOATS) +
                         (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + (size_t)2 * G * B + B) + 64 * 256 +
                         std::max(prefill_ws(B, C, Lp), sizeof(float) * ((size_t)5 * B * (C / 2) * Tr + (size_t)B * C * Tr) + 4096);
     ws_.ensure(need + 65536);
@@ -166,6 +166,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     float* lat = ws_.f32((size_t)B * C);
     float* logits = ws_.f32((size_t)B * VP);
     float* part = ws_.f32((size_t)B * PART_FLOATS);
+    float* part2 = ws_.f32((size_t)B * PART_FLOATS);
     float* lnst = ws_.f32((size_t)B * 64 * 2);
     unsigned char* seen = static_cast<unsigned char*>(ws_.raw((size_t)B * V));
     int* finished = ws_.i32(B);
@@ -244,14 +245,23 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     sp.C = C;
     sp.n_unfinished = nullptr;
 
+    // decode GEMVs in workgroup form with the finishes folded into the consumers' prologues (B <= 8; DTTS_GPT_FAST=0: the older
+    // one-wave split-K kernels, also used for 9..16 sequences)
+    static const bool env_fast = []() { const char* v = getenv("DTTS_GPT_FAST"); return !(v && v[0] == '0'); }();
+    const bool fast = env_fast && B <= 8;
     // lat = final_norm(ln_f(hidden)) must already be in `lat` (fused into the producing kernel)
     auto head_and_sample = [&](int step, float* x_next) {
         // lm_head = (final_norm, mel_head) applied to ln_f(h)   (gpt/model.py:41, 173)
         hipLaunchKernelGGL(store_column_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, lat, C, latents_cm, (long long)C * lat_stride,
                            lat_stride, step);
-        const int sl = gemv_slices(C, VP);
-        launch_gemv_partial(mel_head_.w, C, VP, lat, C, B, part, sl, s);
-        launch_gemv_finish(part, sl, B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
+        if (fast) {
+            launch_gemv_block(mel_head_.w, C, VP, lat, C, B, part, s);
+            launch_gemv_finish(part, gemv_block_slices(C), B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
+        } else {
+            const int sl = gemv_slices(C, VP);
+            launch_gemv_partial(mel_head_.w, C, VP, lat, C, B, part, sl, s);
+            launch_gemv_finish(part, sl, B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
+        }
         sp.step = step;
         sp.x_next = x_next;
         launch_sampler(sp, s);
@@ -277,6 +287,19 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         for (int l = 0; l < NL; ++l) {
             const GptLayerW& w = gpt_layers_[l];
             float* cache = kv + (size_t)l * kv_layer;
+            if (fast) {
+                const int s1 = gemv_block_slices(C), s4 = gemv_block_slices(4 * C);
+                if (l == 0) launch_gemv_block(w.attn.w, C, w.attn.CoutP, hn, C, B, part, s);
+                else launch_gemv_block_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, lnst, nblk, w.ln1_g, w.ln1_b, s);
+                launch_decode_attention_qkv(part, s1, w.attn.CoutP, w.attn.b, cache, kv_bs, cap, pos, klen, B, H, D, ab, s);
+                launch_gemv_block(w.proj.w, C, w.proj.CoutP, ab, C, B, part2, s);
+                launch_gemv_finish(part2, s1, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);   // y = x + attn ; stats for ln_2
+                launch_gemv_block_ln(w.fc.w, C, w.fc.CoutP, y, C, B, part, lnst, nblk, w.ln2_g, w.ln2_b, s);
+                // c_proj(gelu(c_fc + bias)): c_fc's finish is this GEMV's prologue
+                launch_gemv_block_parts(w.fc2.w, 4 * C, w.fc2.CoutP, part, s1, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, B, part2, s);
+                launch_gemv_finish(part2, s4, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s, lnst);     // x = y + mlp ; stats for next ln_1
+                continue;
+            }
             int sl = gemv_slices(C, w.attn.CoutP);
             if (l == 0) launch_gemv_partial(w.attn.w, C, w.attn.CoutP, hn, C, B, part, sl, s);
             else launch_gemv_partial_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, sl, lnst, nblk, w.ln1_g, w.ln1_b, s);
