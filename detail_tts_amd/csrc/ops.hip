@@ -127,26 +127,42 @@ void launch_affine_apply(const float* x, long long x_bs, int x_cs, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm over channels: one thread per time column (coalesced across t), two passes over C.
-__global__ void ln_channels_kernel(const float* x, const float* r, long long bs, int cs, const int* lens, int T, int C,
-                                   const float* gamma, const float* beta, float eps, float* y, long long y_bs, int y_cs) {
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// LayerNorm over channels (two-pass: mean, then centred sum of squares).  A 256-thread workgroup owns 16 time columns:
+// thread (tx = column, ty = one of 16 channel groups) strides over C, the 16 partial sums per column are combined through LDS
+// in a fixed order.  Loads stay coalesced along the contiguous time axis (16 x 4 B segments).
+__global__ __launch_bounds__(256) void ln_channels_kernel(const float* x, const float* r, long long bs, int cs, const int* lens, int T, int C,
+                                                          const float* gamma, const float* beta, float eps, float* y, long long y_bs, int y_cs) {
+    __shared__ float red[16][17];
+    const int b = blockIdx.y, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tx;
     const int len = lens ? lens[b] : T;
-    if (t >= len) return;
-    const float* xb = x + (long long)b * bs + t;
-    const float* rb = r ? r + (long long)b * bs + t : nullptr;
+    const bool ok = t < len;
+    const int tc = ok ? t : (len > 0 ? len - 1 : 0);
+    const float* xb = x + (long long)b * bs + tc;
+    const float* rb = r ? r + (long long)b * bs + tc : nullptr;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += xb[(long long)c * cs] + (rb ? rb[(long long)c * cs] : 0.f);
-    const float mean = s / (float)C;
+    for (int c = ty; c < C; c += 16) s += xb[(long long)c * cs] + (rb ? rb[(long long)c * cs] : 0.f);
+    red[ty][tx] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i][tx];
+    const float mean = tot / (float)C;
+    __syncthreads();
     float q = 0.f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = ty; c < C; c += 16) {
         const float d = xb[(long long)c * cs] + (rb ? rb[(long long)c * cs] : 0.f) - mean;
         q += d * d;
     }
-    const float rstd = rsqrtf(q / (float)C + eps);
+    red[ty][tx] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qt += red[i][tx];
+    const float rstd = rsqrtf(qt / (float)C + eps);
+    if (!ok) return;
     float* yb = y + (long long)b * y_bs + t;
-    for (int c = 0; c < C; ++c) {
+    for (int c = ty; c < C; c += 16) {
         const float v = xb[(long long)c * cs] + (rb ? rb[(long long)c * cs] : 0.f);
         yb[(long long)c * y_cs] = (v - mean) * rstd * gamma[c] + beta[c];
     }
@@ -154,7 +170,7 @@ __global__ void ln_channels_kernel(const float* x, const float* r, long long bs,
 
 void launch_ln_channels(const float* x, const float* r, long long bs, int cs, const int* lens, int T, int B, int C,
                         const float* gamma, const float* beta, float eps, float* y, long long y_bs, int y_cs, hipStream_t s) {
-    hipLaunchKernelGGL(ln_channels_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, s, x, r, bs, cs, lens, T, C, gamma, beta, eps, y,
+    hipLaunchKernelGGL(ln_channels_kernel, dim3(cdiv(T, 16), B), dim3(256), 0, s, x, r, bs, cs, lens, T, C, gamma, beta, eps, y,
                        y_bs, y_cs);
     DTTS_CHECK_HIP(hipGetLastError());
 }
