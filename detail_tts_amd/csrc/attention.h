@@ -21,9 +21,11 @@ struct AttnParams {
     const float* band = nullptr;
     int band_w = 0;
     float* ml_out = nullptr;      // optional [B,H,T,2] (running max, denominator) for the rel-value fix-up
+    int x3 = 0;                   // split-precision (3 x bf16) kernel (attention_x3.hip): head dim 48 + T5 bias only
 };
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream);
+void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3
 
 // VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)
 //   relk[b,h,t,r] = scale * sum_c q[c,t] * Ek[r][c]

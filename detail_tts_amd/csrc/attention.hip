@@ -262,6 +262,11 @@ void launch_flash_attention(const AttnParams& p, hipStream_t stream) {
     dim3 grid(cdiv(p.T, QPB) * p.H * p.B);
     const char* tag = p.D == 48 ? "flash_attn_kernel<48>" : p.D == 64 ? "flash_attn_kernel<64>" : p.D == 96 ? "flash_attn_kernel<96>" : "flash_attn_kernel<192>";
     const double pairs = (double)p.B * p.H * (double)p.T * p.T * (p.causal ? 0.5 : 1.0);
+    if (p.x3 && p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out) {
+        ProfScope ps3("flash_attn_x3_kernel<48>", 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
+        launch_flash_attention_x3(p, stream);
+        return;
+    }
     ProfScope ps(tag, 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
     auto lds = [](int D) { const int nb = D <= 96 ? 2 : 1; return sizeof(float) * (size_t)(nb * D * KPITCH + nb * KT * (D + 4) + 2 * BIAS_CLIP + 1); };
     switch (p.D) {

@@ -1,0 +1,262 @@
+// Split-precision (3 x bf16) flash attention for the diffusion trunk (head dim 48, T5 relative-position bias) on gfx950.
+//
+// Same algorithm and register mapping as flash_attn_kernel (attention.hip): the score tile is computed transposed,
+// S^T[key, query] = K^T Q, so each query's scores sit in registers of 4 lanes and P^T is already the B operand of
+// O[c, query] += V[c, key] P^T[key, query].  The matrix products run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into
+// three bf16 planes (a = a0 + a1 + a2, 24 bits) and the six cross products a_i b_j (i + j <= 2) accumulated in fp32 - the result
+// matches the fp32-MFMA kernel to fp32 rounding at 2.3x less matrix-pipe time (336 vs 768 SIMD-cycles per 16 x 16 score tile).
+//
+//   QK^T : K = 48 channels = one full 32-channel MFMA + one half-used (channels 48..63 of Q are zero, the K lanes of that half
+//          re-read valid chunks).  K tile in LDS: chunks (8 channels x 16 B) [plane][c8 0..5][key 0..63]   -> linear ds_read_b128
+//   P V  : one MFMA consumes 32 keys = two 16-key score tiles; k-slot 8g + r <-> key 4g + r (first tile), 8g + 4 + r <-> key
+//          16 + 4g + r (second).  V tile in LDS: chunks (8 keys in that slot order) [plane][ct][u][g][channel 0..15]
+// K, V and Q are split on the fly while staging (hardware v_cvt_pk_bf16_f32); P is split in registers after the softmax.
+#include "attention.h"
+#include "split3.h"
+
+namespace dtts {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int D = 48, KT = 64, NW = 8, QPW = 16, QPB = NW * QPW, BIAS_CLIP = 64;
+constexpr int KCH = 6 * KT;                    // K chunks per plane
+constexpr int VCH = 3 * 2 * 4 * 16;            // V chunks per plane
+constexpr int BUF_BYTES = 3 * (KCH + VCH) * 16;   // 36 KiB per stage
+
+__device__ __forceinline__ bf16x8 as_bf(const uint4& q) { return __builtin_bit_cast(bf16x8, q); }
+
+// the six significant cross products, smallest first
+#define DTTS_X3_MFMA(acc, A, Bq)                                                          \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], Bq[0], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], Bq[1], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Bq[2], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], Bq[0], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Bq[1], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Bq[0], acc, 0, 0, 0);
+
+// 512 threads = 8 waves x 16 queries: <= 128 VGPRs -> 2 workgroups (16 waves) per CU share each staged K/V tile 8 ways
+__global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams p) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);      // [129], pre-multiplied by log2(e)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int nqb = (p.T + QPB - 1) / QPB;
+    const int Lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = Lid % nqb, hb = Lid / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int len = p.lens ? p.lens[b] : p.T;
+    const int q0 = qb * QPB;
+    if (q0 >= len) return;
+
+    const float* base = p.qkv + (long long)b * p.bs;
+    const float* qp = base + (long long)(p.q_off + h * p.head_stride) * p.cs;
+    const float* kp = base + (long long)(p.k_off + h * p.head_stride) * p.cs;
+    const float* vp = base + (long long)(p.v_off + h * p.head_stride) * p.cs;
+    if (tid < 2 * BIAS_CLIP + 1) bias_s[tid] = p.bias_tab[h * (2 * BIAS_CLIP + 1) + tid] * LOG2E;
+
+    // ---- Q fragments: B operand, lane (query j, g) holds channels kb*32 + 8g .. +7 of each plane, pre-scaled by scale*log2(e)
+    const int tq0 = q0 + wave * QPW;
+    const float qs = p.scale * LOG2E;
+    bf16x8 qf[2][3];
+    {
+        const int t = tq0 + j;
+        const int tc = t < len ? t : len - 1;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float v[8];
+            const int c0 = kb * 32 + 8 * g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c0 < D) ? qp[(long long)(c0 + e < D ? c0 + e : 0) * p.cs + tc] * qs : 0.f;
+            uint4 w0, w1, w2;
+            split8(v, w0, w1, w2);
+            qf[kb][0] = as_bf(w0);
+            qf[kb][1] = as_bf(w1);
+            qf[kb][2] = as_bf(w2);
+        }
+    }
+
+    floatx4 oacc[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) oacc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (len + KT - 1) / KT;
+    const bool wave_active = tq0 < len;
+
+    // ---- staging: K chunk (c8, key) = 8 channels of one key; V chunk (channel, octet o = u*4 + g) = keys {4g..4g+3, 16+4g..+3} + 32u.
+    // 384 + 384 chunks per tile over 512 threads: threads < 384 own K chunk tid, threads >= 128 own V chunk tid - 128.
+    const bool hasK = tid < 384, hasV = tid >= 128;
+    const int kkey = tid & 63, kc8 = hasK ? tid >> 6 : 0;
+    const int vidx = hasV ? tid - 128 : 0, vo = vidx & 7, vc = vidx >> 3;
+    const int vkey = (vo >> 2) * 32 + (vo & 3) * 4;                       // first key of the octet inside the tile
+    const bool vec_ok = ((p.cs & 3) == 0) && ((reinterpret_cast<unsigned long long>(vp) & 15ull) == 0);
+    float kr[8], vr[8];
+    auto load_tile = [&](int kt) {
+        const int s0 = kt * KT;
+        if (hasK) {
+            const int s = s0 + kkey, sc = s < len ? s : len - 1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kr[e] = kp[(long long)(kc8 * 8 + e) * p.cs + sc];
+        }
+        if (hasV) {
+            if (vec_ok && (s0 + KT <= len)) {
+                const float* r = vp + (long long)vc * p.cs + s0 + vkey;
+                const float4 x0 = *reinterpret_cast<const float4*>(r), x1 = *reinterpret_cast<const float4*>(r + 16);
+                vr[0] = x0.x; vr[1] = x0.y; vr[2] = x0.z; vr[3] = x0.w; vr[4] = x1.x; vr[5] = x1.y; vr[6] = x1.z; vr[7] = x1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int sv = s0 + vkey + (e & 3) + (e >> 2) * 16;
+                    const bool ok = sv < len;
+                    const float a = vp[(long long)vc * p.cs + (ok ? sv : len - 1)];
+                    vr[e] = ok ? a : 0.f;                                 // V must be finite (zero) where P == 0
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        uint4* kd = reinterpret_cast<uint4*>(smem + buf * BUF_BYTES);     // [3][6][64]
+        uint4* vd = kd + 3 * KCH;                                         // [3][ct][u][g][16]
+        uint4 w0, w1, w2;
+        if (hasK) {
+            split8(kr, w0, w1, w2);
+            kd[0 * KCH + kc8 * KT + kkey] = w0; kd[1 * KCH + kc8 * KT + kkey] = w1; kd[2 * KCH + kc8 * KT + kkey] = w2;
+        }
+        if (hasV) {
+            const int va = (((vc >> 4) * 2 + (vo >> 2)) * 4 + (vo & 3)) * 16 + (vc & 15);
+            split8(vr, w0, w1, w2);
+            vd[0 * VCH + va] = w0; vd[1 * VCH + va] = w1; vd[2 * VCH + va] = w2;
+        }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // A-operand chunk column of this lane for the two channel blocks: kb 0 -> c8 = g; kb 1 -> c8 = 4 + (g & 1) (lanes g >= 2 meet
+    // zero Q channels 48..63, any finite chunk will do)
+    const int kcol0 = g * KT + j, kcol1 = (4 + (g & 1)) * KT + j;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int s0 = kt * KT, buf = kt & 1;
+        const bool has_next = kt + 1 < ntiles;
+        if (has_next) load_tile(kt + 1);
+        if (wave_active) {
+            const uint4* Kb = reinterpret_cast<const uint4*>(smem + buf * BUF_BYTES);
+            const uint4* Vb = Kb + 3 * KCH;
+            // ---- S^T = K^T Q
+            floatx4 sacc[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc[ks] = floatx4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Kb[pl * KCH + kcol0 + ks * 16]);
+                DTTS_X3_MFMA(sacc[ks], a, qf[0])
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Kb[pl * KCH + kcol1 + ks * 16]);
+                DTTS_X3_MFMA(sacc[ks], a, qf[1])
+            }
+            // ---- bias, length mask, online softmax in the log2 domain (query column j)
+            const bool full_tile = (s0 + KT <= len);
+            const int t = tq0 + j;
+            float mx = -INFINITY;
+            // every (key, query) pair of this wave's tile beyond the bias window on one side -> one bucket, no table look-ups
+            // (wave-uniform; 12 of 15 tiles at T = 936)
+            const bool far_hi = s0 - (tq0 + QPW - 1) >= BIAS_CLIP, far_lo = (s0 + KT - 1) - tq0 <= -BIAS_CLIP;
+            if ((far_hi || far_lo) && full_tile) {
+                const float bfar = bias_s[far_hi ? 2 * BIAS_CLIP : 0];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sacc[ks][r] += bfar;
+                        mx = fmaxf(mx, sacc[ks][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = s0 + ks * 16 + 4 * g + r;
+                        float v = sacc[ks][r];
+                        int off = s - t;
+                        off = off < -BIAS_CLIP ? -BIAS_CLIP : (off > BIAS_CLIP ? BIAS_CLIP : off);
+                        v += bias_s[off + BIAS_CLIP];
+                        if (!full_tile) v = (s >= len) ? -INFINITY : v;
+                        sacc[ks][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[ks][r] - m_use);
+                    sacc[ks][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) oacc[ct] *= alpha;
+            // ---- O += V P^T: per 32 keys (u) split P in registers, then 3 channel tiles x 6 products
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 pf[3];
+                {
+                    const float pv[8] = {sacc[2 * u][0],     sacc[2 * u][1],     sacc[2 * u][2],     sacc[2 * u][3],
+                                         sacc[2 * u + 1][0], sacc[2 * u + 1][1], sacc[2 * u + 1][2], sacc[2 * u + 1][3]};
+                    uint4 w0, w1, w2;
+                    split8(pv, w0, w1, w2);
+                    pf[0] = as_bf(w0);
+                    pf[1] = as_bf(w1);
+                    pf[2] = as_bf(w2);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Vb[pl * VCH + ((ct * 2 + u) * 4 + g) * 16 + j]);
+                    DTTS_X3_MFMA(oacc[ct], a, pf)
+                }
+            }
+        }
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    float* ob = p.out + (long long)b * p.o_bs + (long long)(h * D) * p.o_cs;
+    const int t = tq0 + j;
+    if (t >= len) return;
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[(long long)(ct * 16 + 4 * g + r) * p.o_cs + t] = oacc[ct][r] * inv;
+}
+}  // namespace
+
+void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream) {
+    DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out, "attention_x3 covers head dim 48 with the T5 bias only");
+    constexpr size_t lds = 2 * BUF_BYTES + sizeof(float) * (2 * BIAS_CLIP + 1);
+    static bool attr = false;
+    if (!attr) {
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(flash_attn_x3_kernel, dim3(cdiv(p.T, QPB) * p.H * p.B), dim3(NW * 64), lds, stream, p);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace dtts

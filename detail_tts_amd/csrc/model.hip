@@ -311,6 +311,11 @@ void Model::build_diffusion(hipStream_t s) {
     }
 }
 
+static bool attn_x3_enabled() {
+    static const bool on = []() { const char* v = getenv("DTTS_ATTN_X3"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
 bool Model::use_x3() const {
     static const bool env_on = []() { const char* v = getenv("DTTS_CONV_X3"); return !(v && v[0] == '0'); }();
     return env_on && opt_conv_x3_;
@@ -363,6 +368,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     a.D = D;
     a.scale = 1.f / std::sqrt((float)D);
     a.bias_tab = w.bias_tab;
+    a.x3 = x3 && attn_x3_enabled();
     launch_flash_attention(a, s);
     ConvParams q;
     q.B = B;
