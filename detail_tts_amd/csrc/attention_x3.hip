@@ -89,8 +89,11 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     // 384 + 384 chunks per tile over 512 threads: threads < 384 own K chunk tid, threads >= 128 own V chunk tid - 128.
     const bool hasK = tid < 384, hasV = tid >= 128;
     const int kkey = tid & 63, kc8 = hasK ? tid >> 6 : 0;
-    const int vidx = hasV ? tid - 128 : 0, vo = vidx & 7, vc = vidx >> 3;
-    const int vkey = (vo >> 2) * 32 + (vo & 3) * 4;                       // first key of the octet inside the tile
+    // V chunk v = ((ct*2 + u)*4 + g)*16 + c16 is also its LDS slot: a wave writes 64 consecutive chunks (conflict-free), and the 8
+    // lanes (u, g) of one channel still consume whole 128-byte lines of its row
+    const int vidx = hasV ? tid - 128 : 0;
+    const int vc = ((vidx >> 7) << 4) + (vidx & 15);
+    const int vkey = ((vidx >> 6) & 1) * 32 + ((vidx >> 4) & 3) * 4;       // first key of the octet inside the tile
     const bool vec_ok = ((p.cs & 3) == 0) && ((reinterpret_cast<unsigned long long>(vp) & 15ull) == 0);
     float kr[8], vr[8];
     auto load_tile = [&](int kt) {
@@ -125,9 +128,8 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
             kd[0 * KCH + kc8 * KT + kkey] = w0; kd[1 * KCH + kc8 * KT + kkey] = w1; kd[2 * KCH + kc8 * KT + kkey] = w2;
         }
         if (hasV) {
-            const int va = (((vc >> 4) * 2 + (vo >> 2)) * 4 + (vo & 3)) * 16 + (vc & 15);
             split8(vr, w0, w1, w2);
-            vd[0 * VCH + va] = w0; vd[1 * VCH + va] = w1; vd[2 * VCH + va] = w2;
+            vd[0 * VCH + vidx] = w0; vd[1 * VCH + vidx] = w1; vd[2 * VCH + vidx] = w2;
         }
     };
     load_tile(0);
@@ -145,7 +147,14 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
         if (wave_active) {
             const uint4* Kb = reinterpret_cast<const uint4*>(smem + buf * BUF_BYTES);
             const uint4* Vb = Kb + 3 * KCH;
-            // ---- S^T = K^T Q
+            // The tile is processed in two independent 32-key halves (one PV MFMA step each): the second half's QK^T MFMAs carry
+            // no dependence on the first half's softmax / split VALU work, so the two pipes overlap inside one wave.
+            const bool full_tile = (s0 + KT <= len);
+            const int t = tq0 + j;
+            // every (key, query) pair of this wave's tile beyond the bias window on one side -> one bucket, no table look-ups
+            const bool far_hi = s0 - (tq0 + QPW - 1) >= BIAS_CLIP, far_lo = (s0 + KT - 1) - tq0 <= -BIAS_CLIP;
+            const bool far = (far_hi || far_lo) && full_tile;
+            const float bfar = bias_s[far_hi ? 2 * BIAS_CLIP : 0];
             floatx4 sacc[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -158,64 +167,55 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                 for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Kb[pl * KCH + kcol1 + ks * 16]);
                 DTTS_X3_MFMA(sacc[ks], a, qf[1])
             }
-            // ---- bias, length mask, online softmax in the log2 domain (query column j)
-            const bool full_tile = (s0 + KT <= len);
-            const int t = tq0 + j;
-            float mx = -INFINITY;
-            // every (key, query) pair of this wave's tile beyond the bias window on one side -> one bucket, no table look-ups
-            // (wave-uniform; 12 of 15 tiles at T = 936)
-            const bool far_hi = s0 - (tq0 + QPW - 1) >= BIAS_CLIP, far_lo = (s0 + KT - 1) - tq0 <= -BIAS_CLIP;
-            if ((far_hi || far_lo) && full_tile) {
-                const float bfar = bias_s[far_hi ? 2 * BIAS_CLIP : 0];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sacc[ks][r] += bfar;
-                        mx = fmaxf(mx, sacc[ks][r]);
-                    }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int s = s0 + ks * 16 + 4 * g + r;
-                        float v = sacc[ks][r];
-                        int off = s - t;
-                        off = off < -BIAS_CLIP ? -BIAS_CLIP : (off > BIAS_CLIP ? BIAS_CLIP : off);
-                        v += bias_s[off + BIAS_CLIP];
-                        if (!full_tile) v = (s >= len) ? -INFINITY : v;
-                        sacc[ks][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            float sum = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(sacc[ks][r] - m_use);
-                    sacc[ks][r] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            l_run = l_run * alpha + sum;
-            m_run = m_new;
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) oacc[ct] *= alpha;
-            // ---- O += V P^T: per 32 keys (u) split P in registers, then 3 channel tiles x 6 products
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                float mx = -INFINITY;
+                if (far) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sacc[2 * u + q][r] += bfar;
+                            mx = fmaxf(mx, sacc[2 * u + q][r]);
+                        }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int s = s0 + (2 * u + q) * 16 + 4 * g + r;
+                            float v = sacc[2 * u + q][r];
+                            int off = s - t;
+                            off = off < -BIAS_CLIP ? -BIAS_CLIP : (off > BIAS_CLIP ? BIAS_CLIP : off);
+                            v += bias_s[off + BIAS_CLIP];
+                            if (!full_tile) v = (s >= len) ? -INFINITY : v;
+                            sacc[2 * u + q][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                float sum = 0.f;
+                float pv[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(sacc[2 * u + q][r] - m_use);
+                        pv[q * 4 + r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                l_run = l_run * alpha + sum;
+                m_run = m_new;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) oacc[ct] *= alpha;
                 bf16x8 pf[3];
                 {
-                    const float pv[8] = {sacc[2 * u][0],     sacc[2 * u][1],     sacc[2 * u][2],     sacc[2 * u][3],
-                                         sacc[2 * u + 1][0], sacc[2 * u + 1][1], sacc[2 * u + 1][2], sacc[2 * u + 1][3]};
                     uint4 w0, w1, w2;
                     split8(pv, w0, w1, w2);
                     pf[0] = as_bf(w0);

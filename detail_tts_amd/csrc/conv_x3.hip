@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
 }
 
 template <int EPI>   // 0: bias (+ residual); 1: + activation / out_scale
-__global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
@@ -244,22 +244,40 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
 
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // bias of this lane's 32 output rows: all loads before the first store (one exposed latency per workgroup, no registers
+    // held across the K loop - a third workgroup per CU is worth more)
+    float bv[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            bv[i][r] = p.bias ? p.bias[row < p.Cout ? row : p.Cout - 1] : 0.f;
+        }
     float* yb = p.y + (long long)b * p.y_bs;
     const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
+    // The residual usually IS the output buffer (in-place x += f(x)): the compiler must keep every residual load behind the
+    // previous store, which would serialise 64 load latencies.  Element (row, n) is read and written by this lane only, so per
+    // 32 x 32 tile the 16 residual loads are issued first, into registers, and the 16 stores follow.
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn0 + j * 32 + l31;
             if (n >= nvalid) continue;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                rv[r] = rb ? rb[(long long)(row < p.Cout ? row : p.Cout - 1) * p.res_cs + n] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row >= p.Cout) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[row];
+                float v = acc[i][j][r] + bv[i][r];
                 if (EPI == 1) v = act_apply(v, p.epi_act, p.epi_slope) * p.out_scale;
-                if (rb) v += p.res_scale * rb[(long long)row * p.res_cs + n];
+                v += p.res_scale * rv[r];
                 yb[(long long)row * p.y_cs + n] = v;
             }
         }
@@ -330,7 +348,10 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 6x this in bf16
     const double bytes = 6.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 6.0 * (double)p.Cout * p.Cin * p.KW;
     {
-        ProfScope ps("conv_x3_kernel<128,128>", flops, bytes, s);
+        static const bool by_shape = []() { const char* v = getenv("DTTS_PROF_SHAPES"); return v && v[0] == '1'; }();
+        const char* tag = "conv_x3_kernel<128,128>";
+        if (by_shape) tag = p.KW == 3 ? "conv_x3 k3" : (p.Cout > 1024 ? "conv_x3 k1 M=2304" : (p.res ? "conv_x3 k1 +res" : "conv_x3 k1"));
+        ProfScope ps(tag, flops, bytes, s);
         if (p.epi_act != ACT_NONE || p.out_scale != 1.f) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), lds, s, p);
     }
