@@ -160,7 +160,11 @@ int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const
 int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
                    int B, float* mel_out, void* stream);
 
-/* Runtime options: "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams. */
+/* Runtime options:
+ *   "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams;
+ *   "conv_x3"     (default 1): diffusion-trunk convs and attention on the split-precision path (every fp32 operand as three
+ *                 bf16 planes, six bf16 MFMA products per fp32 product, fp32 accumulate: fp32-class error at 1.7-2.3x the fp32
+ *                 MFMA rate); 0 = the exact fp32-MFMA kernels. */
 int dtts_set_option(dtts_handle* h, const char* key, int value);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
