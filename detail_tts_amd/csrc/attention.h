@@ -22,6 +22,10 @@ struct AttnParams {
     int band_w = 0;
     float* ml_out = nullptr;      // optional [B,H,T,2] (running max, denominator) for the rel-value fix-up
     int x3 = 0;                   // split-precision (3 x bf16) kernel (attention_x3.hip): head dim 48 + T5 bias only
+    // x3 only: write the output as split-precision planes [B][H*D/8][3][x3_tp][8 bf16] (conv_x3.h layout, column t + 1) instead
+    // of fp32 `out`; only columns t < len are written (halo / tail columns keep what the previous writer left: zeros)
+    void* out_x3 = nullptr;
+    int x3_tp = 0;
 };
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream);

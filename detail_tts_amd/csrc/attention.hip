@@ -267,6 +267,7 @@ void launch_flash_attention(const AttnParams& p, hipStream_t stream) {
         launch_flash_attention_x3(p, stream);
         return;
     }
+    DTTS_REQUIRE(!p.out_x3, "split-precision attention output needs the x3 kernel (head dim 48, T5 bias)");
     ProfScope ps(tag, 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
     auto lds = [](int D) { const int nb = D <= 96 ? 2 : 1; return sizeof(float) * (size_t)(nb * D * KPITCH + nb * KT * (D + 4) + 2 * BIAS_CLIP + 1); };
     switch (p.D) {

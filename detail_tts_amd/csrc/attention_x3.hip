@@ -12,6 +12,7 @@
 //          16 + 4g + r (second).  V tile in LDS: chunks (8 keys in that slot order) [plane][ct][u][g][channel 0..15]
 // K, V and Q are split on the fly while staging (hardware v_cvt_pk_bf16_f32); P is split in registers after the softmax.
 #include "attention.h"
+#include "conv_x3.h"
 #include "split3.h"
 
 namespace dtts {
@@ -236,10 +237,26 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     }
 
     if (!wave_active) return;
-    float* ob = p.out + (long long)b * p.o_bs + (long long)(h * D) * p.o_cs;
     const int t = tq0 + j;
     if (t >= len) return;
     const float inv = 1.f / l_run;
+    if (p.out_x3) {
+        // lane (j, g) holds channels ct*16 + 4g + r of query t: half (g & 1) of the 8-channel chunk c8 = h*6 + ct*2 + (g >> 1)
+        unsigned char* ob = static_cast<unsigned char*>(p.out_x3) + ((long long)b * (p.H * D / 8) * 3) * p.x3_tp * 16;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            unsigned w0[2], w1[2], w2[2];
+            split_pair(oacc[ct][0] * inv, oacc[ct][1] * inv, w0[0], w1[0], w2[0]);
+            split_pair(oacc[ct][2] * inv, oacc[ct][3] * inv, w0[1], w1[1], w2[1]);
+            const long long c8 = h * (D / 8) + ct * 2 + (g >> 1);
+            unsigned char* o = ob + ((c8 * 3) * p.x3_tp + (t + X3_HALO)) * 16 + (g & 1) * 8;
+            *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
+            *reinterpret_cast<uint2*>(o + (long long)p.x3_tp * 16) = make_uint2(w1[0], w1[1]);
+            *reinterpret_cast<uint2*>(o + 2LL * p.x3_tp * 16) = make_uint2(w2[0], w2[1]);
+        }
+        return;
+    }
+    float* ob = p.out + (long long)b * p.o_bs + (long long)(h * D) * p.o_cs;
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll

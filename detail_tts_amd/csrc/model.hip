@@ -369,6 +369,13 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     a.scale = 1.f / std::sqrt((float)D);
     a.bias_tab = w.bias_tab;
     a.x3 = x3 && attn_x3_enabled();
+    // the proj conv's input planes come straight from the attention epilogue; xs still holds the zero halo / tail columns that
+    // gn_split_planes wrote for the qkv conv (same B, T, lens), and the qkv conv has consumed the rest
+    const bool att_planes = a.x3 && T + 1 < x3_tp(T);
+    if (att_planes) {
+        a.out_x3 = xs;
+        a.x3_tp = x3_tp(T);
+    }
     launch_flash_attention(a, s);
     ConvParams q;
     q.B = B;
@@ -386,7 +393,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     q.res_bs = bs;
     q.res_cs = Ta;
     if (x3) {
-        launch_split_planes(att, bs, Ta, nullptr, ACT_NONE, lens, T, B, C, xs, s);
+        if (!att_planes) launch_split_planes(att, bs, Ta, nullptr, ACT_NONE, lens, T, B, C, xs, s);
         q.x3 = xs;
         q.x3_tp = x3_tp(T);
     }
