@@ -161,8 +161,15 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
     }
 }
 
-template <int EPI>   // 0: bias (+ residual); 1: + activation / out_scale
+// EPI 0: bias (+ residual); 1: + activation / out_scale.   KW3: three taps (else one).
+// K loop order is (16-channel block, tap): the X tile of a channel block carries its halo (128 + KW - 1 columns) and is fetched
+// ONCE, every tap reads it through a shifted (16-byte aligned) ds_read_b128; only the W tile changes per tap.  A k = 3 conv moves
+// 48.5 KiB per channel block through the L2 -> LDS path instead of 72.
+template <int EPI, bool KW3>
 __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
+    constexpr int KW = KW3 ? 3 : 1;
+    constexpr int XBUF = TILE + 6 * 2 * 16;            // 128-column main part + 2 halo columns per kind
+    constexpr int XOFF = 2 * TILE;                     // LDS: W stage 0 | W stage 1 | X buffer 0 | X buffer 1
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
@@ -173,29 +180,29 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
     const int m0 = mt * BM, n0 = (nb - b * ntiles) * BN;
     const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
     if (n0 >= nvalid) return;
-    const int C8 = p.Cin >> 3, c16n = p.Cin >> 4, nks = p.KW * c16n, Tp = p.x3_tp;
+    const int C8 = p.Cin >> 3, c16n = p.Cin >> 4, nks = KW * c16n, Tp = p.x3_tp;
     const int bin = p.x_bidx ? p.x_bidx[b] : b;
+    const uint4* wbase = static_cast<const uint4*>(p.w3) + m0 + lane;
+    const uint4* xbase = static_cast<const uint4*>(p.x3) + (long long)bin * C8 * 3 * Tp + n0 + (X3_HALO - p.pad) + lane;
+    const long long wtap = (long long)C8 * 3 * p.CoutP;
 
-    const int operand = wave >> 1;                     // waves 0,1 fetch the W tile, waves 2,3 the X tile
-    const uint4* gbase = (operand ? static_cast<const uint4*>(p.x3) + (long long)bin * C8 * 3 * Tp + n0 + (X3_HALO - p.pad)
-                                  : static_cast<const uint4*>(p.w3) + m0) + lane;
-    const long long rowlen = operand ? Tp : p.CoutP;   // chunks per (c8, plane) run
-    const long long tapstride = operand ? 1 : (long long)C8 * 3 * p.CoutP;
-    // The 6 LDS-DMA loads a wave owes per K-step are issued ONE AT A TIME between groups of 4 MFMAs: issued as a burst, the
-    // 72 loads of a CU's 12 waves queue on the texture-address path while every MFMA pipe idles, and the co-resident
-    // workgroups fall into lock-step (load phase, then MFMA phase): measured 161 -> 190 TFLOP/s fp32-equivalent.
-    int ks_n = 0, tap_n = 0, c16_n = 0;                // the K-step being fetched
-    auto issue_one = [&](int i, int stage) {
-        const int j = (wave & 1) * 6 + i, kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
-        const uint4* g = gbase + tap_n * tapstride + ((long long)(2 * c16_n + h) * 3 + pl) * rowlen + rh * 64;
+    // LDS-DMA pieces (1 KiB = 64 rows of one (plane, k-half) "kind"): 12 per W tile, 12 (+ the 12 halo chunks) per X tile.
+    auto dma = [&](const uint4* g, int lds_off) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(smem + stage * 2 * TILE + operand * TILE + kind * 2048 + rh * 1024),
-                                         16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
-    auto advance = [&]() {                             // the last step refetches itself into the idle stage: branch-free tail
-        if (ks_n + 1 < nks) {
-            ++ks_n;
-            if (++c16_n == c16n) { c16_n = 0; ++tap_n; }
+    auto w_piece = [&](int j, int tap, int c16, int stage) {          // j = kind*2 + row half
+        const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
+        dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * 3 + pl) * p.CoutP + rh * 64, stage * TILE + kind * 2048 + rh * 1024);
+    };
+    auto x_piece = [&](int j, int c16, int buf) {
+        const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
+        dma(xbase + ((long long)(2 * c16 + h) * 3 + pl) * Tp + rh * 64, XOFF + buf * XBUF + kind * 2048 + rh * 1024);
+    };
+    auto x_halo = [&](int c16, int buf) {                              // lanes 0..11: (kind, column 128 + r)
+        if (lane < 12) {
+            const int kind = lane >> 1, pl = kind >> 1, h = kind & 1, r = lane & 1;
+            dma(xbase - lane + ((long long)(2 * c16 + h) * 3 + pl) * Tp + 128 + r, XOFF + buf * XBUF + TILE);
         }
     };
 
@@ -209,24 +216,41 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_one(i, 0);
-    advance();
+    for (int i = 0; i < 3; ++i) {
+        w_piece(wave * 3 + i, 0, 0, 0);
+        x_piece(wave * 3 + i, 0, 0);
+    }
+    if (KW3 && wave == 0) x_halo(0, 0);
+
+    int c16 = 0, tap = 0;                               // the step being computed
     for (int ks = 0; ks < nks; ++ks) {
-        // the barrier also orders the previous step's ds_reads of the stage that is refilled next (WAR)
+        // the barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int nst = (ks + 1) & 1;
-        const unsigned char* As = smem + (ks & 1) * 2 * TILE + lhi * 2048;
-        const unsigned char* Bs = As + TILE;
+        // what to fetch during this step: the W tile of the next step; (a share of) the X tile of the next channel block.  The
+        // last step / block refetch themselves into the idle stage: branch-free tail.
+        int tapn = tap + 1, c16w = c16;
+        if (tapn == KW) { tapn = 0; c16w = c16 + 1 < c16n ? c16 + 1 : c16; if (c16 + 1 >= c16n) tapn = tap; }
+        const int c16x = c16 + 1 < c16n ? c16 + 1 : c16;
+        const int wst = (ks + 1) & 1, xbuf = (c16 + 1) & 1;
+
+        const unsigned char* As = smem + (ks & 1) * TILE + lhi * 2048;
+        const unsigned char* Xb = smem + XOFF + (c16 & 1) * XBUF;
         bf16x8 a[2][3], bb[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int i = 0; i < 2; ++i) {
+            const int nn = wn0 + i * 32 + l31 + tap;                    // column of the haloed tile
+            const unsigned char* xq = nn < 128 ? Xb + lhi * 2048 + nn * 16 : Xb + TILE + lhi * 32 + (nn - 128) * 16;
+            const int xps = nn < 128 ? 4096 : 64;                       // plane stride: main part / halo part
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int pl = 0; pl < 3; ++pl) {
                 a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * 4096 + (wm0 + i * 32 + l31) * 16);
-                bb[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * 4096 + (wn0 + i * 32 + l31) * 16);
+                bb[i][pl] = *reinterpret_cast<const bf16x8*>(xq + pl * xps);
             }
-        // term-major: one cross product over the wave's 4 accumulators per group, smallest terms first
+        }
+        // term-major: one cross product over the wave's 4 accumulators per group, smallest terms first; ONE LDS-DMA piece after
+        // each group (as a burst the 72 pieces of a CU's 12 waves queue on the texture-address path while every MFMA pipe idles
+        // and the co-resident workgroups fall into lock-step: 161 -> 190 TFLOP/s fp32-equivalent)
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -236,10 +260,13 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            issue_one(t, nst);
+            if (t < 3) w_piece(wave * 3 + t, tapn, c16w, wst);
+            else if (!KW3) x_piece(wave * 3 + (t - 3), c16x, xbuf);
+            else if (t == 3) x_piece(tap * 4 + wave, c16x, xbuf);
+            else if (t == 4 && tap == 2 && wave == 0) x_halo(c16x, xbuf);
             __builtin_amdgcn_sched_barrier(0);
         }
-        advance();
+        if (++tap == KW) { tap = 0; ++c16; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
 
@@ -334,13 +361,15 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
     DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3: channel padding");
     DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
-    DTTS_REQUIRE(p.pad <= X3_HALO && p.KW - 1 - p.pad <= X3_HALO, "conv_x3: halo");
+    DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
     static bool attr = false;
-    constexpr size_t lds = (size_t)NSTAGE * 2 * TILE;
+    constexpr size_t lds = (size_t)2 * TILE + 2 * (TILE + 6 * 2 * 16);
     if (!attr) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);
@@ -352,8 +381,14 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
         const char* tag = "conv_x3_kernel<128,128>";
         if (by_shape) tag = p.KW == 3 ? "conv_x3 k3" : (p.Cout > 1024 ? "conv_x3 k1 M=2304" : (p.res ? "conv_x3 k1 +res" : "conv_x3 k1"));
         ProfScope ps(tag, flops, bytes, s);
-        if (p.epi_act != ACT_NONE || p.out_scale != 1.f) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), lds, s, p);
+        const bool epi = p.epi_act != ACT_NONE || p.out_scale != 1.f;
+        if (p.KW == 3) {
+            if (epi) hipLaunchKernelGGL((conv_x3_kernel<1, true>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_x3_kernel<0, true>), grid, dim3(256), lds, s, p);
+        } else {
+            if (epi) hipLaunchKernelGGL((conv_x3_kernel<1, false>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_x3_kernel<0, false>), grid, dim3(256), lds, s, p);
+        }
     }
     DTTS_CHECK_HIP(hipGetLastError());
 }
