@@ -131,7 +131,7 @@ def main():
     step(99)                                 # one untimed pass with per-stage hipEvents (adds a sync, so not part of the timed region)
     stage_ms = {k: round(v, 2) for k, v in model.stage_ms.items()}
     model.stage_ms = None
-    model.rt.profile_enable(True)            # per-launch hipEvents on the launch streams, live over the timed region
+    model.rt.profile_enable(os.environ.get("DTTS_BENCH_NO_PROF") != "1")            # per-launch hipEvents on the launch streams, live over the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

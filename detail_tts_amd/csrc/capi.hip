@@ -61,6 +61,8 @@ int dtts_set_option(dtts_handle* h, const char* key, int value) {
 int dtts_profile_enable(int on) {
     dtts::Profiler::get().reset();
     dtts::Profiler::get().on = on != 0;
+    dtts::Profiler::get().all = on >= 2;
+    if (on) dtts::Profiler::get().reserve(1 << 16);
     return 0;
 }
 

@@ -26,8 +26,19 @@ public:
         return p;
     }
     bool on = false;
+    bool all = false;        // also bracket the bandwidth-only helper kernels (flops == 0); off in bench.py: fewer events
+    bool active_ = false;    // the current ProfScope is being recorded
+    // events are created here, outside any timed region
+    void reserve(size_t n) {
+        while (pool_.size() < n) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pool_.push_back(e);
+        }
+    }
     void begin(const char* tag, double flops, double bytes, hipStream_t s) {
-        if (!on) return;
+        active_ = on && (all || flops > 0.0);
+        if (!active_) return;
         if (!base_) {
             (void)hipEventCreate(&base_);
             (void)hipEventRecord(base_, s);
@@ -37,7 +48,7 @@ public:
         (void)hipEventRecord(a, s);
     }
     void end(hipStream_t s) {
-        if (!on) return;
+        if (!active_) return;
         (void)hipEventRecord(recs_.back().stop, s);
     }
     // synchronises, folds the pending records into the per-tag totals and recycles the events

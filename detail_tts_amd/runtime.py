@@ -85,7 +85,8 @@ class Runtime:
         self._rc(self.lib.dtts_set_option(self.h, key.encode(), int(value)))
 
     def profile_enable(self, on=True):
-        self.lib.dtts_profile_enable(1 if on else 0)
+        """True / 1: MFMA kernels; 2: also the bandwidth-only helper kernels; False: off"""
+        self.lib.dtts_profile_enable(int(on))
 
     def profile_report(self):
         arr = (_lib.DttsKernelStat * 64)()

@@ -169,7 +169,8 @@ int dtts_set_option(dtts_handle* h, const char* key, int value);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch hipEvent profiling of the MFMA kernels (conv GEMM, flash attention), recorded on the launch stream.
- * enable(1) resets the totals; report() synchronises and returns the number of entries written. */
+ * enable(1) resets the totals and brackets the MFMA kernels; enable(2) also the bandwidth-only helpers (GroupNorm / split passes);
+ * the events are created at enable time.  report() synchronises and returns the number of entries written. */
 typedef struct dtts_kernel_stat {
     char name[64];
     long long launches;

@@ -18,7 +18,7 @@ def layer():
 
 for _ in range(3):
     layer()
-rt.profile_enable(True)
+rt.profile_enable(2)
 for _ in range(20):
     layer()
 tot = 0.0
