@@ -26,12 +26,10 @@ struct AttnParams {
     // of fp32 `out`; only columns t < len are written (halo / tail columns keep what the previous writer left: zeros)
     void* out_x3 = nullptr;
     int x3_tp = 0;
-    void* kv3 = nullptr;          // x3 only: scratch of attn_x3_kv_bytes(B, H, T) for the pre-split K/V tile images
 };
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream);
-void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);
-size_t attn_x3_kv_bytes(int B, int H, int T);   // called by launch_flash_attention when p.x3
+void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3
 
 // VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)
 //   relk[b,h,t,r] = scale * sum_c q[c,t] * Ek[r][c]

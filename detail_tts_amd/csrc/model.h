@@ -164,7 +164,7 @@ private:
     void run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const;
     // xs: scratch for the split-precision input planes (x3_bytes(B, C, T)); null -> exact fp32 MFMA path
     void attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens, int B,
-                         int T, int Ta, hipStream_t s, void* xs = nullptr, void* kv3 = nullptr);
+                         int T, int Ta, hipStream_t s, void* xs = nullptr);
     void res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T, int Ta,
                        int step, hipStream_t s, void* xs = nullptr);
     bool use_x3() const;

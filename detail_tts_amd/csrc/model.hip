@@ -324,7 +324,7 @@ bool Model::use_x3() const {
 // ------------------------------------------------------------------------------ building blocks
 // AttentionBlock (vqvae/utils/diff_util.py:209-215): y = x + proj(attn(qkv(GN(x))))
 void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens,
-                            int B, int T, int Ta, hipStream_t s, void* xs, void* kv3) {
+                            int B, int T, int Ta, hipStream_t s, void* xs) {
     const int C = w.C, D = C / w.H;
     const long long bs = (long long)C * Ta;
     int groups = 32;
@@ -368,8 +368,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     a.D = D;
     a.scale = 1.f / std::sqrt((float)D);
     a.bias_tab = w.bias_tab;
-    a.x3 = x3 && kv3 && attn_x3_enabled();
-    a.kv3 = kv3;
+    a.x3 = x3 && attn_x3_enabled();
     // the proj conv's input planes come straight from the attention epilogue; xs still holds the zero halo / tail columns that
     // gn_split_planes wrote for the qkv conv (same B, T, lens), and the qkv conv has consumed the rest
     const bool att_planes = a.x3 && T + 1 < x3_tp(T);
@@ -542,10 +541,9 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* qkv = ws_.f32(3 * act);
         float* ab = ws_.f32((size_t)B * C * 2);
         void* xs = x3 ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
-        void* kv3 = x3 ? ws_.raw(attn_x3_kv_bytes(B, cfg.diff_heads, T)) : nullptr;
         auto dlayer_n = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp, const int* lens, int nb) {
             res_block_fwd(l.rb, in, tmp, mid, ab, lens, nb, T, Ta, step, st, xs);
-            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, st, xs, kv3);
+            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, st, xs);
         };
         // conditioning_timestep_integrator (vqvae/diff_model.py:295): B code embeddings | Nu unconditional inputs
         dlayer_n(integ_[0], hf.cin, bufB, bufC, bufA, hf.lens_integ, nbi);
@@ -595,7 +593,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
 
 static size_t pair_ws_bytes(int B, int C, int T) {
     const size_t act = (size_t)B * C * T;
-    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C)) + 3 * x3_bytes(B, C, T) + 2 * attn_x3_kv_bytes(B, 16, T) + 24 * 256;
+    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C)) + 3 * x3_bytes(B, C, T) + 20 * 256;
 }
 
 // ------------------------------------------------------------------------------ stage entry points
@@ -774,7 +772,7 @@ void Model::op_attention_block(const char* prefix, const float* x, const int* le
     DTTS_REQUIRE(bound_, "weights not bound");
     AttnBlockW w = attn_block(prefix, C, cfg.diff_heads);
     const size_t act = (size_t)B * C * T;
-    ws_.ensure(sizeof(float) * (4 * act + (size_t)2 * B * C) + x3_bytes(B, C, T) + attn_x3_kv_bytes(B, cfg.diff_heads, T) + 8192);
+    ws_.ensure(sizeof(float) * (4 * act + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -786,8 +784,7 @@ void Model::op_attention_block(const char* prefix, const float* x, const int* le
         for (auto& dl2 : *grp)
             if (dl2.at.qkv.w == w.qkv.w) w = dl2.at;
     void* xs = (use_x3() && w.qkv.w3) ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
-    void* kv3 = xs ? ws_.raw(attn_x3_kv_bytes(B, cfg.diff_heads, T)) : nullptr;
-    attention_block(w, x, y, qkv, att, ab, dl, B, T, T, s, xs, kv3);
+    attention_block(w, x, y, qkv, att, ab, dl, B, T, T, s, xs);
 }
 
 void Model::op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y,

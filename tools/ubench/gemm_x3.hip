@@ -54,7 +54,6 @@ __global__ __launch_bounds__(WM * 128) void gemm_x3(const uint4* __restrict__ Wp
     };
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     f16v acc[2][2];
-    bf8 a[2][3], bb[2][3];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) issue_one(i, 0);
@@ -67,11 +66,18 @@ __global__ __launch_bounds__(WM * 128) void gemm_x3(const uint4* __restrict__ Wp
         const int nst = (ks + 1) & 1;
         const unsigned char* As = smem + (ks & 1) * STAGE + lhi * (BMk * 16);
         const unsigned char* Bs = smem + (ks & 1) * STAGE + ATILE + lhi * 2048;
+        bf8 a[2][3], bb[2][3];
         auto lda = [&](int i, int p) { a[i][p] = *reinterpret_cast<const bf8*>(As + p * (2 * BMk * 16) + (wm0 + i * 32 + l31) * 16); };
         auto ldb = [&](int j, int p) { bb[j][p] = *reinterpret_cast<const bf8*>(Bs + p * 4096 + (wn0 + j * 32 + l31) * 16); };
-        if (!(ABL & 8) || ks == 0) {
+        if (RD == 0) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) { lda(0, p); lda(1, p); ldb(0, p); ldb(1, p); }
+        } else {
+            lda(0, 2); lda(1, 2); ldb(0, 0); ldb(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lda(0, 1); lda(1, 1); ldb(0, 1); ldb(1, 1);
+            lda(0, 0); lda(1, 0); ldb(0, 2); ldb(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -96,8 +102,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_x3(const uint4* __restrict__ Wp
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, n = n0 + wn0 + j * 32 + l31;
-                if (ABL & 4) { if (acc[i][j][r] == 12345.678f) yb[(long long)row * T + n] = acc[i][j][r]; }
-                else if (n < T) yb[(long long)row * T + n] = acc[i][j][r];
+                if (n < T) yb[(long long)row * T + n] = acc[i][j][r];
             }
 }
 
@@ -152,7 +157,7 @@ void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, int
 
 int main() {
     const int M = 768, C = 768, T = 936, B = 16, Tp = 8 * 128 + 2;
-    for (int taps : {1, 3}) {
+    for (int taps : {1}) {
         std::vector<float> hw((size_t)taps * M * C), hx((size_t)B * C * T);
         srand(1);
         for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.036f;
@@ -179,10 +184,6 @@ int main() {
         run<2, 0, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  no DMA in loop");
         run<2, 0, 2>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  no wait/barrier");
         run<2, 0, 3>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  no DMA, no barrier");
-        run<2, 0, 4>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  no epilogue stores");
-        run<2, 0, 7>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  no DMA, barrier, stores");
-        run<2, 0, 15>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  MFMA only (no LDS reads)");
-        run<2, 0, 8>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "  full but no LDS reads");
         run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "128x128 full");
         run<2, 0, 1>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "  no DMA in loop");
         run<2, 0, 2>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "  no wait/barrier");
