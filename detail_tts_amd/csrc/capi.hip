@@ -52,6 +52,20 @@ int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax
     DTTS_API_END(h)
 }
 
+int dtts_resample(dtts_handle* h, const float* x, int B, int L, const float* kernel, int orig, int neu, int width, float* y, int Lout,
+                  void* stream) {
+    DTTS_API_BEGIN
+    h->m->resample(x, B, L, kernel, orig, neu, width, y, Lout, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, int L, int n_fft, int hop, float* mel_out, int Tmax,
+                         void* stream) {
+    DTTS_API_BEGIN
+    h->m->mel_spectrogram(wav, lens, B, L, n_fft, hop, mel_out, Tmax, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_set_option(dtts_handle* h, const char* key, int value) {
     DTTS_API_BEGIN
     h->m->set_option(key, value);

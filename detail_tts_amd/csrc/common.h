@@ -43,6 +43,7 @@ enum Act : int {
     ACT_GELU_NEW = 4,
     ACT_TANH = 5,
     ACT_MISH = 6,
+    ACT_LOG_CLAMP = 7, // log(max(v, 1e-5))   (dynamic_range_compression_torch, vqvae/utils/data_utils.py:21-27)
 };
 
 // epilogue pairing modes: packed weight rows (2r, 2r+1) hold the two halves of a gated pair
@@ -66,6 +67,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
             float sp = v > 20.f ? v : log1pf(expf(v));
             return v * tanhf(sp);
         }
+        case ACT_LOG_CLAMP: return logf(fmaxf(v, 1e-5f));
         default: return v;
     }
 }

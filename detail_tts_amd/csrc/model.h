@@ -124,6 +124,9 @@ public:
     // ---- VQ decode path (infer_gpt)
     void vq_decode(const int* codes_host, const int* ncodes_host, int nmax, const float* refer, const int* refer_lens_host, int Tr,
                    int B, float* mel_out, hipStream_t s);
+    // ---- prompt front-end
+    void resample(const float* x, int B, int L, const float* kernel, int orig, int neu, int width, float* y, int Lout, hipStream_t s);
+    void mel_spectrogram(const float* wav, const int* lens_host, int B, int L, int n_fft, int hop, float* mel_out, int Tmax, hipStream_t s);
     // ---- unit ops used by the parity tests
     void op_attention_block(const char* prefix, const float* x, const int* lens_host, int B, int C, int T, float* y, hipStream_t s);
     void op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y, hipStream_t s);
@@ -153,6 +156,7 @@ private:
     void build_vocoder();
     void build_gpt();
     void build_vq();
+    void build_frontend();
     void gpt_prefill_layers(float* x, const int* lens, int B, int L, float* kv_cache, long long kv_layer_stride, long long kv_bs,
                             int kv_cs, hipStream_t s);
     MelStyleW mel_style_w(const std::string& prefix, int n_mel, int hidden, int out) const;
@@ -208,6 +212,11 @@ private:
     hipStream_t s2_ = nullptr;            // second stream of the two-stream diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     const int* umap_local_ = nullptr;     // [B] uncond sample -> index of its length group
+
+    // prompt front-end
+    bool has_frontend_ = false;
+    PackedConv fe_dft_, fe_mel_;
+    int fe_nfft_ = 0;
 
     // vq decode path
     bool has_vq_ = false;

@@ -121,6 +121,8 @@ void Model::bind_weights(const void* blob, size_t nbytes, const char* const* nam
     if (has_gpt_) build_gpt();
     has_vq_ = weights_.count("quantizer.table") != 0;
     if (has_vq_) build_vq();
+    has_frontend_ = weights_.count("frontend.dft.wp") != 0;
+    if (has_frontend_) build_frontend();
     bound_ = true;
 }
 

@@ -292,4 +292,7 @@ def pack_all(P, cfg=None, parts=("diffusion",)):
         pack_gpt(pk, P, cfg)
     if "vq" in parts:
         pack_vq(pk, P, cfg)
+    if "frontend" in parts:
+        from .frontend import pack_frontend
+        pack_frontend(pk, cfg)
     return pk

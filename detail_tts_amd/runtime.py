@@ -34,7 +34,7 @@ def _check(t, name):
         raise DttsError(f"{name}: expected a contiguous float32 CUDA tensor")
 
 
-ALL_PARTS = ("diffusion", "gpt", "vocoder", "vq")
+ALL_PARTS = ("diffusion", "gpt", "vocoder", "vq", "frontend")
 
 
 class Runtime:
@@ -63,6 +63,7 @@ class Runtime:
         if rc != 0:
             raise DttsError(f"dtts_create failed ({rc}): {self.lib.dtts_last_error(None).decode()}")
         self.parts = tuple(parts)
+        self._rs_kernels = {}
         P = state if (folded or not self.parts) else select_inference_params(state, self.cfg)
         pk = pack_all(P, self.cfg, parts=self.parts)
         for k, v in (extra or {}).items():          # test hook: ad-hoc packed tensors
@@ -253,6 +254,37 @@ class Runtime:
         self._rc(self.lib.dtts_vq_decode(self.h, codes.ctypes.data_as(_lib.c_int_p), nn.ctypes.data_as(_lib.c_int_p), nmax, _ptr(refer), rl[0], Tr, B,
                                          _ptr(mel), self._stream()))
         return mel
+
+    # ------------------------------------------------------------------ prompt front-end
+    def resample(self, wav, orig_freq, new_freq):
+        """torchaudio.transforms.Resample(orig, new)(wav) (api.py:39): wav cuda fp32 [B, L] -> [B, ceil(L*new/orig)]"""
+        _check(wav, "wav")
+        from .frontend import resample_kernel
+        B, L = wav.shape
+        if int(orig_freq) == int(new_freq):
+            return wav.clone()
+        key = (int(orig_freq), int(new_freq))
+        if key not in self._rs_kernels:
+            k, width, orig, new = resample_kernel(*key)
+            self._rs_kernels[key] = (torch.from_numpy(k).to(self.device), width, orig, new)
+        k, width, orig, new = self._rs_kernels[key]
+        Lout = -(-new * L // orig)
+        out = torch.empty((B, Lout), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_resample(self.h, _ptr(wav), B, L, _ptr(k), orig, new, width, _ptr(out), Lout, self._stream()))
+        return out
+
+    def mel_spectrogram(self, wav, lens=None):
+        """mel_spectrogram_torch(y, 1024, 128, 24000, 256, 1024, 0, None) (vqvae/utils/data_utils.py:105): wav cuda fp32 [B, L]
+        in [-1, 1] -> log-mel [B, 128, L // hop]; `lens` = valid samples per row (reflect padding at each row's own end)"""
+        _check(wav, "wav")
+        d = self.cfg["data"]
+        B, L = wav.shape
+        hop = d["hop_length"]
+        li = _ints(lens if lens is not None else [L] * B)
+        T = L // hop
+        out = torch.zeros((B, d["n_mel_channels"], T), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_mel_spectrogram(self.h, _ptr(wav), li[0], B, L, d["filter_length"], hop, _ptr(out), T, self._stream()))
+        return out
 
     # ------------------------------------------------------------------ unit ops
     def op_attention_block(self, prefix, x, lens=None):

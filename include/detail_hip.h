@@ -160,6 +160,18 @@ int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const
 int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
                    int B, float* mel_out, void* stream);
 
+/* ---- prompt front-end: api.py:34-45 --------------------------------------------------------- */
+/* torchaudio.transforms.Resample(orig, new)(wav) (api.py:39; torchaudio 2.x functional.resample, sinc_interp_hann).  `kernel` is the
+ * polyphase filter bank DEVICE [new][2*width + orig] built by the host (frequencies already divided by their gcd):
+ *   y[b][q*new + p] = sum_k kernel[p][k] * x[b][q*orig + k - width]   (zero outside the signal), y DEVICE [B][Lout] */
+int dtts_resample(dtts_handle* h, const float* x, int B, int L, const float* kernel, int orig, int neu, int width, float* y, int Lout,
+                  void* stream);
+/* mel_spectrogram_torch (vqvae/utils/data_utils.py:105-155): wav DEVICE [B][L] -> log-mel DEVICE [B, n_mels, Tmax], T_b = lens[b] / hop
+ * frames per row: reflect pad (n_fft - hop)/2, Hann-windowed DFT (one fp32 GEMM against the packed "frontend.dft" matrix),
+ * sqrt(re^2 + im^2 + 1e-6), mel filterbank GEMM ("frontend.mel"), log(clamp(., 1e-5)).  lens HOST (null -> L). */
+int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, int L, int n_fft, int hop, float* mel_out, int Tmax,
+                         void* stream);
+
 /* Runtime options:
  *   "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams;
  *   "conv_x3"     (default 1): diffusion-trunk convs and attention on the split-precision path (every fp32 operand as three

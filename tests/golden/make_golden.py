@@ -272,6 +272,20 @@ def main():
     save("vq_path", refer=refer, codes=vq_codes, latent=latent, g_vq=g_vq, recon=recon, wav=wav_vq, seed=np.array(SEED_N),
          sample_id=np.array(6))
 
+    # ---- 11. prompt front-end (api.py:40-45, vqvae/utils/data_utils.py:56-155): the reference's own STFT / magnitude / log
+    # arithmetic.  librosa is absent here, so the mel filterbank handed to the reference function is the oracle's restatement of
+    # librosa.filters.mel (parity for the filterbank values themselves stays unpinned); torchaudio's resampler is not exercised.
+    import vqvae.utils.data_utils as du
+    from oracle import frontend as FE
+    du.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: FE.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    tt = np.arange(13000) / 24000.0
+    yw = (0.3 * np.sin(2 * np.pi * (200 + 4000 * tt) * tt) + 0.1 * rs.randn(13000) * np.exp(-3 * tt) + 0.02 * rs.randn(13000)).astype(np.float32)
+    yw = np.stack([yw, np.roll(yw, 777) * 0.5]).astype(np.float32)
+    yw_t = torch.from_numpy(yw)
+    spec_lin = du.spectrogram_torch(yw_t, 1024, 256, 1024)
+    mel_ref = du.mel_spectrogram_torch(yw_t, 1024, 128, 24000, 256, 1024, 0.0, None)
+    save("frontend", wav=yw, spec=spec_lin, mel=mel_ref)
+
 
 if __name__ == "__main__":
     main()

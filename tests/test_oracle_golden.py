@@ -165,3 +165,43 @@ def test_vq_decode_path(weights, golden):
     ref = g["wav"][0, 0]
     assert wav.shape == ref.shape
     assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-3
+
+
+def test_frontend_mel_against_reference_function(golden):
+    """oracle.frontend.mel_spectrogram vs the reference's own mel_spectrogram_torch / spectrogram_torch (fixture `frontend`)."""
+    from oracle import frontend as FE
+    g = golden("frontend")
+    mel = FE.mel_spectrogram(g["wav"])
+    assert mel.shape == g["mel"].shape
+    assert maxabs(mel, g["mel"]) < 1e-4
+    # linear magnitude through the same filterbank == exp(log-mel) where the clamp is inactive
+    mb = FE.mel_filterbank(24000, 1024, 128)
+    lin = np.einsum("mf,bft->bmt", mb, g["spec"])
+    ok = lin > 1e-4
+    assert maxabs(np.log(lin[ok]), g["mel"][ok]) < 1e-4
+
+
+def test_frontend_filterbank_and_resampler_known_answers():
+    """librosa / torchaudio are absent: known answers of their published algorithms."""
+    from oracle import frontend as FE
+    # Slaney scale anchors (librosa.hz_to_mel docs): 1000 Hz -> 15 mel, 6400 Hz -> 42 mel; linear below 1 kHz at 200/3 Hz per mel
+    assert abs(float(FE._hz_to_mel_slaney(1000.0)) - 15.0) < 1e-9 and abs(float(FE._hz_to_mel_slaney(6400.0)) - 42.0) < 1e-9
+    assert abs(float(FE._hz_to_mel_slaney(500.0)) - 7.5) < 1e-9
+    mb = FE.mel_filterbank(24000, 1024, 128)
+    assert mb.shape == (128, 513) and mb.dtype == np.float32 and (mb >= 0).all()
+    # Slaney norm: each triangle integrates to 1 over frequency (bin width 24000/1024 Hz) up to discretisation
+    area = mb.sum(1) * (24000 / 1024)
+    assert np.all(np.abs(area[4:] - 1.0) < 0.12), (area.min(), area.max())
+    peaks = mb.argmax(1)
+    assert np.all(np.diff(peaks) >= 0) and peaks[0] >= 1 and peaks[-1] <= 511
+    # resampler: output length, unity DC gain away from the edges, a 440 Hz tone survives 44.1 -> 24 kHz with the right phase
+    k, width, orig, new = FE.resample_kernel(44100, 24000)
+    assert (orig, new, width) == (147, 80, 12) and k.shape == (80, 171)
+    x = np.ones((1, 44100), np.float32)
+    y = FE.resample(x, 44100, 24000)
+    assert y.shape == (1, 24000) and np.abs(y[0, 100:-100] - 1.0).max() < 2e-3
+    t = np.arange(44100) / 44100.0
+    y = FE.resample(np.sin(2 * np.pi * 440 * t)[None].astype(np.float32), 44100, 24000)[0]
+    ref = np.sin(2 * np.pi * 440 * np.arange(24000) / 24000.0)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 1e-3
+    assert FE.resample(x[:, :1000], 24000, 24000).shape == (1, 1000)

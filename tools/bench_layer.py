@@ -27,3 +27,16 @@ for st in rt.profile_report():
     tot += st["total_ms"] / 20 * 1e3
     print(f"{st['name']:34s} {st['launches'] // 20:2d}/layer {us:8.1f} us  {st['flops'] / max(st['total_ms'], 1e-9) / 1e9:7.1f} TFLOP/s(eq)  {st['bytes'] / max(st['total_ms'], 1e-9) / 1e9:7.2f} TB/s(alg)")
 print(f"profiled kernels per layer: {tot:.1f} us   (B={B}, T={T})")
+
+# launch gaps: wall time of the same sequence without the profiler's events vs the sum of the kernel durations above
+rt.profile_enable(False)
+for _ in range(3):
+    layer()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50):
+    layer()
+e1.record()
+torch.cuda.synchronize()
+print(f"wall per layer without profiling: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
