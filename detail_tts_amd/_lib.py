@@ -46,6 +46,7 @@ SIGNATURES = {
     "dtts_last_error": (C.c_char_p, [C.c_void_p]),
     "dtts_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), c_u64_p, c_u64_p, C.c_int, C.c_void_p]),
     "dtts_vq_decode": (C.c_int, [C.c_void_p, c_int_p, c_int_p, C.c_int, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dtts_vq_encode": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dtts_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

@@ -52,6 +52,12 @@ int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax
     DTTS_API_END(h)
 }
 
+int dtts_vq_encode(dtts_handle* h, const float* mel, const int* lens, int B, int T, int* codes, float* x_vq, void* stream) {
+    DTTS_API_BEGIN
+    h->m->vq_encode(mel, lens, B, T, codes, x_vq, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_resample(dtts_handle* h, const float* x, int B, int L, const float* kernel, int orig, int neu, int width, float* y, int Lout,
                   void* stream) {
     DTTS_API_BEGIN

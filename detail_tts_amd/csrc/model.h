@@ -127,6 +127,8 @@ public:
     // ---- prompt front-end
     void resample(const float* x, int B, int L, const float* kernel, int orig, int neu, int width, float* y, int Lout, hipStream_t s);
     void mel_spectrogram(const float* wav, const int* lens_host, int B, int L, int n_fft, int hop, float* mel_out, int Tmax, hipStream_t s);
+    // SynthesizerTrn.encode: mel [B,128,T] -> codes DEVICE int32 [B][nmax] (nmax = ceil(ceil(T/2)/2)), optional x_vq [B,768,nmax]
+    void vq_encode(const float* mel, const int* lens_host, int B, int T, int* codes_out, float* xvq_out, hipStream_t s);
     // ---- unit ops used by the parity tests
     void op_attention_block(const char* prefix, const float* x, const int* lens_host, int B, int C, int T, float* y, hipStream_t s);
     void op_resblock(const char* prefix, const float* x, const int* lens_host, int B, int T, int step, float* y, hipStream_t s);
@@ -223,6 +225,9 @@ private:
     MelStyleW vq_ref_enc_;
     PackedConv vq_up1_, vq_up2_, vq_out_;
     const float *vq_table_ = nullptr, *vq_ln_g_ = nullptr, *vq_ln_b_ = nullptr;
+    bool has_vq_enc_ = false;
+    PackedConv vqe_c1_, vqe_c2_, vqe_c3_, vq_proj_in_;
+    const float *vqe_ln_g_ = nullptr, *vqe_ln_b_ = nullptr, *vq_embed_ = nullptr, *vq_embed_sq_ = nullptr;
 
     Arena ws_;        // per-call activations
     Arena persist_;   // tables built at bind time

@@ -449,6 +449,106 @@ void Model::build_vq() {
     vq_up2_ = conv("vq_dec.5", 2 * inter, 2 * inter, 2);
     vq_out_ = conv("vq_dec.7", inter, cfg.mel_channels, 3);
     vq_ref_enc_ = mel_style_w("vq_ref_enc", cfg.mel_channels, 128, C);
+    has_vq_enc_ = weights_.count("vq_enc.3.wp") != 0;
+    if (has_vq_enc_) {
+        vqe_ln_g_ = W("vq_enc.1.weight", cfg.mel_channels);
+        vqe_ln_b_ = W("vq_enc.1.bias", cfg.mel_channels);
+        vqe_c1_ = conv("vq_enc.3", cfg.mel_channels, 2 * inter, 3);
+        vqe_c2_ = conv("vq_enc.5", 2 * inter, C, 3);
+        vqe_c3_ = conv("vq_enc.7", C, C, 3);
+        vq_proj_in_ = conv("quantizer.project_in", C, 8, 1);
+        vq_embed_ = W("quantizer.embed", (size_t)8192 * 8);
+        vq_embed_sq_ = W("quantizer.embed_sq", 8192);
+    }
+}
+
+// EuclideanCodebook.quantize (vqvae/modules/core_vq.py:175-183): argmax of -(x^2 - 2 x.e + e^2) == first argmin of the distance.
+// One workgroup per (frame, sample): thread i scans codes i, i+256, ...; ties resolve to the lowest index (torch's max on CPU).
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ x8, long long x_bs, int x_cs, const int* __restrict__ lens,
+                                                         const float* __restrict__ embed, const float* __restrict__ embed_sq, int bins,
+                                                         int* __restrict__ codes, int code_stride) {
+    __shared__ float sd[256];
+    __shared__ int si[256];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (t >= lens[b]) return;
+    float x[8], xx = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        x[c] = x8[(long long)b * x_bs + (long long)c * x_cs + t];
+        xx += x[c] * x[c];
+    }
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < bins; k += 256) {
+        const float* e = embed + (long long)k * 8;
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dot += x[c] * e[c];
+        const float d = xx - 2.f * dot + embed_sq[k];
+        if (d < best) { best = d; bi = k; }
+    }
+    sd[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float d2 = sd[tid + o];
+            const int i2 = si[tid + o];
+            if (d2 < sd[tid] || (d2 == sd[tid] && i2 < si[tid])) { sd[tid] = d2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) codes[(long long)b * code_stride + t] = si[0];
+}
+
+// SynthesizerTrn.encode (vqvae/model_24k.py:877-880): codes = quantizer(vq_enc(y), layers=[0]).codes[0]; x_vq = vq_enc(y)
+void Model::vq_encode(const float* mel, const int* lens_host, int B, int T, int* codes_out, float* xvq_out, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vq_ && has_vq_enc_, "vq encoder weights not bound");
+    const int inter = cfg.inter_channels, C = 4 * inter, MC = cfg.mel_channels;
+    const int T1 = (T + 1) / 2, T2 = (T1 + 1) / 2;               // conv k3 s2 p1: ceil(T/2)
+    std::vector<int> l0(B), l1(B), l2(B);
+    for (int b = 0; b < B; ++b) {
+        l0[b] = lens_host ? lens_host[b] : T;
+        DTTS_REQUIRE(l0[b] >= 1 && l0[b] <= T, "mel length");
+        l1[b] = (l0[b] + 1) / 2;
+        l2[b] = (l1[b] + 1) / 2;
+    }
+    ws_.ensure(sizeof(float) * ((size_t)B * MC * T + (size_t)B * 2 * inter * T1 + (size_t)2 * B * C * T2 + (size_t)B * 32 * T2) + 65536);
+    float* ln = ws_.f32((size_t)B * MC * T);
+    float* h1 = ws_.f32((size_t)B * 2 * inter * T1);
+    float* h2 = ws_.f32((size_t)B * C * T2);
+    float* xv = xvq_out ? xvq_out : ws_.f32((size_t)B * C * T2);
+    float* x8 = ws_.f32((size_t)B * 32 * T2);
+    const int* d0 = upload_ints(l0.data(), B, s);
+    const int* d1 = upload_ints(l1.data(), B, s);
+    const int* d2 = upload_ints(l2.data(), B, s);
+    launch_ln_channels(mel, nullptr, (long long)MC * T, T, d0, T, B, MC, vqe_ln_g_, vqe_ln_b_, 1e-5f, ln, (long long)MC * T, T, s);
+    ConvParams p = cp(ln, MC, h1, 2 * inter, B, T, T, d0);
+    p.stride = 2;
+    p.pad = 1;
+    p.Nout = T1;
+    p.len_out = d1;
+    p.y_bs = (long long)2 * inter * T1;
+    p.y_cs = T1;
+    p.epi_act = ACT_SILU;
+    run_conv(vqe_c1_, p, s);
+    p = cp(h1, 2 * inter, h2, C, B, T1, T1, d1);
+    p.stride = 2;
+    p.pad = 1;
+    p.Nout = T2;
+    p.len_out = d2;
+    p.y_bs = (long long)C * T2;
+    p.y_cs = T2;
+    p.epi_act = ACT_SILU;
+    run_conv(vqe_c2_, p, s);
+    p = cp(h2, C, xv, C, B, T2, T2, d2);
+    p.pad = 1;
+    run_conv(vqe_c3_, p, s);
+    p = cp(xv, C, x8, 8, B, T2, T2, d2);
+    p.y_bs = (long long)32 * T2;
+    run_conv(vq_proj_in_, p, s);
+    hipLaunchKernelGGL(vq_nearest_kernel, dim3(T2, B), dim3(256), 0, s, x8, (long long)32 * T2, T2, d2, vq_embed_, vq_embed_sq_, 8192, codes_out, T2);
+    DTTS_CHECK_HIP(hipGetLastError());
 }
 
 // infer_gpt's decode: recon = vq_dec(quantizer.decode(codes) + vq_ref_enc(refer * mask, mask))   (vqvae/model_24k.py:828-845)

@@ -278,6 +278,16 @@ def pack_vq(pk, P, cfg):
         pk.conv(f"vq_dec.{i}", weq, np.tile(P[f"vq_dec.{i}.bias"], 2))
     pk.conv("vq_dec.7", P["vq_dec.7.weight"], P["vq_dec.7.bias"])
     _mel_style(pk, P, "vq_ref_enc")
+    # encode side (vqvae/model_24k.py:877-880): vq_enc, project_in, and the codebook with its squared norms for the nearest search
+    if "vq_enc.3.weight" in P:
+        pk.add("vq_enc.1.weight", P["vq_enc.1.weight"])
+        pk.add("vq_enc.1.bias", P["vq_enc.1.bias"])
+        for i in (3, 5, 7):
+            pk.conv(f"vq_enc.{i}", P[f"vq_enc.{i}.weight"], P[f"vq_enc.{i}.bias"])
+        pk.conv("quantizer.project_in", P["quantizer.vq.layers.0.project_in.weight"][:, :, None], P["quantizer.vq.layers.0.project_in.bias"])
+        e = P["quantizer.vq.layers.0._codebook.embed"].astype(F32)
+        pk.add("quantizer.embed", e)
+        pk.add("quantizer.embed_sq", np.square(e).sum(1, dtype=F32))          # embed.pow(2).sum(0) of core_vq.py:180, fp32 like torch
 
 
 def pack_all(P, cfg=None, parts=("diffusion",)):

@@ -255,6 +255,17 @@ class Runtime:
                                          _ptr(mel), self._stream()))
         return mel
 
+    def vq_encode(self, mel, lens=None):
+        """SynthesizerTrn.encode: mel cuda [B,128,T] -> (codes cuda int32 [B, n], x_vq cuda [B,768,n]), n = ceil(ceil(T/2)/2)"""
+        _check(mel, "mel")
+        B, _, T = mel.shape
+        n = ((T + 1) // 2 + 1) // 2
+        codes = torch.zeros((B, n), device=self.device, dtype=torch.int32)
+        xvq = torch.zeros((B, 4 * self.cfg["vaegan"]["inter_channels"], n), device=self.device, dtype=torch.float32)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_vq_encode(self.h, _ptr(mel), li[0] if li else None, B, T, C.c_void_p(codes.data_ptr()), _ptr(xvq), self._stream()))
+        return codes, xvq
+
     # ------------------------------------------------------------------ prompt front-end (SURVEY §8f row 1)
     def resample(self, wav, orig_freq, new_freq):
         """torchaudio.transforms.Resample(orig, new)(wav) (api.py:39): wav cuda fp32 [B, L] -> [B, ceil(L*new/orig)]"""

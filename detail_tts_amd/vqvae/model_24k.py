@@ -163,6 +163,22 @@ class SynthesizerTrn:
         lens_t = [4 * len(c) for c in code_list]
         return self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
 
+    def encode(self, y, y_lengths=None):
+        """vqvae/model_24k.py:877-880 -> (codes [B, T/4] int64, x_vq [B,768,T/4])"""
+        y = torch.as_tensor(y).to(self.device, torch.float32).contiguous()
+        lens = None if y_lengths is None else [int(v) for v in torch.as_tensor(y_lengths).reshape(-1).tolist()]
+        codes, xvq = self.rt.vq_encode(y, lens)
+        return codes.long(), xvq
+
+    def infer_vqvae(self, y, noise_scale=NOISE_SCALE, *, seed=0, sample_ids=None):
+        """vqvae/model_24k.py:864-876: mel -> codes -> quantised latent + vq_ref_enc -> vq_dec -> (recon, wav); first row only"""
+        y = torch.as_tensor(y)[:1].to(self.device, torch.float32).contiguous()
+        assert y.shape[-1] % 4 == 0
+        codes, _ = self.rt.vq_encode(y)
+        recon = self.rt.vq_decode([codes[0].cpu().numpy()], y, [y.shape[-1]])
+        sample_ids = [0] if sample_ids is None else list(sample_ids)
+        return recon, self.rt.vocoder(recon, seed, sample_ids, lens=[y.shape[-1]], noise_scale=noise_scale)
+
     def infer_flowvae(self, y, y_lengths, data=None, noise_scale=NOISE_SCALE, *, batch=False, seed=0, sample_ids=None):
         """vqvae/model_24k.py:848-863"""
         y = torch.as_tensor(y)

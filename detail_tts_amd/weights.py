@@ -229,6 +229,16 @@ def inference_param_spec(cfg=None) -> "OrderedDict[str, tuple]":
     spec["quantizer.vq.layers.0._codebook.embed"] = ((v["vq_bins"], 8), K_UNCOND)
     spec["quantizer.vq.layers.0.project_out.weight"] = ((4 * inter, 8), K_W)
     spec["quantizer.vq.layers.0.project_out.bias"] = ((4 * inter,), K_B)
+    spec["quantizer.vq.layers.0.project_in.weight"] = ((8, 4 * inter), K_W)
+    spec["quantizer.vq.layers.0.project_in.bias"] = ((8,), K_B)
+    spec["vq_enc.1.weight"] = ((n_mel,), K_NG)
+    spec["vq_enc.1.bias"] = ((n_mel,), K_NB)
+    spec["vq_enc.3.weight"] = ((2 * inter, n_mel, 3), K_W)
+    spec["vq_enc.3.bias"] = ((2 * inter,), K_B)
+    spec["vq_enc.5.weight"] = ((4 * inter, 2 * inter, 3), K_W)
+    spec["vq_enc.5.bias"] = ((4 * inter,), K_B)
+    spec["vq_enc.7.weight"] = ((4 * inter, 4 * inter, 3), K_W)
+    spec["vq_enc.7.bias"] = ((4 * inter,), K_B)
     spec["vq_dec.1.weight"] = ((4 * inter,), K_NG)
     spec["vq_dec.1.bias"] = ((4 * inter,), K_NB)
     spec["vq_dec.3.weight"] = ((4 * inter, 2 * inter, 3), K_W)            # ConvTranspose1d [in, out, k]

@@ -160,6 +160,11 @@ int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const
 int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
                    int B, float* mel_out, void* stream);
 
+/* SynthesizerTrn.encode (vqvae/model_24k.py:877-880): codes = quantizer(vq_enc(mel), layers=[0]).codes[0], x_vq = vq_enc(mel).
+ * mel DEVICE [B,128,T], lens HOST (null -> T) -> codes DEVICE int32 [B][n], n = ceil(ceil(T/2)/2) (entries beyond a row's own
+ * length are left untouched); x_vq DEVICE [B,768,n] or null. */
+int dtts_vq_encode(dtts_handle* h, const float* mel, const int* lens, int B, int T, int* codes, float* x_vq, void* stream);
+
 /* ---- prompt front-end: api.py:34-45 --------------------------------------------------------- */
 /* torchaudio.transforms.Resample(orig, new)(wav) (api.py:39; torchaudio 2.x functional.resample, sinc_interp_hann).  `kernel` is the
  * polyphase filter bank DEVICE [new][2*width + orig] built by the host (frequencies already divided by their gcd):

@@ -49,3 +49,28 @@ def infer_gpt_from_codes(P, codes, refer, seed, sample_id, noise_scale=0.667):
     """One utterance: codes [n] (without stop), refer [128,T_ref] -> wav."""
     mel = vq_decode_mel(P, np.asarray(codes)[None], np.asarray(refer, F32)[None], [refer.shape[1]])
     return V.infer_flowvae(P, mel, [mel.shape[2]], seed, [sample_id], noise_scale)[0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------- encode side
+def vq_enc(P, y):
+    """nn.Sequential vq_enc, vqvae/model_24k.py:606-615: LN(mel ch) -> conv k3 s2 -> SiLU -> conv k3 s2 -> SiLU -> conv k3."""
+    h = ops.layer_norm_channels(y, P["vq_enc.1.weight"], P["vq_enc.1.bias"])
+    h = ops.silu(ops.conv1d(h, P["vq_enc.3.weight"], P["vq_enc.3.bias"], stride=2, padding=1))
+    h = ops.silu(ops.conv1d(h, P["vq_enc.5.weight"], P["vq_enc.5.bias"], stride=2, padding=1))
+    return ops.conv1d(h, P["vq_enc.7.weight"], P["vq_enc.7.bias"], padding=1)
+
+
+def quantize_distances(P, x_vq):
+    """x_vq [B,768,n] -> (x8 [B,n,8], d [B,n,bins]) with d = x^2 - 2 x.e + e^2 in fp32 (core_vq.py:175-183 up to the sign)."""
+    x = ops.linear(np.ascontiguousarray(x_vq.transpose(0, 2, 1)), P["quantizer.vq.layers.0.project_in.weight"],
+                   P["quantizer.vq.layers.0.project_in.bias"])
+    e = P["quantizer.vq.layers.0._codebook.embed"].astype(F32)
+    d = (np.square(x).sum(-1, keepdims=True, dtype=F32) - F32(2) * (x @ e.T) + np.square(e).sum(1, dtype=F32)[None, None, :]).astype(F32)
+    return x, d
+
+
+def encode(P, y):
+    """SynthesizerTrn.encode (vqvae/model_24k.py:877-880): y [B,128,T] -> (codes [B, T/4] int64, x_vq [B,768,T/4])."""
+    x_vq = vq_enc(P, np.asarray(y, F32))
+    _, d = quantize_distances(P, x_vq)
+    return d.argmin(-1).astype(np.int64), x_vq

@@ -76,6 +76,8 @@ def build_reference_model():
                "gpt.inference_model.", "gpt.gpt.wte.")
     bad = [k for k in res.missing_keys if not k.startswith(allowed)]
     assert not bad, bad
+    # a trained checkpoint carries `inited` = 1; without it the first quantizer forward would k-means re-initialise the codebook
+    model.quantizer.vq.layers[0]._codebook.inited.fill_(1.0)
     return model
 
 
@@ -271,6 +273,9 @@ def main():
     g.inference_speech_tortoise = orig
     save("vq_path", refer=refer, codes=vq_codes, latent=latent, g_vq=g_vq, recon=recon, wav=wav_vq, seed=np.array(SEED_N),
          sample_id=np.array(6))
+    # encode side (vqvae/model_24k.py:877-880)
+    enc_codes, enc_xvq = m.encode(refer_t, rl)
+    save("vq_encode", mel=refer, codes=enc_codes, x_vq=enc_xvq)
 
     # ---- 11. prompt front-end (api.py:40-45, vqvae/utils/data_utils.py:56-155): the reference's own STFT / magnitude / log
     # arithmetic.  librosa is absent here, so the mel filterbank handed to the reference function is the oracle's restatement of

@@ -125,3 +125,54 @@ def test_vq_decode_rejects_out_of_codebook(rt_vq):
     from detail_tts_amd.runtime import DttsError
     with pytest.raises(DttsError):
         rt_vq.vq_decode([np.array([5, 8192])], torch.zeros(1, 128, 20, device="cuda"))      # start/stop tokens are not codebook rows
+
+
+def test_vq_encode_golden_and_diverse_codebook(weights, golden):
+    """encode: the reference fixture (seed-0 weights send every frame to one code), then a codebook re-centred on the projected
+    frames so that the nearest-entry search is exercised with many different winners (bit-exact indices vs the oracle)."""
+    from detail_tts_amd.runtime import Runtime
+    from oracle import vq
+    g = golden("vq_encode")
+    r = Runtime(weights, folded=True, parts=("vocoder", "vq"))
+    codes, xvq = r.vq_encode(dev(g["mel"]))
+    assert maxabs(host(xvq), g["x_vq"]) < 1e-4
+    assert np.array_equal(host(codes).astype(np.int64), g["codes"])
+
+    rs = np.random.RandomState(31)
+    mel = (rs.randn(2, 128, 120) * 2 - 5).astype(np.float32)
+    lens = [120, 90]
+    P = dict(weights)
+    x8, _ = vq.quantize_distances(P, vq.vq_enc(P, mel))
+    emb = P["quantizer.vq.layers.0._codebook.embed"].copy()
+    pts = x8.reshape(-1, 8)
+    emb[:] = pts[rs.randint(0, len(pts), len(emb))] + rs.randn(*emb.shape).astype(np.float32) * float(pts.std()) * 0.5
+    P["quantizer.vq.layers.0._codebook.embed"] = emb
+    r2 = Runtime(P, folded=True, parts=("vocoder", "vq"))
+    codes, xvq = r2.vq_encode(dev(mel), lens)
+    codes = host(codes)
+    for b, L in enumerate(lens):
+        ref_codes, ref_x = vq.encode(P, mel[b:b + 1, :, :L])
+        n = ref_codes.shape[1]
+        assert n == (L + 3) // 4
+        assert maxabs(host(xvq)[b, :, :n], ref_x[0]) < 1e-4
+        same = codes[b, :n] == ref_codes[0]
+        if not same.all():          # a flipped index is only acceptable on an fp32-level tie of the two distances
+            _, d = vq.quantize_distances(P, ref_x)
+            for t in np.nonzero(~same)[0]:
+                assert abs(d[0, t, codes[b, t]] - d[0, t, ref_codes[0, t]]) < 1e-5 * max(1.0, abs(d[0, t, ref_codes[0, t]]))
+        assert len(np.unique(ref_codes)) > 8
+
+
+def test_infer_vqvae_roundtrip_surface(weights):
+    from detail_tts_amd.vqvae.model_24k import SynthesizerTrn
+    from oracle import vq
+    m = SynthesizerTrn(weights, folded=True)
+    rs = np.random.RandomState(32)
+    mel = (rs.randn(1, 128, 40) * 2 - 5).astype(np.float32)
+    codes, x_vq = m.encode(torch.from_numpy(mel), torch.tensor([40]))
+    ref_codes, _ = vq.encode(weights, mel)
+    assert codes.dtype == torch.int64 and np.array_equal(codes.cpu().numpy(), ref_codes)
+    recon, wav = m.infer_vqvae(torch.from_numpy(mel), seed=3, sample_ids=[9])
+    ref_mel = vq.vq_decode_mel(weights, ref_codes, mel, [40])
+    assert maxabs(recon.cpu().numpy(), ref_mel) < 2e-4
+    assert tuple(wav.shape) == (1, 1, 40 * 256) and bool(torch.isfinite(wav).all())

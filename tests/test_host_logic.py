@@ -34,8 +34,8 @@ def test_weight_spec_counts():
     from detail_tts_amd.weights import folded_param_names, inference_param_spec
     spec = inference_param_spec()
     n = sum(int(np.prod(s)) for s, _ in spec.values())
-    assert abs(n - 268.136e6) < 1e4           # 266.35 M for infer + 1.78 M for infer_gpt's VQ decode path
-    n_vq = sum(int(np.prod(s)) for k, (s, _) in spec.items() if k.startswith(("quantizer.", "vq_dec.", "vq_ref_enc.")))
+    assert abs(n - 270.946e6) < 1e4           # 266.35 M for infer + 4.59 M for the VQ decode / encode paths
+    n_vq = sum(int(np.prod(s)) for k, (s, _) in spec.items() if k.startswith(("quantizer.", "vq_dec.", "vq_enc.", "vq_ref_enc.")))
     assert abs(n - n_vq - 266.355e6) < 1e4
     assert len(folded_param_names()) == len(spec) - sum(k.endswith(".weight_v") for k in spec)
 

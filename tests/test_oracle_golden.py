@@ -205,3 +205,12 @@ def test_frontend_filterbank_and_resampler_known_answers():
     ref = np.sin(2 * np.pi * 440 * np.arange(24000) / 24000.0)
     assert np.abs(y[200:-200] - ref[200:-200]).max() < 1e-3
     assert FE.resample(x[:, :1000], 24000, 24000).shape == (1, 1000)
+
+
+def test_vq_encode_path(weights, golden):
+    """SynthesizerTrn.encode (vqvae/model_24k.py:877-880): vq_enc + nearest codebook entry, vs the reference fixture."""
+    from oracle import vq
+    g = golden("vq_encode")
+    codes, x_vq = vq.encode(weights, g["mel"])
+    assert maxabs(x_vq, g["x_vq"]) < 1e-5
+    assert np.array_equal(codes, g["codes"])
