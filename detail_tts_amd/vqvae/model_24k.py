@@ -51,6 +51,35 @@ class Generator:
 
     __call__ = forward
 
+    HALO = 16      # frames of context on each side: the generator's receptive field is 13.2 frames
+
+    def stream(self, x, g, chunk=64):
+        """Chunked synthesis for long utterances: yields wav pieces [B,1,256*n] whose concatenation equals
+        forward(x, g) to fp32 rounding.  The generator is purely convolutional, so every chunk is computed inside a window with
+        a 16-frame halo and only its interior is emitted; peak memory is one window instead of the whole utterance."""
+        x = x.float().contiguous()
+        g2 = g.reshape(g.shape[0], -1).float().contiguous()
+        T, H = x.shape[-1], self.HALO
+        for t0 in range(0, T, chunk):
+            t1 = min(T, t0 + chunk)
+            a, b = max(0, t0 - H), min(T, t1 + H)
+            w = self.rt.generator(x[:, :, a:b].contiguous(), g2)
+            yield w[:, :, (t0 - a) * 256:(t1 - a) * 256]
+
+
+def write_wav(path, wav, sample_rate=24000):
+    """torchaudio.save(path, wav, 24000) of api.py:50 without torchaudio: mono / [C, S] float tensor in [-1, 1] -> 16-bit PCM."""
+    import wave
+    w = torch.as_tensor(wav).detach().float().cpu()
+    if w.dim() == 1:
+        w = w[None]
+    pcm = (w.clamp(-1.0, 1.0) * 32767.0).round().to(torch.int16).t().contiguous().numpy()
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(w.shape[0])
+        f.setsampwidth(2)
+        f.setframerate(int(sample_rate))
+        f.writeframes(pcm.tobytes())
+
 
 class SynthesizerTrn:
     def __init__(self, state, cfg=None, device="cuda:0", folded=False):

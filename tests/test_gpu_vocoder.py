@@ -176,3 +176,24 @@ def test_infer_vqvae_roundtrip_surface(weights):
     ref_mel = vq.vq_decode_mel(weights, ref_codes, mel, [40])
     assert maxabs(recon.cpu().numpy(), ref_mel) < 2e-4
     assert tuple(wav.shape) == (1, 1, 40 * 256) and bool(torch.isfinite(wav).all())
+
+
+def test_generator_stream_equals_full_and_wav_writer(weights, tmp_path):
+    """chunked generator with halo == one-shot generator; the WAV writer round-trips through the stdlib reader."""
+    import wave
+    from detail_tts_amd.vqvae.model_24k import SynthesizerTrn, write_wav
+    m = SynthesizerTrn(weights, folded=True)
+    rs = np.random.RandomState(41)
+    z = torch.from_numpy(rs.randn(1, 192, 150).astype(np.float32)).cuda()
+    g = torch.from_numpy((rs.randn(1, 768, 1) * 0.1).astype(np.float32)).cuda()
+    full = m.dec(z, g=g)
+    parts = list(m.dec.stream(z, g, chunk=48))
+    assert [p.shape[-1] for p in parts] == [48 * 256, 48 * 256, 48 * 256, 6 * 256]
+    cat = torch.cat(parts, -1)
+    assert cat.shape == full.shape and float((cat - full).abs().max()) < 1e-5
+    path = tmp_path / "gen.wav"
+    write_wav(path, full[0], 24000)
+    with wave.open(str(path), "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 24000, 150 * 256)
+        pcm = np.frombuffer(f.readframes(f.getnframes()), np.int16)
+    assert np.abs(pcm / 32767.0 - full[0, 0].clamp(-1, 1).cpu().numpy()).max() < 1.0 / 32767 + 1e-6
