@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
         w_piece(wave * 3 + i, 0, 0, 0);
         x_piece(wave * 3 + i, 0, 0);
     }
+    // the tile's 128 bias values -> LDS (read back in the epilogue; the first K-step barrier orders the write)
+    float* bias_s = reinterpret_cast<float*>(smem + XOFF + 2 * XBUF);
+    if (tid < BM) bias_s[tid] = (p.bias && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.f;
     if (KW3 && wave == 0) x_halo(0, 0);
 
     int c16 = 0, tap = 0;                               // the step being computed
@@ -271,16 +274,13 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
 
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // bias of this lane's 32 output rows: all loads before the first store (one exposed latency per workgroup, no registers
-    // held across the K loop - a third workgroup per CU is worth more)
+    // bias of this lane's 32 output rows from the LDS copy made at kernel start: no global latency here, no registers held
+    // across the K loop
     float bv[2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            bv[i][r] = p.bias ? p.bias[row < p.Cout ? row : p.Cout - 1] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) bv[i][r] = bias_s[wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
     float* yb = p.y + (long long)b * p.y_bs;
     const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
     // The residual usually IS the output buffer (in-place x += f(x)): the compiler must keep every residual load behind the
@@ -364,7 +364,7 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
     static bool attr = false;
-    constexpr size_t lds = (size_t)2 * TILE + 2 * (TILE + 6 * 2 * 16);
+    constexpr size_t lds = (size_t)2 * TILE + 2 * (TILE + 6 * 2 * 16) + BM * sizeof(float);
     if (!attr) {
         DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
