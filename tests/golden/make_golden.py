@@ -277,6 +277,16 @@ def main():
     enc_codes, enc_xvq = m.encode(refer_t, rl)
     save("vq_encode", mel=refer, codes=enc_codes, x_vq=enc_xvq)
 
+    # ---- 12 (host). text front-end: the reference tokenizer on its own vocabulary (bpe_tokenizers/voice_tokenizer.py:31-54); the
+    # pinyin sentence is the one pinned in demo.ipynb (api.py:14 through pypinyin)
+    from bpe_tokenizers.voice_tokenizer import VoiceBpeTokenizer as RefTok
+    tok = RefTok(os.path.join(REF, "bpe_tokenizers/zh_tokenizer.json"))
+    kat_texts = [" da4 jia1 hao3 \uff0c jin1 tian1 lai2 dian3 da4 jia1 xiang3 kan4 de5 dong1 xi1 \u3002 ",
+                 " ni3 hao3 {shi4 jie4} [ce4 shi4] \u2014 yi1 er4 san1 ! ", "hello world, this is a test."]
+    with open(os.path.join(HERE, "tokenizer_kat.json"), "w") as fh:
+        json.dump([{"text": t, "ids": tok.encode(t), "decoded": tok.decode(np.array(tok.encode(t)))} for t in kat_texts], fh, indent=1)
+    print("tokenizer_kat:", [len(tok.encode(t)) for t in kat_texts])
+
     # ---- 11. prompt front-end (api.py:40-45, vqvae/utils/data_utils.py:56-155): the reference's own STFT / magnitude / log
     # arithmetic.  librosa is absent here, so the mel filterbank handed to the reference function is the oracle's restatement of
     # librosa.filters.mel (parity for the filterbank values themselves stays unpinned); torchaudio's resampler is not exercised.

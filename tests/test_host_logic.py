@@ -222,3 +222,21 @@ def test_two_rank_gloo_weight_broadcast_and_sharding():
     assert all(abs(r[1] - 499500.0) < 1e-3 for r in res)                 # both ranks hold rank 0's blob
     assert sorted(res[0][2] + res[1][2]) == list(range(6))                 # disjoint cover of the utterances
     assert res[0][3] == res[1][3] and len(sum(res[0][3], [])) == 6         # no data-path collective needed beyond this
+
+
+def test_voice_bpe_tokenizer_known_answers():
+    """Text front-end mirror vs ids produced by the reference tokenizer (tests/golden/tokenizer_kat.json; the first sentence is the
+    demo.ipynb KAT: 38 ids).  Needs the reference's vocabulary file, which only exists in the build container."""
+    import json
+    import os
+    vocab = "/root/reference/bpe_tokenizers/zh_tokenizer.json"
+    if not os.path.exists(vocab):
+        pytest.skip("reference vocabulary file not available on this machine")
+    from detail_tts_amd.bpe_tokenizers.voice_tokenizer import VoiceBpeTokenizer, remove_extraneous_punctuation
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_kat.json")))
+    tok = VoiceBpeTokenizer(vocab)
+    assert len(kat[0]["ids"]) == 38
+    for case in kat:
+        assert tok.encode(case["text"]) == case["ids"]
+        assert tok.decode(np.array(case["ids"])) == case["decoded"]
+    assert remove_extraneous_punctuation("{a}[b]`c—d") == "(a)(b)'c-d" and remove_extraneous_punctuation("@") == ""
