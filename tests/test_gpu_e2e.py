@@ -112,3 +112,23 @@ def test_infer_gpt_free_sampling_vs_oracle(model, weights):
     ref = vq.infer_gpt_from_codes(weights, codes[0, :-1], refer[0], 99, 12)
     assert wav.shape[2] == ref.shape[0]
     assert rms(wav[0, 0], ref) < 1e-3
+
+
+def test_wav_in_wav_out_example(tmp_path):
+    """examples/api.py: the reference's api.py flow end to end (wav file -> resample -> mel -> infer -> wav file) on the device."""
+    import subprocess
+    import sys
+    import wave
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    src = tmp_path / "prompt.wav"
+    rs = np.random.RandomState(8)
+    t = np.arange(2 * 44100) / 44100.0
+    pcm = ((0.3 * np.sin(2 * np.pi * 330 * t) + 0.02 * rs.randn(t.size)) * 32767).astype(np.int16)
+    with wave.open(str(src), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(44100); f.writeframes(pcm.tobytes())
+    out = tmp_path / "gen.wav"
+    r = subprocess.run([sys.executable, __import__("os").path.join(root, "examples", "api.py"), "--synthetic", "--wav", str(src), "--out", str(out),
+                        "--max-generate-length", "6"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with wave.open(str(out), "rb") as f:
+        assert f.getframerate() == 24000 and f.getnframes() == 5 * 1024           # 6 tokens incl. the last one dropped -> 5 codes
