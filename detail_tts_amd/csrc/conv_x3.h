@@ -27,7 +27,7 @@ void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* 
 // launch_gn_coeffs (ops.h)
 void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
                             const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs, int act,
-                            void* out, hipStream_t s);
+                            void* out, hipStream_t s, const int* ada_idx = nullptr);
 // uses p.w3 / p.x3 / p.x3_tp (+ the epilogue fields of ConvParams); stride 1, dilation 1, pad <= X3_HALO, no gate / phases / badd
 void launch_conv_x3(const ConvParams& p, hipStream_t s);
 

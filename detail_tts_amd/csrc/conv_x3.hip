@@ -67,7 +67,7 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
                                                               const int* __restrict__ lens, int T, int C, int groups,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                               const float* __restrict__ ada, int ada_stride, int ada_bs, int Tp,
-                                                              uint4* __restrict__ out) {
+                                                              uint4* __restrict__ out, const int* __restrict__ ada_idx) {
     __shared__ float red[2][16];
     __shared__ float sa[64], sd[64];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
         float a = rstd * gamma[c];
         float d = beta[c] - mean * a;
         if (ada) {
-            const float* ad = ada + (long long)b * ada_bs;
+            const float* ad = ada + (ada_idx ? (long long)ada_idx[b] : (long long)b * ada_bs);
             const float sc = 1.f + ad[(long long)c * ada_stride], sh = ad[(long long)(C + c) * ada_stride];
             a *= sc;
             d = d * sc + sh;
@@ -339,7 +339,7 @@ void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* 
 
 void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
                             const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs, int act,
-                            void* out, hipStream_t s) {
+                            void* out, hipStream_t s, const int* ada_idx) {
     DTTS_REQUIRE(C % groups == 0 && (C / groups) % 8 == 0 && C / groups <= 64, "gn_split_planes: group size");
     DTTS_REQUIRE(act == ACT_NONE || act == ACT_SILU, "gn_split_planes: activation");
     const int Tp = x3_tp(T);
@@ -349,10 +349,10 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
     static const int nt = []() { const char* v = getenv("DTTS_GN_SPLIT_NT"); return v ? atoi(v) : 1024; }();
     if (act == ACT_SILU)
         hipLaunchKernelGGL(gn_split_planes_kernel<ACT_SILU>, dim3(groups, B, ns), dim3(nt), 0, s, x, x_bs, x_cs, lens, T, C, groups, gamma,
-                           beta, eps, ada, ada_stride, ada_bs, Tp, o);
+                           beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);
     else
         hipLaunchKernelGGL(gn_split_planes_kernel<ACT_NONE>, dim3(groups, B, ns), dim3(nt), 0, s, x, x_bs, x_cs, lens, T, C, groups, gamma,
-                           beta, eps, ada, ada_stride, ada_bs, Tp, o);
+                           beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

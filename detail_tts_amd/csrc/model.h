@@ -172,12 +172,17 @@ private:
     void attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens, int B,
                          int T, int Ta, hipStream_t s, void* xs = nullptr);
     void res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T, int Ta,
-                       int step, hipStream_t s, void* xs = nullptr);
+                       int step, hipStream_t s, void* xs = nullptr, const int* step_idx = nullptr);
     bool use_x3() const;
     // cbuf0: [B + Nu, C, T] = B conditional code embeddings followed by Nu unconditional inputs (one per distinct length)
+    // integ (optional): [B + Nu, C, T] outputs of the conditioning_timestep_integrator for this step (precompute_integrator)
     void diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, const int* lens_i, const int* umap, int B, int Nu,
-                           int T, int step, float* out2, hipStream_t s);
-    struct PairPlan { const int *lens2, *lens_i, *umap; int Nu; };
+                           int T, int step, float* out2, hipStream_t s, const float* integ = nullptr);
+    // The integrator sees (code embedding | unconditioned embedding, timestep) only - never x_t - so its output for every sampling
+    // step is known before the loop starts: steps are evaluated J at a time as one batch of J*(B+Nu) samples, each at its own step.
+    void precompute_integrator(const float* cbuf0, const int* lens_i_host, int B, int Nu, int T, const std::vector<int>& steps,
+                               float* integ_all, hipStream_t s);
+    struct PairPlan { const int *lens2, *lens_i, *umap; int Nu; std::vector<int> ulen; };
     PairPlan plan_pair(const int* lens_host, int B, int T, hipStream_t s);
 
     std::unordered_map<std::string, std::pair<const float*, size_t>> weights_;

@@ -404,7 +404,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
 
 // diffusion ResBlock (vqvae/diff_model.py:106-119): y = x + conv3(SiLU(AdaGN(conv1(SiLU(GN(x))))))
 void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T,
-                          int Ta, int step, hipStream_t s, void* xs) {
+                          int Ta, int step, hipStream_t s, void* xs, const int* step_idx) {
     const int C = cfg.diff_channels;
     const long long bs = (long long)C * Ta;
     int groups = 32;
@@ -431,9 +431,9 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
         p.x3_tp = x3_tp(T);
     }
     run_conv(w.c1, p, s);
-    const float* ada = ss_table_ + (size_t)w.index * 2 * C * n_steps_ + step;
-    if (x3) launch_gn_split_planes(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ACT_SILU, xs, s);
-    else launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s);
+    const float* ada = ss_table_ + (size_t)w.index * 2 * C * n_steps_ + (step_idx ? 0 : step);   // step_idx: per-sample steps
+    if (x3) launch_gn_split_planes(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ACT_SILU, xs, s, step_idx);
+    else launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s, step_idx);
     ConvParams q = p;
     q.x = h1;
     q.pad = 1;
@@ -468,6 +468,7 @@ Model::PairPlan Model::plan_pair(const int* lens_host, int B, int T, hipStream_t
     umap_local_ = upload_ints(um2.data(), B, s);
     PairPlan pl;
     pl.Nu = (int)ul.size();
+    pl.ulen = ul;
     pl.lens2 = upload_ints(l2.data(), 2 * B, s);
     pl.lens_i = upload_ints(li.data(), (int)li.size(), s);
     pl.umap = upload_ints(um.data(), 2 * B, s);
@@ -478,7 +479,7 @@ Model::PairPlan Model::plan_pair(const int* lens_host, int B, int T, hipStream_t
 // two HIP streams (fork after the shared x-path, join before returning): the per-launch prologue/epilogue of one half's
 // kernels overlaps the matrix work of the other's (measured +6..9 % on the conv GEMMs).  DTTS_TWO_STREAMS=0 disables it.
 void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* lens2, const int* lens_i, const int* umap, int B, int Nu,
-                              int T, int step, float* out2, hipStream_t s) {
+                              int T, int step, float* out2, hipStream_t s, const float* integ) {
     const int C = cfg.diff_channels, Ta = T, OC = cfg.diff_out_channels;
     const long long bs = (long long)C * Ta;
     static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
@@ -548,17 +549,22 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
             attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, st, xs);
         };
         // conditioning_timestep_integrator (vqvae/diff_model.py:295): B code embeddings | Nu unconditional inputs
-        dlayer_n(integ_[0], hf.cin, bufB, bufC, bufA, hf.lens_integ, nbi);
-        dlayer_n(integ_[1], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
-        dlayer_n(integ_[2], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);          // bufA = code path
+        const float* code_path = bufA;
+        if (integ) {
+            code_path = integ + (hi ? (size_t)B * C * Ta : 0);                    // evaluated before the loop (precompute_integrator)
+        } else {
+            dlayer_n(integ_[0], hf.cin, bufB, bufC, bufA, hf.lens_integ, nbi);
+            dlayer_n(integ_[1], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
+            dlayer_n(integ_[2], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
+        }
         // integrating_conv, code half, accumulated onto the shared x-path term
-        ConvParams r = cp(bufA, C, bufB, C, B, T, Ta, lens2);
+        ConvParams r = cp(code_path, C, bufB, C, B, T, Ta, lens2);
         r.res = xpath;
         r.res_bs = bs;
         r.res_cs = Ta;
         r.x_bidx = hf.xmap;
         if (x3) {
-            launch_split_planes(bufA, bs, Ta, nullptr, ACT_NONE, hf.lens_integ, T, nbi, C, xs, st);
+            launch_split_planes(code_path, bs, Ta, nullptr, ACT_NONE, hf.lens_integ, T, nbi, C, xs, st);
             r.x3 = xs;
             r.x3_tp = x3_tp(T);
         }
@@ -591,6 +597,75 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         DTTS_CHECK_HIP(hipEventRecord(ev_join_, s2_));
         DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join_, 0));
     }
+}
+
+static size_t integ_ws_bytes(int Bv, int C, int T) {
+    const size_t act = (size_t)Bv * C * T;
+    return sizeof(float) * (act + 2 * (6 * act + (size_t)2 * Bv * C)) + 2 * x3_bytes(Bv, C, T) + 32 * 256;
+}
+static int integ_chunk(int Bi) {     // steps per batched evaluation (~36 samples per launch; DTTS_INTEG_SAMPLES overrides)
+    static const int target = []() { const char* v = getenv("DTTS_INTEG_SAMPLES"); return v ? atoi(v) : 36; }();
+    return std::max(1, target / Bi);
+}
+
+void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, int B, int Nu, int T, const std::vector<int>& steps,
+                                  float* integ_all, hipStream_t s) {
+    const int C = cfg.diff_channels, Bi = B + Nu, J = integ_chunk(Bi), NS = (int)steps.size();
+    const size_t ct = (size_t)C * T, mark = ws_.mark();
+    const int Bv = J * Bi;
+    const bool x3 = use_x3();
+    static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
+    const bool two = env_two && opt_two_streams_;
+    if (two && !s2_) {
+        DTTS_CHECK_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
+    float* vin = ws_.f32((size_t)Bv * ct);
+    for (int j = 0; j < J; ++j)
+        DTTS_CHECK_HIP(hipMemcpyAsync(vin + (size_t)j * Bi * ct, cbuf0, sizeof(float) * (size_t)Bi * ct, hipMemcpyDeviceToDevice, s));
+    // chunks of J steps alternate between the two streams (independent of each other), each with its own scratch
+    struct Lane { hipStream_t st; float *bufA, *bufB, *bufC, *qkv, *ab; void* xs; };
+    Lane lanes[2];
+    for (int q = 0; q < (two ? 2 : 1); ++q) {
+        lanes[q].st = q ? s2_ : s;
+        lanes[q].bufB = ws_.f32((size_t)Bv * ct);
+        lanes[q].bufC = ws_.f32((size_t)Bv * ct);
+        lanes[q].bufA = ws_.f32((size_t)Bv * ct);
+        lanes[q].qkv = ws_.f32((size_t)3 * Bv * ct);
+        lanes[q].ab = ws_.f32((size_t)2 * Bv * C);
+        lanes[q].xs = x3 ? ws_.raw(x3_bytes(Bv, C, T)) : nullptr;
+    }
+    if (two) {
+        DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
+        DTTS_CHECK_HIP(hipStreamWaitEvent(s2_, ev_fork_, 0));
+    }
+    std::vector<int> lv(Bv), sv(Bv);
+    int ci = 0;
+    for (int k0 = 0; k0 < NS; k0 += J, ++ci) {
+        const Lane& L = lanes[two ? (ci & 1) : 0];
+        const int jn = std::min(J, NS - k0), nb = jn * Bi;
+        for (int j = 0; j < jn; ++j)
+            for (int b = 0; b < Bi; ++b) {
+                lv[j * Bi + b] = lens_i_host[b];
+                sv[j * Bi + b] = steps[k0 + j];
+            }
+        const int* dl = upload_ints(lv.data(), nb, L.st);
+        const int* ds = upload_ints(sv.data(), nb, L.st);
+        float* outp = integ_all + (size_t)k0 * Bi * ct;
+        auto dlayer = [&](const DiffLayerW& l, const float* in, float* o) {
+            res_block_fwd(l.rb, in, L.bufB, L.bufC, L.ab, dl, nb, T, T, 0, L.st, L.xs, ds);
+            attention_block(l.at, L.bufC, o, L.qkv, L.bufB, L.ab, dl, nb, T, T, L.st, L.xs);
+        };
+        dlayer(integ_[0], vin, L.bufA);
+        dlayer(integ_[1], L.bufA, L.bufA);
+        dlayer(integ_[2], L.bufA, outp);
+    }
+    if (two) {
+        DTTS_CHECK_HIP(hipEventRecord(ev_join_, s2_));
+        DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+    }
+    ws_.rewind(mark);
 }
 
 static size_t pair_ws_bytes(int B, int C, int T) {
@@ -626,7 +701,10 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     const int C = cfg.diff_channels, OC = cfg.diff_out_channels, MC = cfg.mel_channels;
     if (n_steps <= 0 || n_steps > n_steps_) n_steps = n_steps_;
     const size_t per_call = pair_ws_bytes(B, C, T);
-    ws_.ensure(per_call + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
+    // the integrator outputs of all steps are evaluated up front (opt-out: DTTS_INTEG_PRECOMPUTE=0); Nu <= B distinct lengths
+    static const bool env_pre = []() { const char* v = getenv("DTTS_INTEG_PRECOMPUTE"); return !(v && v[0] == '0'); }();
+    const size_t integ_bytes = env_pre ? sizeof(float) * (size_t)n_steps * 2 * B * C * T + integ_ws_bytes(integ_chunk(B + 1) * 2 * B, C, T) : 0;
+    ws_.ensure(per_call + integ_bytes + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
     const PairPlan pl = plan_pair(lens_host, B, T, s);
     const int* lens2 = pl.lens2;
     const int* sids = upload_ints(sample_ids_host, B, s);
@@ -656,11 +734,22 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
             }
         }
     }
+    float* integ_all = nullptr;
+    const int Bi = B + pl.Nu;
+    if (env_pre) {
+        std::vector<int> steps(n_steps), li(Bi);
+        for (int k = 0; k < n_steps; ++k) steps[k] = n_steps_ - 1 - k;
+        for (int b = 0; b < B; ++b) li[b] = lens_host ? lens_host[b] : T;
+        for (int u = 0; u < pl.Nu; ++u) li[B + u] = pl.ulen[u];
+        integ_all = ws_.f32((size_t)n_steps * Bi * C * T);
+        precompute_integrator(cbuf0, li.data(), B, pl.Nu, T, steps, integ_all, s);
+    }
     const size_t mark = ws_.mark();
     for (int k = 0; k < n_steps; ++k) {
         const int i = n_steps_ - 1 - k;
         ws_.rewind(mark);                              // the forward's scratch is re-carved every step
-        diff_forward_pair(x, cbuf0, lens2, pl.lens_i, pl.umap, B, pl.Nu, T, i, out2, s);
+        diff_forward_pair(x, cbuf0, lens2, pl.lens_i, pl.umap, B, pl.Nu, T, i, out2, s,
+                          integ_all ? integ_all + (size_t)k * Bi * C * T : nullptr);
         const bool last = (k == n_steps - 1);
         launch_diff_update(x, xbs, T, out2, (long long)OC * T, T, lens2, T, B, MC, step_coefs_[i], seed, sids, i,
                            step_noise ? step_noise + (size_t)k * B * MC * T : nullptr, (denorm && last) ? 1 : 0, s);

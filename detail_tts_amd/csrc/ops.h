@@ -8,10 +8,11 @@ namespace dtts {
 // optionally composed with the AdaGN scale/shift of the diffusion ResBlock
 // (vqvae/diff_model.py:111-115):  a = rstd*gamma*(1+scale), d = (beta - mean*rstd*gamma)*(1+scale) + shift.
 // ada (or null): scale for channel c at ada[c*ada_stride], shift at ada[(C+c)*ada_stride] (shared by the batch),
-// or per-sample when ada_bs != 0 (ada + b*ada_bs).
+// or per-sample when ada_bs != 0 (ada + b*ada_bs), or at ada + ada_idx[b] when a per-sample index array is given (a batch whose
+// samples sit at different sampling steps).
 void launch_gn_coeffs(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
                       const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs,
-                      float* ab_out, hipStream_t s);
+                      float* ab_out, hipStream_t s, const int* ada_idx = nullptr);
 
 // y[b,c,t*up + u] = act(a*x[b,c,t] + d)   (GroupNorm apply, optional nearest-neighbour upsample by `up`)
 void launch_affine_apply(const float* x, long long x_bs, int x_cs, const float* ab, const int* lens, int T, int B, int C,

@@ -27,7 +27,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // red: >= 4
 // problem even when |mean| >> std), float4 loads when the rows are 16-byte aligned.
 __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long long x_bs, int x_cs, const int* lens, int T, int C,
                                                         int groups, const float* gamma, const float* beta, float eps,
-                                                        const float* ada, int ada_stride, int ada_bs, float* ab_out) {
+                                                        const float* ada, int ada_stride, int ada_bs, float* ab_out, const int* ada_idx) {
     __shared__ float red[8];
     const int g = blockIdx.x, b = blockIdx.y;
     const int len = lens ? lens[b] : T;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long lon
         float a = rstd * gamma[c];
         float d = beta[c] - mean * a;
         if (ada) {
-            const float* ad = ada + (long long)b * ada_bs;
+            const float* ad = ada + (ada_idx ? (long long)ada_idx[b] : (long long)b * ada_bs);
             const float sc = 1.f + ad[(long long)c * ada_stride], sh = ad[(long long)(C + c) * ada_stride];
             a *= sc;
             d = d * sc + sh;
@@ -100,10 +100,10 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const float* x, long lon
 
 void launch_gn_coeffs(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
                       const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs,
-                      float* ab_out, hipStream_t s) {
+                      float* ab_out, hipStream_t s, const int* ada_idx) {
     DTTS_REQUIRE(C % groups == 0 && C / groups <= 256, "group size");
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups, B), dim3(256), 0, s, x, x_bs, x_cs, lens, T, C, groups, gamma, beta, eps,
-                       ada, ada_stride, ada_bs, ab_out);
+                       ada, ada_stride, ada_bs, ab_out, ada_idx);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
