@@ -506,7 +506,6 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
                                                                    int cap, const int* pos, const int* klen, int H, float* out) {
     extern __shared__ float sc[];            // [cap] scores / probabilities
     __shared__ float red[4];
-    __shared__ float part_o[4][D];
     __shared__ float qkv_s[3][D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = H * D;
@@ -560,21 +559,46 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
     if (lane == 0) red[wave] = l;
     __syncthreads();
     l = red[0] + red[1] + red[2] + red[3];
-    float o = 0.f;
-    if (lane < D) {
-        float o4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int s = wave;
-        for (; s + 28 < nc; s += 32) {
+    // PV: thread (slot = tid / 12, c4 = tid % 12) owns the float4 channel group c4 of the keys s = slot, slot + 21, ... (V rows are
+    // token-major: 12 consecutive lanes read one 192-byte row); every load of a thread is independent, so a ~300-key cache is two
+    // batches of loads instead of ~10 dependent rounds.  The 21 slots are then combined through LDS in a fixed order.
+    constexpr int D4 = D / 4, SLOTS = 256 / D4;          // 12 float4 per row, 21 key slots (252 threads)
+    __shared__ float4 pvs[SLOTS][D4];
+    {
+        const int slot = tid / D4, c4 = tid - slot * D4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < SLOTS) {
+            int s = slot;
+            for (; s + 3 * SLOTS < nc; s += 4 * SLOTS) {
+                float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) o4[u] += sc[s + 4 * u] * vp[(long long)(s + 4 * u) * C + lane];
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(vp + (long long)(s + u * SLOTS) * C + c4 * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float pr = sc[s + u * SLOTS];
+                    acc.x += pr * v[u].x; acc.y += pr * v[u].y; acc.z += pr * v[u].z; acc.w += pr * v[u].w;
+                }
+            }
+            for (; s < nc; s += SLOTS) {
+                const float4 v = *reinterpret_cast<const float4*>(vp + (long long)s * C + c4 * 4);
+                const float pr = sc[s];
+                acc.x += pr * v.x; acc.y += pr * v.y; acc.z += pr * v.z; acc.w += pr * v.w;
+            }
+            if (slot == 0) {                                  // the key just produced (value row in LDS)
+                const float pr = sc[nc];
+                acc.x += pr * qkv_s[2][c4 * 4]; acc.y += pr * qkv_s[2][c4 * 4 + 1]; acc.z += pr * qkv_s[2][c4 * 4 + 2]; acc.w += pr * qkv_s[2][c4 * 4 + 3];
+            }
+            pvs[slot][c4] = acc;
         }
-        for (; s < nc; s += 4) o4[0] += sc[s] * vp[(long long)s * C + lane];
-        if ((nc & 3) == wave) o4[1] += sc[nc] * qkv_s[2][lane];       // the key just produced, in the wave that owns column nc
-        o = ((o4[0] + o4[1]) + (o4[2] + o4[3])) + ((o4[4] + o4[5]) + (o4[6] + o4[7]));
     }
-    if (lane < D) part_o[wave][lane] = o;
     __syncthreads();
-    if (tid < D) out[(long long)b * C + h * D + tid] = (part_o[0][tid] + part_o[1][tid] + part_o[2][tid] + part_o[3][tid]) / l;
+    if (tid < D) {
+        const int c4 = tid >> 2, e = tid & 3;
+        float o = 0.f;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) o += reinterpret_cast<const float*>(&pvs[q][c4])[e];
+        out[(long long)b * C + h * D + tid] = o / l;
+    }
 }
 
 void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* bias, float* cache, long long cache_bs,
