@@ -32,8 +32,8 @@ void launch_gemv_finish_qkv(const float* part, int slices, int B, int C, int Cou
                             long long cache_bs, int cache_cs, const int* pos, hipStream_t s);
 
 // Decode GEMV, workgroup form (8 waves x 16 rows x 256 columns, one partial per 128 input rows): K % 128 == 0, B <= 8.
-// part[slice][b][col] with slice = K/128 (gemv_block_slices); consumed by launch_gemv_finish or by a *_parts / attention prologue.
-int gemv_block_slices(int K);
+// part[slice][b][col] with gemv_block_slices(K, CoutP) slices (K/128, or K/64 for the smallest projection); consumed by launch_gemv_finish or by a *_parts / attention prologue.
+int gemv_block_slices(int K, int CoutP);
 void launch_gemv_block(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, hipStream_t s);
 void launch_gemv_block_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, const float* stats,
                           int nblk, const float* gamma, const float* beta, hipStream_t s);

@@ -2,6 +2,7 @@
 // per token regardless of the batch -> these kernels are HBM-bound: wide (16 B/lane) coalesced
 // weight loads, many waves in flight, wave64 shuffle reductions, no MFMA.
 #include "gpt_kernels.h"
+#include <cstdlib>
 #include "philox.h"
 
 namespace dtts {
@@ -211,23 +212,32 @@ struct GemvIn {
     const float* in_bias = nullptr;
 };
 
-template <int PRO>
+// VEC = columns per lane: 4 (256-column workgroups, 16-byte loads) for the wide projections; 1 (64-column workgroups) when the
+// wide form would leave most of the chip idle (the 768-column projections: 3 column groups x K/128 slices = 18..72 workgroups).
+template <int PRO, int VEC, int RPW>
 __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict__ W, int K, int CoutP, GemvIn in, int B,
                                                          float* __restrict__ part) {
-    constexpr int NB = 8, RPW = 16, RB = 128;
+    constexpr int NB = 8, RB = 8 * RPW;                 // RPW weight rows per wave, RB input rows per workgroup (= one partial slice)
     __shared__ __attribute__((aligned(16))) float xs[NB][RB];
-    __shared__ float4 red[8][4][64];
+    __shared__ __attribute__((aligned(16))) float red[8][4][64][VEC];
     __shared__ float smr[NB][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = blockIdx.x * 256 + lane * 4;
+    const int col = blockIdx.x * (64 * VEC) + lane * VEC;
     const int k0 = blockIdx.y * RB;
     const bool cok = col < CoutP;
-    // weights first: 16 independent 16-byte loads per lane stay in flight across the prologue
-    float4 w[RPW];
+    // weights first: 16 independent loads per lane stay in flight across the prologue
+    float w[RPW][VEC];
     {
         const float* wp = W + (long long)(k0 + wave * RPW) * CoutP + (cok ? col : 0);
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) w[r] = *reinterpret_cast<const float4*>(wp + (long long)r * CoutP);
+        for (int r = 0; r < RPW; ++r) {
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(wp + (long long)r * CoutP);
+                w[r][0] = t.x; w[r][VEC > 1 ? 1 : 0] = t.y; w[r][VEC > 2 ? 2 : 0] = t.z; w[r][VEC > 3 ? 3 : 0] = t.w;
+            } else {
+                w[r][0] = wp[(long long)r * CoutP];
+            }
+        }
     }
     if (PRO == GP_LN) {
         // wave b rebuilds (mean, rstd) of row b from the producer's per-block partial sums (fixed order -> deterministic)
@@ -242,7 +252,8 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
     }
 #pragma unroll
     for (int e0 = 0; e0 < NB * RB; e0 += 512) {
-        const int e = e0 + tid, b = e >> 7, i = e & 127, bb = b < B ? b : B - 1, k = k0 + i;
+        if (e0 + tid >= NB * RB) break;
+        const int e = e0 + tid, b = e / RB, i = e % RB, bb = b < B ? b : B - 1, k = k0 + i;
         float v;
         if (PRO == GP_PARTS) {
             v = in.in_bias ? in.in_bias[k] : 0.f;
@@ -255,9 +266,11 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
         xs[b][i] = v;
     }
     __syncthreads();
-    float4 acc[NB];
+    float acc[NB][VEC];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[b][c] = 0.f;
 #pragma unroll
     for (int q = 0; q < RPW / 4; ++q)
 #pragma unroll
@@ -265,43 +278,70 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
             const float4 xv = *reinterpret_cast<const float4*>(&xs[b][wave * RPW + 4 * q]);      // LDS broadcast
             const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 ww = w[4 * q + u];
-                acc[b].x += ww.x * xe[u]; acc[b].y += ww.y * xe[u]; acc[b].z += ww.z * xe[u]; acc[b].w += ww.w * xe[u];
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc[b][c] += w[4 * q + u][c] * xe[u];
         }
     // combine the 8 waves (rows) through LDS, 4 batch rows per round; wave order fixed -> deterministic
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 4; ++b) red[wave][b][lane] = acc[h * 4 + b];
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) red[wave][b][lane][c] = acc[h * 4 + b][c];
         __syncthreads();
         if (tid < 256) {
             const int b = tid >> 6, l = tid & 63;
-            float4 t = red[0][b][l];
+            float t[VEC];
 #pragma unroll
-            for (int wv = 1; wv < 8; ++wv) {
-                const float4 u = red[wv][b][l];
-                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            for (int c = 0; c < VEC; ++c) t[c] = red[0][b][l][c];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) t[c] += red[wv][b][l][c];
+            const int bo = h * 4 + b, cc = blockIdx.x * (64 * VEC) + l * VEC;
+            if (bo < B && cc < CoutP) {
+                float* o = part + ((long long)blockIdx.y * B + bo) * CoutP + cc;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) o[c] = t[c];
             }
-            const int bo = h * 4 + b, c = blockIdx.x * 256 + l * 4;
-            if (bo < B && c < CoutP) *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * B + bo) * CoutP + c) = t;
         }
     }
 }
 
+template <int VEC, int RPW>
+static void gemv_block_launch_v(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
+    const dim3 grid(cdiv(CoutP, 64 * VEC), K / (8 * RPW));
+    if (pro == GP_PLAIN) hipLaunchKernelGGL((gemv_block_kernel<GP_PLAIN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else if (pro == GP_LN) hipLaunchKernelGGL((gemv_block_kernel<GP_LN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else hipLaunchKernelGGL((gemv_block_kernel<GP_PARTS, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+}
+
+// Workgroup shape per GEMV: enough workgroups to put one on most CUs.  Wide (256-column, 16-byte loads) when that already yields
+// >= 192; else narrow 64-column workgroups; and 64 instead of 128 input rows per workgroup when even those are fewer than 128
+// (the 768 x 768 attention projection: 12 column groups x 6 slices).
+static int gemv_rows(int K, int CoutP) {
+    static const int force = []() { const char* v = getenv("DTTS_GEMV_ROWS"); return v ? atoi(v) : 0; }();
+    if (force) return force;
+    return ((long long)cdiv(CoutP, 64) * (K / 128) < 128 && K % 64 == 0) ? 64 : 128;
+}
+static bool gemv_wide(int K, int CoutP) {
+    static const int force = []() { const char* v = getenv("DTTS_GEMV_VEC"); return v ? atoi(v) : 0; }();
+    return force ? force == 4 : (long long)cdiv(CoutP, 256) * (K / 128) >= 192;
+}
+
 static void gemv_block_launch(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
     DTTS_REQUIRE(B >= 1 && B <= 8 && K % 128 == 0 && CoutP % 4 == 0, "gemv_block shape");
-    DTTS_REQUIRE((long long)(K / 128) * CoutP * B <= 8LL * 262144, "gemv partial scratch");
-    const dim3 grid(cdiv(CoutP, 256), K / 128);
-    if (pro == GP_PLAIN) hipLaunchKernelGGL(gemv_block_kernel<GP_PLAIN>, grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else if (pro == GP_LN) hipLaunchKernelGGL(gemv_block_kernel<GP_LN>, grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else hipLaunchKernelGGL(gemv_block_kernel<GP_PARTS>, grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    const int rows = gemv_rows(K, CoutP);
+    DTTS_REQUIRE((long long)(K / rows) * CoutP * B <= 8LL * 262144, "gemv partial scratch");
+    if (gemv_wide(K, CoutP)) gemv_block_launch_v<4, 16>(pro, W, K, CoutP, in, B, part, s);
+    else if (rows == 64) gemv_block_launch_v<1, 8>(pro, W, K, CoutP, in, B, part, s);
+    else gemv_block_launch_v<1, 16>(pro, W, K, CoutP, in, B, part, s);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-int gemv_block_slices(int K) { return K / 128; }
+int gemv_block_slices(int K, int CoutP) { return gemv_wide(K, CoutP) ? K / 128 : K / gemv_rows(K, CoutP); }
 
 void launch_gemv_block(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, hipStream_t s) {
     GemvIn in;

@@ -256,7 +256,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
                            lat_stride, step);
         if (fast) {
             launch_gemv_block(mel_head_.w, C, VP, lat, C, B, part, s);
-            launch_gemv_finish(part, gemv_block_slices(C), B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
+            launch_gemv_finish(part, gemv_block_slices(C, VP), B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
         } else {
             const int sl = gemv_slices(C, VP);
             launch_gemv_partial(mel_head_.w, C, VP, lat, C, B, part, sl, s);
@@ -288,15 +288,16 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
             const GptLayerW& w = gpt_layers_[l];
             float* cache = kv + (size_t)l * kv_layer;
             if (fast) {
-                const int s1 = gemv_block_slices(C), s4 = gemv_block_slices(4 * C);
+                const int sq = gemv_block_slices(C, w.attn.CoutP), sp = gemv_block_slices(C, w.proj.CoutP);
+                const int sf = gemv_block_slices(C, w.fc.CoutP), s4 = gemv_block_slices(4 * C, w.fc2.CoutP);
                 if (l == 0) launch_gemv_block(w.attn.w, C, w.attn.CoutP, hn, C, B, part, s);
                 else launch_gemv_block_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, lnst, nblk, w.ln1_g, w.ln1_b, s);
-                launch_decode_attention_qkv(part, s1, w.attn.CoutP, w.attn.b, cache, kv_bs, cap, pos, klen, B, H, D, ab, s);
+                launch_decode_attention_qkv(part, sq, w.attn.CoutP, w.attn.b, cache, kv_bs, cap, pos, klen, B, H, D, ab, s);
                 launch_gemv_block(w.proj.w, C, w.proj.CoutP, ab, C, B, part2, s);
-                launch_gemv_finish(part2, s1, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);   // y = x + attn ; stats for ln_2
+                launch_gemv_finish(part2, sp, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);   // y = x + attn ; stats for ln_2
                 launch_gemv_block_ln(w.fc.w, C, w.fc.CoutP, y, C, B, part, lnst, nblk, w.ln2_g, w.ln2_b, s);
                 // c_proj(gelu(c_fc + bias)): c_fc's finish is this GEMV's prologue
-                launch_gemv_block_parts(w.fc2.w, 4 * C, w.fc2.CoutP, part, s1, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, B, part2, s);
+                launch_gemv_block_parts(w.fc2.w, 4 * C, w.fc2.CoutP, part, sf, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, B, part2, s);
                 launch_gemv_finish(part2, s4, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s, lnst);     // x = y + mlp ; stats for next ln_1
                 continue;
             }
