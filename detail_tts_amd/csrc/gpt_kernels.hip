@@ -804,14 +804,36 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                     if ((k & mask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int acc = 0, bin = 255;
-                    for (; bin > 0; --bin) {
-                        if (acc + (int)hist[bin] >= krem) break;
-                        acc += (int)hist[bin];
+                if (tid < 64) {
+                    // wave 0: lane l owns bins 255-4l .. 252-4l (descending); exclusive prefix of the counts above each lane's bins,
+                    // then the lane whose 4 bins cross `krem` walks them.  Exactly the serial top-down scan, in 6 shuffle steps.
+                    const int b0 = 255 - 4 * tid;
+                    const int c0 = (int)hist[b0], c1 = (int)hist[b0 - 1], c2 = (int)hist[b0 - 2], c3 = (int)hist[b0 - 3];
+                    const int mine = c0 + c1 + c2 + c3;
+                    int incl = mine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int v = __shfl_up(incl, o);
+                        if (tid >= o) incl += v;
                     }
-                    sh_u[0] = (unsigned)bin;
-                    sh_i[0] = krem - acc;
+                    const int excl = incl - mine;
+                    const bool crosses = excl < krem && incl >= krem;
+                    // no lane crosses when the total is < krem: the serial scan then ends at bin 0 with acc = everything above it
+                    if (crosses) {
+                        int acc = excl, bin = b0;
+                        if (acc + c0 >= krem) bin = b0;
+                        else if (acc + c0 + c1 >= krem) { acc += c0; bin = b0 - 1; }
+                        else if (acc + c0 + c1 + c2 >= krem) { acc += c0 + c1; bin = b0 - 2; }
+                        else { acc += c0 + c1 + c2; bin = b0 - 3; }
+                        if (bin == 0) acc = excl + (b0 == 3 ? c0 + c1 + c2 : (b0 == 2 ? c0 + c1 : (b0 == 1 ? c0 : 0)));
+                        sh_u[0] = (unsigned)bin;
+                        sh_i[0] = krem - acc;
+                    }
+                    const int total = __shfl(incl, 63);
+                    if (tid == 0 && total < krem) {
+                        sh_u[0] = 0u;
+                        sh_i[0] = krem - (total - (int)hist[0]);
+                    }
                 }
                 __syncthreads();
                 prefix |= sh_u[0] << sh;
@@ -844,6 +866,27 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             while (n2 < M) n2 <<= 1;
             for (int i = M + tid; i < n2; i += SAMP_THREADS) { skey[i] = INFINITY; sidx[i] = 0xffff; }
             __syncthreads();
+            if (n2 == 64) {
+                // top-k 50 leaves <= 64 candidates: one wave sorts them with no workgroup barriers (21 of them otherwise).  LDS
+                // operations of a wave complete in issue order; the wave barrier only pins the compiler's ordering.
+                if (tid < 64) {
+                    for (int k = 2; k <= 64; k <<= 1)
+                        for (int j = k >> 1; j > 0; j >>= 1) {
+                            const int i = tid, ixj = i ^ j;
+                            const float a = skey[i], c = skey[ixj];
+                            const unsigned short ia = sidx[i], ic = sidx[ixj];
+                            __builtin_amdgcn_wave_barrier();
+                            if (ixj > i) {
+                                const bool asc = (i & k) == 0;
+                                const bool gt = (a > c) || (a == c && ia > ic);      // total order: value, then id
+                                if (gt == asc) { skey[i] = c; skey[ixj] = a; sidx[i] = ic; sidx[ixj] = ia; }
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                }
+                __syncthreads();
+            } else {
             for (int k = 2; k <= n2; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int i = tid; i < n2; i += SAMP_THREADS) {
@@ -859,6 +902,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                     }
                     __syncthreads();
                 }
+            }
             // Z over the kept set, then inclusive cumulative prob in ascending order
             float z = 0.f;
             for (int i = tid; i < M; i += SAMP_THREADS) z += expf(skey[i] - mx);
