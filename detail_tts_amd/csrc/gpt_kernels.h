@@ -9,8 +9,9 @@ constexpr int GEMV_MAXB = 16;     // sequences per decode step (rows of the skin
 // y[b, :] = LayerNorm(x[b, :]) over C (eps 1e-5); x, y [B][C] contiguous. One block per row.
 void launch_vec_layernorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, hipStream_t s);
 // two LayerNorms back to back: y = LN2(LN1(x))  (ln_f then final_norm, gpt/model.py:173 + HF GPT2Model.ln_f)
+// col_dst (optional): also store the result as column `col` of a [B, C, *] tensor (the captured latents)
 void launch_vec_layernorm2(const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* y, int B, int C,
-                           hipStream_t s);
+                           hipStream_t s, float* col_dst = nullptr, long long col_bs = 0, int col_cs = 0, int col = 0);
 
 // Skinny GEMM for B <= 16 rows against a K-major packed weight W[K][CoutP]:
 //   part[slice][b][col] = sum_{i in slice} x[b][i] * W[i][col]
@@ -82,6 +83,7 @@ struct SamplerParams {
     const float* mel_emb;
     const float* mel_pos;
     float* x_next;
+    float* x_stats;           // optional [B][ceil(C/64)][2]: per-64-column (sum, sum sq) of x_next for the consumer's fused LayerNorm
     int C;
     int* n_unfinished;        // [1] device counter (written each step)
 };

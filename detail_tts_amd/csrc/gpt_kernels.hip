@@ -47,7 +47,8 @@ __device__ __forceinline__ void block_ln_256(float* v, int n_per, int C, const f
 }
 
 __global__ __launch_bounds__(256) void vec_layernorm_kernel(const float* x, const float* g1, const float* b1, const float* g2,
-                                                            const float* b2, float* y, int C) {
+                                                            const float* b2, float* y, int C, float* col_dst, long long col_bs,
+                                                            int col_cs, int col) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     float v[8];
@@ -60,20 +61,23 @@ __global__ __launch_bounds__(256) void vec_layernorm_kernel(const float* x, cons
     if (g2) block_ln_256(v, n_per, C, g2, b2, red);
     for (int i = 0; i < n_per; ++i) {
         const int c = tid + i * 256;
-        if (c < C) y[(long long)b * C + c] = v[i];
+        if (c < C) {
+            y[(long long)b * C + c] = v[i];
+            if (col_dst) col_dst[(long long)b * col_bs + (long long)c * col_cs + col] = v[i];     // latents[b, :, step]
+        }
     }
 }
 
 void launch_vec_layernorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, hipStream_t s) {
     DTTS_REQUIRE(C <= 2048, "vec_layernorm width");
-    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, gamma, beta, nullptr, nullptr, y, C);
+    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, gamma, beta, nullptr, nullptr, y, C, nullptr, 0, 0, 0);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
 void launch_vec_layernorm2(const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* y, int B, int C,
-                           hipStream_t s) {
+                           hipStream_t s, float* col_dst, long long col_bs, int col_cs, int col) {
     DTTS_REQUIRE(C <= 2048, "vec_layernorm width");
-    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, g1, b1, g2, b2, y, C);
+    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, g1, b1, g2, b2, y, C, col_dst, col_bs, col_cs, col);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -958,8 +962,24 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         if (token == p.eos) p.finished[b] = 1;
     }
     // next input embedding: mel_embedding[token] + mel_pos_embedding[step + 1]   (gpt/model.py:134-136 with position k)
-    for (int c = tid; c < p.C; c += SAMP_THREADS)
-        p.x_next[(long long)b * p.C + c] = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(p.step + 1) * p.C + c];
+    // + the per-64-column (sum, sum of squares) the first layer's GEMV prologue rebuilds its LayerNorm from (same layout as
+    // gemv_finish_kernel's statistics: [B][ceil(C/64)][2]) - the first layer needs no LayerNorm kernel of its own
+    for (int c0 = 0; c0 < p.C; c0 += SAMP_THREADS) {
+        const int c = c0 + tid;
+        float v = 0.f;
+        if (c < p.C) {
+            v = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(p.step + 1) * p.C + c];
+            p.x_next[(long long)b * p.C + c] = v;
+        }
+        if (p.x_stats) {
+            const float s1 = wsum(v), s2 = wsum(v * v);
+            if ((tid & 63) == 0 && c < p.C) {
+                float* st = p.x_stats + ((long long)b * ((p.C + 63) / 64) + (c >> 6)) * 2;
+                st[0] = s1;
+                st[1] = s2;
+            }
+        }
+    }
 }
 
 void launch_sampler(const SamplerParams& p, hipStream_t s) {

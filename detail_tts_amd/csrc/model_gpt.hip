@@ -244,6 +244,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     sp.mel_pos = mel_pos_;
     sp.C = C;
     sp.n_unfinished = nullptr;
+    sp.x_stats = nullptr;
 
     // decode GEMVs in workgroup form with the finishes folded into the consumers' prologues (B <= 8; DTTS_GPT_FAST=0: the older
     // one-wave split-K kernels, also used for 9..16 sequences)
@@ -252,8 +253,9 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     // lat = final_norm(ln_f(hidden)) must already be in `lat` (fused into the producing kernel)
     auto head_and_sample = [&](int step, float* x_next) {
         // lm_head = (final_norm, mel_head) applied to ln_f(h)   (gpt/model.py:41, 173)
-        hipLaunchKernelGGL(store_column_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, lat, C, latents_cm, (long long)C * lat_stride,
-                           lat_stride, step);
+        if (!fast)
+            hipLaunchKernelGGL(store_column_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, lat, C, latents_cm, (long long)C * lat_stride,
+                               lat_stride, step);
         if (fast) {
             launch_gemv_block(mel_head_.w, C, VP, lat, C, B, part, s);
             launch_gemv_finish(part, gemv_block_slices(C, VP), B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
@@ -264,9 +266,10 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         }
         sp.step = step;
         sp.x_next = x_next;
+        sp.x_stats = fast ? lnst : nullptr;       // layer 0 of the next token normalises x_next from these (no LayerNorm kernel)
         launch_sampler(sp, s);
     };
-    launch_vec_layernorm2(xa, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s);
+    launch_vec_layernorm2(xa, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s, fast ? latents_cm : nullptr, (long long)C * lat_stride, lat_stride, 0);
     head_and_sample(0, xb);
 
     std::vector<int> fin(B, 0);
@@ -283,18 +286,17 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         const int* klen = klen_tab + (size_t)t * B;
         const int nblk = cdiv(C, 64);
         // the sampler wrote x (next input embedding) without LN statistics: one small LN for layer 0
-        launch_vec_layernorm(x, gpt_layers_[0].ln1_g, gpt_layers_[0].ln1_b, hn, B, C, s);
+        if (!fast) launch_vec_layernorm(x, gpt_layers_[0].ln1_g, gpt_layers_[0].ln1_b, hn, B, C, s);
         for (int l = 0; l < NL; ++l) {
             const GptLayerW& w = gpt_layers_[l];
             float* cache = kv + (size_t)l * kv_layer;
             if (fast) {
-                const int sq = gemv_block_slices(C, w.attn.CoutP), sp = gemv_block_slices(C, w.proj.CoutP);
+                const int sq = gemv_block_slices(C, w.attn.CoutP), spj = gemv_block_slices(C, w.proj.CoutP);
                 const int sf = gemv_block_slices(C, w.fc.CoutP), s4 = gemv_block_slices(4 * C, w.fc2.CoutP);
-                if (l == 0) launch_gemv_block(w.attn.w, C, w.attn.CoutP, hn, C, B, part, s);
-                else launch_gemv_block_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, lnst, nblk, w.ln1_g, w.ln1_b, s);
+                launch_gemv_block_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, lnst, nblk, w.ln1_g, w.ln1_b, s);
                 launch_decode_attention_qkv(part, sq, w.attn.CoutP, w.attn.b, cache, kv_bs, cap, pos, klen, B, H, D, ab, s);
                 launch_gemv_block(w.proj.w, C, w.proj.CoutP, ab, C, B, part2, s);
-                launch_gemv_finish(part2, sp, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);   // y = x + attn ; stats for ln_2
+                launch_gemv_finish(part2, spj, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);   // y = x + attn ; stats for ln_2
                 launch_gemv_block_ln(w.fc.w, C, w.fc.CoutP, y, C, B, part, lnst, nblk, w.ln2_g, w.ln2_b, s);
                 // c_proj(gelu(c_fc + bias)): c_fc's finish is this GEMV's prologue
                 launch_gemv_block_parts(w.fc2.w, 4 * C, w.fc2.CoutP, part, sf, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, B, part2, s);
@@ -316,7 +318,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
             launch_gemv_partial(w.fc2.w, 4 * C, w.fc2.CoutP, mb, 4 * C, B, part, sl, s);
             launch_gemv_finish(part, sl, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s, lnst);        // x = y + mlp ; stats for next ln_1
         }
-        launch_vec_layernorm2(x, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s);
+        launch_vec_layernorm2(x, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s, fast ? latents_cm : nullptr, (long long)C * lat_stride, lat_stride, t);
         head_and_sample(t, y);
         std::swap(x, y);
         steps_done = t + 1;
