@@ -176,7 +176,7 @@ def main():
         # layer: in_layers 1x1, out_layers k3, qkv 1x1 (M=2304), proj 1x1.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_layer_traffic.json" if x3 else "r01_pmc_conv_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_layer_traffic.json" if x3 else "r01_pmc_conv_traffic.json")))
             mix = ["768->768 k1", "768->768 k3", "768->2304 k1", "768->768 k1 (proj)" if x3 else "768->768 k1"]
             traffic = round(sum((tj[k]["fetch_MB"] + tj[k]["write_MB"]) for k in mix) / len(mix) * 1e6)
         except Exception:
