@@ -132,3 +132,23 @@ def test_wav_in_wav_out_example(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     with wave.open(str(out), "rb") as f:
         assert f.getframerate() == 24000 and f.getnframes() == 5 * 1024           # 6 tokens incl. the last one dropped -> 5 codes
+
+
+def test_long_form_batch4_streaming_vocoder(model):
+    """BASELINE configs[4] at reduced length (15 s instead of 60 s to keep the suite short; tools/longform.py runs the full size):
+    batch 4, forced codes, and the vocoder's generator streamed in 64-frame chunks == the one-shot waveform."""
+    rs = np.random.RandomState(77)
+    B, n = 4, 352                                   # T = 1408 mel frames, 15.0 s
+    refer = torch.from_numpy((rs.randn(B, 128, 300) * 2 - 5).astype(np.float32))
+    text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, 30)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+    codes = [rs.randint(0, 8192, size=n) for _ in range(B)]
+    wav, lens = model.infer(text, torch.full((B,), 31), refer, torch.full((B,), 300), batch=True, seed=11, sample_ids=list(range(B)),
+                            forced_codes=codes, return_lengths=True)
+    assert tuple(wav.shape) == (B, 1, n * 1024) and lens == [n * 1024] * B and bool(torch.isfinite(wav).all())
+    assert float(wav.pow(2).mean().sqrt()) > 1e-4
+    # streaming generator on a latent of the same length
+    z = torch.from_numpy(rs.randn(1, 192, 4 * n).astype(np.float32)).cuda()
+    g = torch.from_numpy((rs.randn(1, 768, 1) * 0.1).astype(np.float32)).cuda()
+    full = model.dec(z, g=g)
+    cat = torch.cat(list(model.dec.stream(z, g, chunk=64)), -1)
+    assert float((cat - full).abs().max()) < 1e-5
