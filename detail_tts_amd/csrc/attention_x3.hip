@@ -24,6 +24,7 @@ constexpr int D = 48, KT = 64, NW = 8, QPW = 16, QPB = NW * QPW, BIAS_CLIP = 64;
 constexpr int KCH = 6 * KT;                    // K chunks per plane
 constexpr int VCH = 3 * 2 * 4 * 16;            // V chunks per plane
 constexpr int BUF_BYTES = 3 * (KCH + VCH) * 16;   // 36 KiB per stage
+constexpr int NBUF = 2;                            // LDS stages (1: single buffer, two barriers per tile, half the LDS)
 
 __device__ __forceinline__ bf16x8 as_bf(const uint4& q) { return __builtin_bit_cast(bf16x8, q); }
 
@@ -40,7 +41,7 @@ __device__ __forceinline__ bf16x8 as_bf(const uint4& q) { return __builtin_bit_c
 __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams p) {
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);      // [129], pre-multiplied by log2(e)
+    float* bias_s = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES);      // [129], pre-multiplied by log2(e)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     const int kcol0 = g * KT + j, kcol1 = (4 + (g & 1)) * KT + j;
 
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int s0 = kt * KT, buf = kt & 1;
+        const int s0 = kt * KT, buf = NBUF == 2 ? (kt & 1) : 0;
         const bool has_next = kt + 1 < ntiles;
         if (has_next) load_tile(kt + 1);
         if (wave_active) {
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                 }
             }
         }
-        if (has_next) store_tile(buf ^ 1);
+        if (NBUF == 1) __syncthreads();                 // everyone is done reading the tile before it is overwritten
+        if (has_next) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
 
 void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream) {
     DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out, "attention_x3 covers head dim 48 with the T5 bias only");
-    constexpr size_t lds = 2 * BUF_BYTES + sizeof(float) * (2 * BIAS_CLIP + 1);
+    constexpr size_t lds = NBUF * BUF_BYTES + sizeof(float) * (2 * BIAS_CLIP + 1);
     static bool attr = false;
     if (!attr) {
         DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
