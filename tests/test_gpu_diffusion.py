@@ -238,3 +238,22 @@ def test_split_precision_path_equals_fp32_path(rt):
         assert maxabs(a, r) < 5e-5 * max(1.0, float(np.abs(r).max())), (b, maxabs(a, r))
         rel = float(np.sqrt(np.mean((a - r) ** 2)) / np.sqrt(np.mean(r ** 2)))
         assert rel < 1e-5, rel          # measured 2.7e-6 through ~100 layers: the spread of two fp32 summation orders
+
+
+def test_trunk_blocks_random_shapes(rt, weights):
+    """Split-precision ResBlock / AttentionBlock at random ragged shapes (tile edges: T around 64 / 128 multiples, very short rows)."""
+    from oracle import diffusion as D
+    rs = np.random.RandomState(99)
+    sched = D.make_schedule()
+    for T, lens in ((5, [5, 3]), (63, [63, 17]), (65, [65, 64]), (127, [100, 127]), (129, [129, 1]), (257, [256, 130])):
+        B = len(lens)
+        x = rs.randn(B, 768, T).astype(np.float32)
+        step = int(rs.randint(0, 50))
+        y = host(rt.op_resblock("diffusion.layers.5.resblk", dev(x), step, lens))
+        z = host(rt.op_attention_block("diffusion.layers.5.attn", dev(x), lens))
+        temb = D.time_embed(weights, [sched["timestep_map"][step]], 768)
+        for b, L in enumerate(lens):
+            ref = D.res_block(weights, "diffusion.layers.5.resblk", x[b:b + 1, :, :L], temb)[0]
+            assert maxabs(y[b, :, :L], ref) < 1e-4, ("resblock", T, b)
+            ref = D.attention_block(weights, "diffusion.layers.5.attn", x[b:b + 1, :, :L], 16)[0]
+            assert maxabs(z[b, :, :L], ref) < 1e-4, ("attention", T, b)
