@@ -275,11 +275,12 @@ void run64(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, i
 
 int main() {
     const int M = 768, C = 768, T = 936, B = 16, Tp = 8 * 128 + 2;
+    const bool zero_data = getenv("ZERO") != nullptr;
     for (int taps : {1}) {
         std::vector<float> hw((size_t)taps * M * C), hx((size_t)B * C * T);
         srand(1);
-        for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.036f;
-        for (auto& v : hx) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 1.7f;
+        for (auto& v : hw) v = zero_data ? 0.f : ((rand() / (float)RAND_MAX) * 2 - 1) * 0.036f;
+        for (auto& v : hx) v = zero_data ? 0.f : ((rand() / (float)RAND_MAX) * 2 - 1) * 1.7f;
         std::vector<unsigned short> wp((size_t)taps * (C / 8) * 3 * M * 8), xp((size_t)B * (C / 8) * 3 * Tp * 8, 0);
         unsigned short pl[3];
         for (int tap = 0; tap < taps; ++tap)
@@ -298,12 +299,8 @@ int main() {
         (void)hipMalloc(&Wp, wp.size() * 2); (void)hipMalloc(&Xp, xp.size() * 2); (void)hipMalloc(&Y, (size_t)B * M * T * 4);
         (void)hipMemcpy(Wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(Xp, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
-        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "128x128");
-        run64(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "128x64");
-        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "128x128");
-        run64(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "128x64");
-        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "128x128");
-        run64(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "128x64");
+        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, zero_data ? "full kernel, ZERO operands" : "full kernel, random operands");
+        run<2, 0, 15>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, zero_data ? "MFMA stream only, ZERO operands" : "MFMA stream only, random operands");
         (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
     }
     return 0;
