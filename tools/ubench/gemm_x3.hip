@@ -106,6 +106,88 @@ __global__ __launch_bounds__(WM * 128) void gemm_x3(const uint4* __restrict__ Wp
             }
 }
 
+// Strength-reduced K loop (1-tap): all DMA source pointers are running per-lane pointers bumped by a constant per K-step, the
+// loop is unrolled by two so that every LDS address (stage parity) is an immediate offset: ~30 instead of ~170 integer
+// instructions per 24 MFMAs.
+__global__ __launch_bounds__(256) void gemm_x3_sr(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M,
+                                                  int C8, int taps, int Tp, int T, int xoff) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z, lin = (bz * gridDim.y + by) * gridDim.x + bx;
+        const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        bx = v % gridDim.x; by = (v / gridDim.x) % gridDim.y; bz = v / (gridDim.x * gridDim.y);
+    }
+    const int m0 = bx * BM, n0 = by * BN, b = bz;
+    const int nks = C8 / 2;                            // taps == 1
+    const int operand = wave >> 1;
+    const long long rowlen = operand ? Tp : M;
+    // six running source pointers (per lane), one per piece this wave owns; each K-step advances them by 2*3*rowlen chunks
+    const uint4* src[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int j = (wave & 1) * 6 + i, kind = j >> 1, p = kind >> 1, h = kind & 1, rh = j & 1;
+        src[i] = (operand ? Xp + (size_t)b * C8 * 3 * Tp + n0 + xoff : Wp + m0) + lane + ((long long)h * 3 + p) * rowlen + rh * 64;
+    }
+    const long long kstride = 6 * rowlen;
+    const int lds_piece0 = operand * TILE + ((wave & 1) * 6) * 1024;     // pieces j -> kind*2048 + rh*1024 == j*1024
+    auto issue_one = [&](int i, int stage) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                         (__attribute__((address_space(3))) void*)(smem + stage * 2 * TILE + lds_piece0 + i * 1024), 16, 0, 0);
+        src[i] += kstride;
+    };
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    f16v acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_one(i, 0);
+    const unsigned char* a_base = smem + lhi * 2048 + (wm0 + l31) * 16;
+    const unsigned char* b_base = smem + TILE + lhi * 2048 + (wn0 + l31) * 16;
+    constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+    auto kstep = [&](int stage, bool fetch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf8 a[2][3], bb[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][p] = *reinterpret_cast<const bf8*>(a_base + stage * 2 * TILE + p * 4096 + i * 512);
+                bb[i][p] = *reinterpret_cast<const bf8*>(b_base + stage * 2 * TILE + p * 4096 + i * 512);
+            }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (fetch) issue_one(t, stage ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int ks = 0;
+    for (; ks + 2 < nks; ks += 2) {
+        kstep(0, true);
+        kstep(1, true);
+    }
+    for (; ks < nks; ++ks) kstep(ks & 1, ks + 1 < nks);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* yb = Y + (long long)b * M * T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, n = n0 + wn0 + j * 32 + l31;
+                if (n < T) yb[(long long)row * T + n] = acc[i][j][r];
+            }
+}
+
 // 128 x 64 block (wave tile 64 x 32): twice the workgroups of the 128 x 128 form at the same problem size, 18 DMA pieces per K-step
 template <int DUMMY>
 __global__ __launch_bounds__(256) void gemm_x3_n64(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M,
@@ -273,6 +355,41 @@ void run64(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int taps, i
            maxerr, maxerr / scale, ms / reps * 1e3, fl / (ms * 1e-3) / 1e12);
 }
 
+void runsr(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int T, int Tp, int B, int nstream, const std::vector<float>& hw,
+           const std::vector<float>& hx, const char* name) {
+    const int taps = 1, pad = 0, halo = 1;
+    dim3 grid(M / 128, (T + 127) / 128, B);
+    const size_t lds = (size_t)2 * 2 * TILE;
+    hipLaunchKernelGGL(gemm_x3_sr, grid, dim3(256), lds, 0, Wp, Xp, Y, M, C / 8, taps, Tp, T, halo - pad);
+    (void)hipDeviceSynchronize();
+    std::vector<float> hy((size_t)M * T);
+    (void)hipMemcpy(hy.data(), Y + (size_t)(B - 1) * M * T, hy.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0, scale = 0;
+    const float* xb = hx.data() + (size_t)(B - 1) * C * T;
+    for (int m = 0; m < M; m += 37)
+        for (int n = 0; n < T; n += 53) {
+            double ref = 0;
+            for (int c = 0; c < C; ++c) ref += (double)hw[(size_t)m * C + c] * (double)xb[(size_t)c * T + n];
+            maxerr = fmax(maxerr, fabs(ref - hy[(size_t)m * T + n]));
+            scale = fmax(scale, fabs(ref));
+        }
+    hipStream_t st[2]; (void)hipStreamCreate(&st[0]); (void)hipStreamCreate(&st[1]);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i)
+        for (int k = 0; k < nstream; ++k)
+            hipLaunchKernelGGL(gemm_x3_sr, grid, dim3(256), lds, nstream > 1 ? st[k] : 0, Wp, Xp + (size_t)k * B * (C / 8) * 3 * Tp,
+                               Y + (size_t)k * B * M * T, M, C / 8, taps, Tp, T, halo - pad);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double fl = 2.0 * M * C * taps * (double)T * B * reps * nstream;
+    printf("%-28s taps %d B %2d x%d stream  max err %.3e (rel %.2e)  %7.1f us/launch-set  %6.1f TFLOP/s fp32-equivalent\n", name, taps, B, nstream,
+           maxerr, maxerr / scale, ms / reps * 1e3, fl / (ms * 1e-3) / 1e12);
+}
+
 int main() {
     const int M = 768, C = 768, T = 936, B = 16, Tp = 8 * 128 + 2;
     const bool zero_data = getenv("ZERO") != nullptr;
@@ -299,8 +416,12 @@ int main() {
         (void)hipMalloc(&Wp, wp.size() * 2); (void)hipMalloc(&Xp, xp.size() * 2); (void)hipMalloc(&Y, (size_t)B * M * T * 4);
         (void)hipMemcpy(Wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(Xp, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
-        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, zero_data ? "full kernel, ZERO operands" : "full kernel, random operands");
-        run<2, 0, 15>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, zero_data ? "MFMA stream only, ZERO operands" : "MFMA stream only, random operands");
+        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 16, 1, hw, hx, "current loop");
+        runsr(Wp, Xp, Y, M, C, T, Tp, 16, 1, hw, hx, "strength-reduced loop");
+        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 1, hw, hx, "current loop");
+        runsr(Wp, Xp, Y, M, C, T, Tp, 8, 1, hw, hx, "strength-reduced loop");
+        run<2, 0, 0>(Wp, Xp, Y, M, C, taps, T, Tp, 8, 2, hw, hx, "current loop");
+        runsr(Wp, Xp, Y, M, C, T, Tp, 8, 2, hw, hx, "strength-reduced loop");
         (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
     }
     return 0;
