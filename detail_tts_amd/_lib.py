@@ -54,6 +54,17 @@ SIGNATURES = {
     "dtts_profile_report": (C.c_int, [C.POINTER(DttsKernelStat), C.c_int]),
     "dtts_gpt_generate": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int,
                                     C.POINTER(DttsGptOptions), c_int_p, c_int_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dtts_gpt_prefill": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int,
+                                   C.POINTER(DttsGptOptions), C.c_void_p, C.c_int, C.c_void_p]),
+    "dtts_gpt_decode_step": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dtts_gpt_decode": (C.c_int, [C.c_void_p, C.c_int, c_int_p, C.c_void_p]),
+    "dtts_gpt_steps": (C.c_int, [C.c_void_p]),
+    "dtts_gpt_all_finished": (C.c_int, [C.c_void_p, c_int_p, C.c_void_p]),
+    "dtts_gpt_finish": (C.c_int, [C.c_void_p, c_int_p, c_int_p, C.c_void_p]),
+    "dtts_op_sample_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                        C.c_float, C.c_float, c_int_p, C.c_void_p]),
+    "dtts_diff_p_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_ulonglong, c_int_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "dtts_gpt_latents": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int,
                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_diff_conditioning": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -63,6 +74,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_vocoder": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_float, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dtts_vocoder_stream": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_float, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_mel_style": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_attention_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

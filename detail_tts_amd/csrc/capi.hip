@@ -141,6 +141,57 @@ int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens,
     DTTS_API_END(h)
 }
 
+int dtts_gpt_prefill(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
+                     int Lt_max, int B, const dtts_gpt_options* opts, float* latents_cm, int lat_stride, void* stream) {
+    DTTS_API_BEGIN
+    DTTS_REQUIRE(opts && opts->sample_ids, "options");
+    h->m->gpt_prefill(refer, refer_lens, Tr, text, text_lens, Lt_max, B, *opts, latents_cm, lat_stride, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_gpt_decode_step(dtts_handle* h, void* stream) {
+    DTTS_API_BEGIN
+    h->m->gpt_decode_step((hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_gpt_decode(dtts_handle* h, int n_steps, int* n_done, void* stream) {
+    DTTS_API_BEGIN
+    const int n = h->m->gpt_decode(n_steps, (hipStream_t)stream);
+    if (n_done) *n_done = n;
+    DTTS_API_END(h)
+}
+
+int dtts_gpt_steps(dtts_handle* h) { return h ? h->m->gpt_steps() : 0; }
+
+int dtts_gpt_all_finished(dtts_handle* h, int* all_finished, void* stream) {
+    DTTS_API_BEGIN
+    DTTS_REQUIRE(all_finished, "all_finished");
+    *all_finished = h->m->gpt_all_finished((hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_gpt_finish(dtts_handle* h, int* codes_out, int* ncodes_out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->gpt_finish(codes_out, ncodes_out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_sample_logits(dtts_handle* h, const float* logits, int R, int V, const int* history, int hist_len, const float* uniforms,
+                          int top_k, float top_p, float temperature, float repetition_penalty, int* tokens_out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_sample_logits(logits, R, V, history, hist_len, uniforms, top_k, top_p, temperature, repetition_penalty, tokens_out,
+                           (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_diff_p_sample(dtts_handle* h, float* x, const float* code_emb, const int* lens, int B, int T, int step,
+                       unsigned long long seed, const int* sample_ids, const float* noise, float* x0_out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->diff_p_sample(x, code_emb, lens, B, T, step, seed, sample_ids, noise, x0_out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_gpt_latents(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
                      int Lt_max, const int* codes, const int* ncodes, int n_max, int B, float* latents_cm, int lat_stride,
                      void* stream) {
@@ -182,6 +233,14 @@ int dtts_vocoder(dtts_handle* h, const float* mel, const int* lens, int B, int T
                  float noise_scale, const float* noise_override, float* wav, float* trace_z, void* stream) {
     DTTS_API_BEGIN
     h->m->vocoder(mel, lens, B, T, seed, sample_ids, noise_scale, noise_override, wav, trace_z, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_vocoder_stream(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
+                        float noise_scale, const float* noise_override, int chunk_frames, float* wav, void* stream) {
+    DTTS_API_BEGIN
+    DTTS_REQUIRE(chunk_frames >= 16, "chunk_frames must be >= 16");
+    h->m->vocoder(mel, lens, B, T, seed, sample_ids, noise_scale, noise_override, wav, nullptr, (hipStream_t)stream, chunk_frames);
     DTTS_API_END(h)
 }
 

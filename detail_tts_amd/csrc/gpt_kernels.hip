@@ -46,185 +46,119 @@ __device__ __forceinline__ void block_ln_256(float* v, int n_per, int C, const f
     }
 }
 
-__global__ __launch_bounds__(256) void vec_layernorm_kernel(const float* x, const float* g1, const float* b1, const float* g2,
-                                                            const float* b2, float* y, int C, float* col_dst, long long col_bs,
-                                                            int col_cs, int col) {
+// ------------------------------------------------------------------------------------------ decode step (graph-capturable)
+// Every value that changes from token to token or from call to call lives in the device-side GptCtl block: a decode step is a
+// fixed sequence of kernel launches with fixed arguments, so it can be captured once in a hipGraph and replayed.
+//
+// Per layer FIVE launches (the LayerNorms and the split-K finishes live in the consumers' prologues):
+//   K1 c_attn GEMV   in: X = res + bias + sum(partials of the previous c_proj(mlp)) -> writes X and its rows' (sum, sum sq);  W (gamma . X)
+//   K2 attention     q/k/v = LN-algebra finish of K1's partials, KV append, softmax(q K) V
+//   K3 c_proj GEMV   in: attention output
+//   K4 c_fc GEMV     in: Y = X + bias + sum(K3 partials)                             -> writes Y and its statistics;           W (gamma . Y)
+//   K5 c_proj(mlp)   in: gelu(LN-algebra finish of K4's partials)
+// LN algebra: W^T LN(y) = r (W^T (gamma . y) - mu c) + d with c = W^T gamma, d = W^T beta + bias (precomputed at bind time,
+// launch_ln_fold_vectors), r = rstd, mu = mean: the GEMV never needs the row statistics, its CONSUMER applies them as two scalars
+// per row.  Only the order of fp32 sums changes; nothing is approximated.
+
+// (mean, rstd) of row b from the per-slice partial sums st[slice][B][2]
+__device__ __forceinline__ void ln_row_stats(const float* __restrict__ st, int nsl, int B, int b, int K, float& mean, float& rstd) {
+    float S = 0.f, Q = 0.f;
+    for (int i = 0; i < nsl; ++i) { S += st[((long long)i * B + b) * 2]; Q += st[((long long)i * B + b) * 2 + 1]; }
+    mean = S / (float)K;
+    rstd = rsqrtf(fmaxf(Q / (float)K - mean * mean, 0.f) + 1e-5f);
+}
+
+// sum over split-K slices of element (b, k): 4 independent loads per round
+__device__ __forceinline__ float sum_parts(const float* __restrict__ parts, int nsl, long long slice_stride, long long off) {
+    const float* p = parts + off;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sl = 0;
+    for (; sl + 4 <= nsl; sl += 4) {
+        const float v0 = p[0], v1 = p[slice_stride], v2 = p[2 * slice_stride], v3 = p[3 * slice_stride];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        p += 4 * slice_stride;
+    }
+    for (; sl < nsl; ++sl) { a0 += p[0]; p += slice_stride; }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// final LayerNorms of a token: h = res + bias + sum(partials) ; lat = final_norm(ln_f(h)) -> lat[b][C] and latents[b, :, step]
+__global__ __launch_bounds__(256) void gpt_final_ln_kernel(const float* res, const float* bias, const float* parts, int in_slices, int in_stride,
+                                                           int B, const float* g1, const float* b1, const float* g2, const float* b2,
+                                                           float* y, int C, const GptCtl* ctl) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     float v[8];
     const int n_per = (C + 255) / 256;
     for (int i = 0; i < n_per; ++i) {
         const int c = tid + i * 256;
-        v[i] = c < C ? x[(long long)b * C + c] : 0.f;
+        float a = 0.f;
+        if (c < C) {
+            a = res[(long long)b * C + c] + (bias ? bias[c] : 0.f);
+            if (in_slices) a += sum_parts(parts, in_slices, (long long)B * in_stride, (long long)b * in_stride + c);
+        }
+        v[i] = a;
     }
     block_ln_256(v, n_per, C, g1, b1, red);
-    if (g2) block_ln_256(v, n_per, C, g2, b2, red);
+    block_ln_256(v, n_per, C, g2, b2, red);
+    const int step = ctl->step[b];
+    float* col = (ctl->latents && step < ctl->max_steps) ? ctl->latents + (long long)b * ctl->lat_bs + step : nullptr;
     for (int i = 0; i < n_per; ++i) {
         const int c = tid + i * 256;
         if (c < C) {
             y[(long long)b * C + c] = v[i];
-            if (col_dst) col_dst[(long long)b * col_bs + (long long)c * col_cs + col] = v[i];     // latents[b, :, step]
+            if (col) col[(long long)c * ctl->lat_cs] = v[i];
         }
     }
 }
 
-void launch_vec_layernorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, hipStream_t s) {
-    DTTS_REQUIRE(C <= 2048, "vec_layernorm width");
-    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, gamma, beta, nullptr, nullptr, y, C, nullptr, 0, 0, 0);
+void launch_gpt_final_ln(const float* res, const float* bias, const float* parts, int in_slices, int in_stride, int B, const float* g1,
+                         const float* b1, const float* g2, const float* b2, float* y, int C, const GptCtl* ctl, hipStream_t s) {
+    DTTS_REQUIRE(C <= 2048, "final LayerNorm width");
+    hipLaunchKernelGGL(gpt_final_ln_kernel, dim3(B), dim3(256), 0, s, res, bias, parts, in_slices, in_stride, B, g1, b1, g2, b2, y, C, ctl);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-void launch_vec_layernorm2(const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float* y, int B, int C,
-                           hipStream_t s, float* col_dst, long long col_bs, int col_cs, int col) {
-    DTTS_REQUIRE(C <= 2048, "vec_layernorm width");
-    hipLaunchKernelGGL(vec_layernorm_kernel, dim3(B), dim3(256), 0, s, x, g1, b1, g2, b2, y, C, col_dst, col_bs, col_cs, col);
+// c[n] = sum_k gamma[k] W[k][n] ; d[n] = sum_k beta[k] W[k][n] + bias[n]   (bind time; fixed summation order)
+__global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ W, int K, int CoutP, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias,
+                                                              float* __restrict__ c, float* __restrict__ d) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= CoutP) return;
+    float sc = 0.f, sd = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float w = W[(long long)k * CoutP + n];
+        sc += gamma[k] * w;
+        sd += beta[k] * w;
+    }
+    c[n] = sc;
+    d[n] = sd + (bias ? bias[n] : 0.f);
+}
+
+void launch_ln_fold_vectors(const float* W, int K, int CoutP, const float* gamma, const float* beta, const float* bias, float* c, float* d,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(ln_fold_vectors_kernel, dim3(cdiv(CoutP, 256)), dim3(256), 0, s, W, K, CoutP, gamma, beta, bias, c, d);
     DTTS_CHECK_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------ skinny GEMM
-int gemv_slices(int K, int CoutP) {
-    const int colblocks = cdiv(CoutP, 256);
-    int s = 768 / colblocks;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;                       // bounded so the finish stage reads few partials
-    if (s > K / 8) s = K / 8 > 0 ? K / 8 : 1;
-    return s;
-}
-
-// LN != 0: the input rows are LayerNorm'ed on the fly, x' = (x - mean_b) * rstd_b * gamma_i + beta_i, with (mean, rstd) rebuilt
-// from the per-block partial sums (sum, sum of squares) that the producing finish kernel left in `stats[b][nblk][2]`.
-template <int NB, int LN>
-__global__ __launch_bounds__(64) void gemv_partial_kernel(const float* __restrict__ W, int K, int CoutP, const float* __restrict__ x,
-                                                          int x_stride, int B, float* __restrict__ part, int rows_per_slice,
-                                                          const float* __restrict__ stats, int nblk, const float* __restrict__ gam,
-                                                          const float* __restrict__ bet) {
-    const int lane = threadIdx.x;
-    const int col = blockIdx.x * 256 + lane * 4;
-    const int k0 = blockIdx.y * rows_per_slice;
-    const int k1 = min(K, k0 + rows_per_slice);
-    float mean[NB], rstd[NB];
-    if (LN) {   // lane k holds partial k of every row; one wave reduction per row (fixed order -> deterministic)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int bb = b < B ? b : B - 1;
-            float S = 0.f, Q = 0.f;
-            if (lane < nblk) { S = stats[((long long)bb * nblk + lane) * 2]; Q = stats[((long long)bb * nblk + lane) * 2 + 1]; }
-            S = wsum(S);
-            Q = wsum(Q);
-            const float m = S / (float)K;
-            mean[b] = m;
-            rstd[b] = rsqrtf(fmaxf(Q / (float)K - m * m, 0.f) + 1e-5f);
-        }
-    }
-    // LN: normalise this slice's input rows once into LDS (rows_per_slice <= 64), then stream the weights
-    __shared__ float xs[LN ? NB : 1][LN ? 64 : 1];
-    if (LN) {
-        const int nrow = k1 - k0;
-        for (int e = lane; e < NB * nrow; e += 64) {
-            const int b = e / nrow, i = e - b * nrow;
-            const int bb = b < B ? b : B - 1;
-            // mean/rstd live in registers indexed by the compile-time row id: select without dynamic indexing
-            float m = 0.f, r = 0.f;
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-                if (q == b) { m = mean[q]; r = rstd[q]; }
-            xs[b][i] = (x[(long long)bb * x_stride + k0 + i] - m) * r * gam[k0 + i] + bet[k0 + i];
-        }
-        __syncthreads();
-    }
-    float4 acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* wp = W + (long long)k0 * CoutP + col;
-    int i = k0;
-    if (col < CoutP) {
-    for (; i + 4 <= k1; i += 4) {
-        float4 w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (long long)u * CoutP);
-        wp += 4LL * CoutP;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float* xr = x + (long long)(b < B ? b : B - 1) * x_stride + i;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float xv = LN ? xs[b][i - k0 + u] : xr[u];
-                acc[b].x += w[u].x * xv; acc[b].y += w[u].y * xv; acc[b].z += w[u].z * xv; acc[b].w += w[u].w * xv;
-            }
-        }
-    }
-    for (; i < k1; ++i) {
-        const float4 w = *reinterpret_cast<const float4*>(wp);
-        wp += CoutP;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float xv = LN ? xs[b][i - k0] : x[(long long)(b < B ? b : B - 1) * x_stride + i];
-            acc[b].x += w.x * xv; acc[b].y += w.y * xv; acc[b].z += w.z * xv; acc[b].w += w.w * xv;
-        }
-    }
-    }
-    if (col >= CoutP) return;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (b < B) *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * B + b) * CoutP + col) = acc[b];
-}
-
-template <int LN>
-static void gemv_partial_dispatch(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices,
-                                  const float* stats, int nblk, const float* gam, const float* bet, hipStream_t s) {
-    const int rps = cdiv(K, slices);
-    dim3 grid(cdiv(CoutP, 256), slices);
-    if (B <= 1) hipLaunchKernelGGL((gemv_partial_kernel<1, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
-    else if (B <= 4) hipLaunchKernelGGL((gemv_partial_kernel<4, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
-    else if (B <= 8) hipLaunchKernelGGL((gemv_partial_kernel<8, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
-    else hipLaunchKernelGGL((gemv_partial_kernel<16, LN>), grid, dim3(64), 0, s, W, K, CoutP, x, x_stride, B, part, rps, stats, nblk, gam, bet);
-    DTTS_CHECK_HIP(hipGetLastError());
-}
-
-void launch_gemv_partial(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices, hipStream_t s) {
-    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && CoutP % 4 == 0, "gemv shape");
-    DTTS_REQUIRE((long long)slices * CoutP <= 262144, "gemv partial scratch");
-    gemv_partial_dispatch<0>(W, K, CoutP, x, x_stride, B, part, slices, nullptr, 0, nullptr, nullptr, s);
-}
-
-void launch_gemv_partial_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, int slices,
-                            const float* stats, int nblk, const float* gamma, const float* beta, hipStream_t s) {
-    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && CoutP % 4 == 0, "gemv shape");
-    DTTS_REQUIRE((long long)slices * CoutP <= 262144, "gemv partial scratch");
-    DTTS_REQUIRE(cdiv(K, slices) <= 64, "LN prologue slice too long");
-    gemv_partial_dispatch<1>(W, K, CoutP, x, x_stride, B, part, slices, stats, nblk, gamma, beta, s);
 }
 
 // ------------------------------------------------------------------------------------------ block GEMV (decode)
-// One 512-thread workgroup = 8 waves x 16 weight rows x 256 columns: every lane issues its 16 float4 weight loads up front
-// (16 KiB per wave, >= 768 waves per GEMV -> > 8 MiB in flight, what HBM needs), the 8 waves' partial sums are combined through
-// LDS, and a workgroup leaves ONE partial per 128 input rows (K/128 slices instead of K/64 one-wave slices: 8x less partial
-// traffic, no 1-wave workgroups).  The input prologue folds what used to be separate kernels:
-//   GP_PLAIN  x[b][k] as is
-//   GP_LN     LayerNorm on the fly from the producer's per-block (sum, sum sq) statistics
-//   GP_PARTS  x[b][k] = act(sum_slices parts[sl][b][k] + bias[k])      (the previous GEMV's finish: c_fc -> gelu -> c_proj)
-enum { GP_PLAIN = 0, GP_LN = 1, GP_PARTS = 2 };
-struct GemvIn {
-    const float* x = nullptr;
-    int x_stride = 0;
-    const float* stats = nullptr;
-    int nblk = 0;
-    const float* gamma = nullptr;
-    const float* beta = nullptr;
-    const float* parts = nullptr;
-    int in_slices = 0, in_stride = 0, in_act = 0;
-    const float* in_bias = nullptr;
-};
-
-// VEC = columns per lane: 4 (256-column workgroups, 16-byte loads) for the wide projections; 1 (64-column workgroups) when the
-// wide form would leave most of the chip idle (the 768-column projections: 3 column groups x K/128 slices = 18..72 workgroups).
+// One 512-thread workgroup = 8 waves x RPW weight rows x (64 VEC) columns: every lane issues its weight loads up front (16 KiB per
+// wave, >= 768 waves per GEMV -> > 8 MiB in flight, what HBM needs), the 8 waves' partial sums are combined through LDS, and a
+// workgroup leaves ONE partial per RB = 8 RPW input rows (split-K slices; the consumer sums them).  Input prologues:
+//   GP_PLAIN   x[b][k] as is
+//   GP_RESSUM  v = res[b][k] + in_bias[k] + sum_slices parts[sl][b][k]  (the residual stream = the previous GEMV's finish); the
+//              column-block-0 workgroups store v to y_out and their rows' (sum, sum sq) to stats_out[slice][b]; GEMV input gamma[k] v
+//   GP_LNPARTS v = act(r_b (sum_slices parts[sl][b][k] - mu_b c[k]) + d[k]) with (mu_b, r_b) from stats_in: the LN-algebra finish
+//              of the producing GEMV (c_fc) + GELU
 template <int PRO, int VEC, int RPW>
 __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict__ W, int K, int CoutP, GemvIn in, int B,
                                                          float* __restrict__ part) {
     constexpr int NB = 8, RB = 8 * RPW;                 // RPW weight rows per wave, RB input rows per workgroup (= one partial slice)
+    static_assert(RB == 64 || RB == 128, "a row's RB values must be one or two whole waves");
     __shared__ __attribute__((aligned(16))) float xs[NB][RB];
     __shared__ __attribute__((aligned(16))) float red[8][4][64][VEC];
     __shared__ float smr[NB][2];
+    __shared__ float sst[NB][2][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = blockIdx.x * (64 * VEC) + lane * VEC;
     const int k0 = blockIdx.y * RB;
@@ -243,33 +177,44 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
             }
         }
     }
-    if (PRO == GP_LN) {
-        // wave b rebuilds (mean, rstd) of row b from the producer's per-block partial sums (fixed order -> deterministic)
-        const int bb = wave < B ? wave : B - 1;
-        float S = 0.f, Q = 0.f;
-        if (lane < in.nblk) { S = in.stats[((long long)bb * in.nblk + lane) * 2]; Q = in.stats[((long long)bb * in.nblk + lane) * 2 + 1]; }
-        S = wsum(S);
-        Q = wsum(Q);
-        const float m = S / (float)K;
-        if (lane == 0) { smr[wave][0] = m; smr[wave][1] = rsqrtf(fmaxf(Q / (float)K - m * m, 0.f) + 1e-5f); }
+    if (PRO == GP_LNPARTS) {
+        if (tid < NB) {
+            float m = 0.f, r = 0.f;
+            if (tid < B) ln_row_stats(in.stats_in, in.stats_slices, B, tid, in.K_ln, m, r);
+            smr[tid][0] = m;
+            smr[tid][1] = r;
+        }
         __syncthreads();
     }
+    const bool lead = PRO == GP_RESSUM && blockIdx.x == 0;       // this workgroup also publishes the residual rows + statistics
+    const long long pstride = (long long)B * in.in_stride;
 #pragma unroll
     for (int e0 = 0; e0 < NB * RB; e0 += 512) {
-        if (e0 + tid >= NB * RB) break;
-        const int e = e0 + tid, b = e / RB, i = e % RB, bb = b < B ? b : B - 1, k = k0 + i;
+        const int e = e0 + tid, b = e / RB, i = e % RB, bb = b < B ? b : B - 1, k = k0 + i;   // a wave never straddles two rows
         float v;
-        if (PRO == GP_PARTS) {
-            v = in.in_bias ? in.in_bias[k] : 0.f;
-            for (int sl = 0; sl < in.in_slices; ++sl) v += in.parts[((long long)sl * B + bb) * in.in_stride + k];
-            v = act_apply(v, in.in_act, 0.f);
+        if (PRO == GP_LNPARTS) {
+            const float a = sum_parts(in.parts, in.in_slices, pstride, (long long)bb * in.in_stride + k);
+            v = act_apply(smr[bb][1] * (a - smr[bb][0] * in.fold_c[k]) + in.fold_d[k], in.in_act, 0.f);
+        } else if (PRO == GP_RESSUM) {
+            v = in.x[(long long)bb * in.x_stride + k] + (in.in_bias ? in.in_bias[k] : 0.f);
+            if (in.in_slices) v += sum_parts(in.parts, in.in_slices, pstride, (long long)bb * in.in_stride + k);
+            if (lead) {
+                if (b < B) in.y_out[(long long)b * K + k] = v;
+                const float s1 = wsum(v), s2 = wsum(v * v);           // fixed order -> deterministic
+                if (lane == 0) { sst[b][RB == 128 ? (wave & 1) : 0][0] = s1; sst[b][RB == 128 ? (wave & 1) : 0][1] = s2; }
+            }
+            v *= in.gamma[k];
         } else {
             v = in.x[(long long)bb * in.x_stride + k];
-            if (PRO == GP_LN) v = (v - smr[b][0]) * smr[b][1] * in.gamma[k] + in.beta[k];
         }
         xs[b][i] = v;
     }
     __syncthreads();
+    if (lead && tid < B) {
+        float* st = in.stats_out + ((long long)blockIdx.y * B + tid) * 2;
+        st[0] = RB == 128 ? sst[tid][0][0] + sst[tid][1][0] : sst[tid][0][0];
+        st[1] = RB == 128 ? sst[tid][0][1] + sst[tid][1][1] : sst[tid][0][1];
+    }
     float acc[NB][VEC];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -318,8 +263,8 @@ template <int VEC, int RPW>
 static void gemv_block_launch_v(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
     const dim3 grid(cdiv(CoutP, 64 * VEC), K / (8 * RPW));
     if (pro == GP_PLAIN) hipLaunchKernelGGL((gemv_block_kernel<GP_PLAIN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else if (pro == GP_LN) hipLaunchKernelGGL((gemv_block_kernel<GP_LN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else hipLaunchKernelGGL((gemv_block_kernel<GP_PARTS, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else if (pro == GP_RESSUM) hipLaunchKernelGGL((gemv_block_kernel<GP_RESSUM, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else hipLaunchKernelGGL((gemv_block_kernel<GP_LNPARTS, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
 }
 
 // Workgroup shape per GEMV: enough workgroups to put one on most CUs.  Wide (256-column, 16-byte loads) when that already yields
@@ -335,233 +280,46 @@ static bool gemv_wide(int K, int CoutP) {
     return force ? force == 4 : (long long)cdiv(CoutP, 256) * (K / 128) >= 192;
 }
 
-static void gemv_block_launch(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
-    DTTS_REQUIRE(B >= 1 && B <= 8 && K % 128 == 0 && CoutP % 4 == 0, "gemv_block shape");
+int gemv_block_slices(int K, int CoutP) { return gemv_wide(K, CoutP) ? K / 128 : K / gemv_rows(K, CoutP); }
+
+void launch_gemv_block(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
+    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && K % 128 == 0 && CoutP % 4 == 0, "gemv_block shape");
     const int rows = gemv_rows(K, CoutP);
-    DTTS_REQUIRE((long long)(K / rows) * CoutP * B <= 8LL * 262144, "gemv partial scratch");
+    DTTS_REQUIRE((long long)(K / rows) * CoutP * B <= (long long)GEMV_PART_FLOATS * GEMV_MAXB, "gemv partial scratch");
     if (gemv_wide(K, CoutP)) gemv_block_launch_v<4, 16>(pro, W, K, CoutP, in, B, part, s);
     else if (rows == 64) gemv_block_launch_v<1, 8>(pro, W, K, CoutP, in, B, part, s);
     else gemv_block_launch_v<1, 16>(pro, W, K, CoutP, in, B, part, s);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-int gemv_block_slices(int K, int CoutP) { return gemv_wide(K, CoutP) ? K / 128 : K / gemv_rows(K, CoutP); }
-
-void launch_gemv_block(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, hipStream_t s) {
-    GemvIn in;
-    in.x = x;
-    in.x_stride = x_stride;
-    gemv_block_launch(GP_PLAIN, W, K, CoutP, in, B, part, s);
-}
-
-void launch_gemv_block_ln(const float* W, int K, int CoutP, const float* x, int x_stride, int B, float* part, const float* stats,
-                          int nblk, const float* gamma, const float* beta, hipStream_t s) {
-    DTTS_REQUIRE(nblk <= 64, "LN statistics blocks");
-    GemvIn in;
-    in.x = x;
-    in.x_stride = x_stride;
-    in.stats = stats;
-    in.nblk = nblk;
-    in.gamma = gamma;
-    in.beta = beta;
-    gemv_block_launch(GP_LN, W, K, CoutP, in, B, part, s);
-}
-
-void launch_gemv_block_parts(const float* W, int K, int CoutP, const float* parts_in, int in_slices, int in_stride, const float* in_bias,
-                             int in_act, int B, float* part, hipStream_t s) {
-    GemvIn in;
-    in.parts = parts_in;
-    in.in_slices = in_slices;
-    in.in_stride = in_stride;
-    in.in_bias = in_bias;
-    in.in_act = in_act;
-    gemv_block_launch(GP_PARTS, W, K, CoutP, in, B, part, s);
-}
-
-// y[b] = sum_slices part + bias + res[b];  hn[b] = LayerNorm(y[b])  — one 256-thread block per row (C <= 1024)
-__global__ __launch_bounds__(256) void gemv_finish_res_ln_kernel(const float* part, int slices, int B, int C, int CoutP,
-                                                                 const float* bias, const float* res, float* y, const float* g1,
-                                                                 const float* b1, const float* g2, const float* b2, float* hn) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float v[4];
-    const int n_per = (C + 255) / 256;
-    for (int i = 0; i < n_per; ++i) {
-        const int c = tid + i * 256;
-        float a = 0.f;
-        if (c < C) {
-            a = bias[c] + res[(long long)b * C + c];
-            for (int sl = 0; sl < slices; ++sl) a += part[((long long)sl * B + b) * CoutP + c];
-            y[(long long)b * C + c] = a;
-        }
-        v[i] = a;
-    }
-    block_ln_256(v, n_per, C, g1, b1, red);
-    if (g2) block_ln_256(v, n_per, C, g2, b2, red);
-    for (int i = 0; i < n_per; ++i) {
-        const int c = tid + i * 256;
-        if (c < C) hn[(long long)b * C + c] = v[i];
-    }
-}
-
-void launch_gemv_finish_res_ln(const float* part, int slices, int B, int C, int CoutP, const float* bias, const float* res, float* y,
-                               const float* g1, const float* b1, const float* g2, const float* b2, float* hn, hipStream_t s) {
-    DTTS_REQUIRE(C <= 1024, "finish_res_ln width");
-    hipLaunchKernelGGL(gemv_finish_res_ln_kernel, dim3(B), dim3(256), 0, s, part, slices, B, C, CoutP, bias, res, y, g1, b1, g2, b2, hn);
-    DTTS_CHECK_HIP(hipGetLastError());
-}
-
-// finish: 64 columns x 4 slice-groups per 256-thread block; group g sums slices g, g+4, ... then an LDS combine.
-__device__ __forceinline__ float finish_sum(const float* part, int slices, int B, int CoutP, int b, int col, float* red) {
-    const int g = threadIdx.x >> 6;
-    float v = 0.f;
-    for (int sl = g; sl < slices; sl += 4) v += part[((long long)sl * B + b) * CoutP + col];
-    red[threadIdx.x] = v;
-    __syncthreads();
-    return red[threadIdx.x & 63] + red[64 + (threadIdx.x & 63)] + red[128 + (threadIdx.x & 63)] + red[192 + (threadIdx.x & 63)];
-}
-
-__global__ __launch_bounds__(256) void gemv_finish_kernel(const float* part, int slices, int B, int Cout, int CoutP, const float* bias,
-                                                          int act, const float* res, int res_stride, float* y, int y_stride,
-                                                          float* stats) {
-    __shared__ float red[256];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y;
-    const int colc = col < CoutP ? col : CoutP - 1;
-    float v = finish_sum(part, slices, B, CoutP, b, colc, red);
-    if (threadIdx.x >= 64) return;
-    const bool ok = col < Cout;
-    if (ok) {
-        if (bias) v += bias[col];
-        v = act_apply(v, act, 0.f);
-        if (res) v += res[(long long)b * res_stride + col];
-        y[(long long)b * y_stride + col] = v;
-    } else v = 0.f;
-    if (stats) {            // per-block partial sums for the consumer's fused LayerNorm
-        const float s1 = wsum(v), s2 = wsum(v * v);
-        if (threadIdx.x == 0) {
-            float* st = stats + ((long long)b * gridDim.x + blockIdx.x) * 2;
-            st[0] = s1;
-            st[1] = s2;
-        }
-    }
-}
-
-void launch_gemv_finish(const float* part, int slices, int B, int Cout, int CoutP, const float* bias, int act, const float* res,
-                        int res_stride, float* y, int y_stride, hipStream_t s, float* ln_stats) {
-    hipLaunchKernelGGL(gemv_finish_kernel, dim3(cdiv(Cout, 64), B), dim3(256), 0, s, part, slices, B, Cout, CoutP, bias, act, res,
-                       res_stride, y, y_stride, ln_stats);
-    DTTS_CHECK_HIP(hipGetLastError());
-}
-
-// cache layout per (layer, sample): K [C][cap] (channel-major, keys contiguous) then V [cap][C] (token-major)
-__global__ __launch_bounds__(256) void gemv_finish_qkv_kernel(const float* part, int slices, int B, int C, int CoutP, const float* bias,
-                                                              float* qbuf, float* cache, long long cache_bs, int cap, const int* pos) {
-    __shared__ float red[256];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y;
-    float v = finish_sum(part, slices, B, CoutP, b, col < CoutP ? col : CoutP - 1, red);
-    if (threadIdx.x >= 64 || col >= 3 * C) return;
-    v += bias[col];
-    float* cb = cache + (long long)b * cache_bs;
-    if (col < C) qbuf[(long long)b * C + col] = v;
-    else if (col < 2 * C) cb[(long long)(col - C) * cap + pos[b]] = v;
-    else cb[(long long)C * cap + (long long)pos[b] * C + (col - 2 * C)] = v;
-}
-
-void launch_gemv_finish_qkv(const float* part, int slices, int B, int C, int CoutP, const float* bias, float* qbuf, float* cache,
-                            long long cache_bs, int cache_cs, const int* pos, hipStream_t s) {
-    hipLaunchKernelGGL(gemv_finish_qkv_kernel, dim3(cdiv(3 * C, 64), B), dim3(256), 0, s, part, slices, B, C, CoutP, bias, qbuf, cache,
-                       cache_bs, cache_cs, pos);
-    DTTS_CHECK_HIP(hipGetLastError());
-}
-
 // ------------------------------------------------------------------------------------------ decode attention
-template <int D>
-__global__ __launch_bounds__(256) void decode_attention_kernel(const float* qbuf, const float* cache, long long cache_bs, int cap,
-                                                               const int* klen, int H, float* out) {
-    extern __shared__ float sc[];            // [cap] scores / probabilities
-    __shared__ float red[4];
-    __shared__ float part[4][D];
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = H * D;
-    const int n = klen[b];
-    const float* kp = cache + (long long)b * cache_bs + (long long)(h * D) * cap;       // K [C][cap]
-    const float* vp = cache + (long long)b * cache_bs + (long long)C * cap + h * D;      // V [cap][C]
-    float q[D];
-    const float scale = rsqrtf((float)D);
-#pragma unroll
-    for (int c = 0; c < D; ++c) q[c] = qbuf[(long long)b * C + h * D + c] * scale;
-    float mx = -INFINITY;
-    for (int s = tid; s < n; s += 256) {
-        float kv[D];
-#pragma unroll
-        for (int c = 0; c < D; ++c) kv[c] = kp[(long long)c * cap + s];      // D independent coalesced loads in flight
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int c = 0; c < D; c += 4) { a0 += q[c] * kv[c]; a1 += q[c + 1] * kv[c + 1]; a2 += q[c + 2] * kv[c + 2]; a3 += q[c + 3] * kv[c + 3]; }
-        const float a = (a0 + a1) + (a2 + a3);
-        sc[s] = a;
-        mx = fmaxf(mx, a);
-    }
-    mx = wmax(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float l = 0.f;
-    for (int s = tid; s < n; s += 256) {
-        const float pr = expf(sc[s] - mx);
-        sc[s] = pr;
-        l += pr;
-    }
-    l = wsum(l);
-    if (lane == 0) red[wave] = l;
-    __syncthreads();
-    l = red[0] + red[1] + red[2] + red[3];
-    // PV: wave g takes keys g, g+4, ...; lanes = channels (token-major V rows are contiguous)
-    float o = 0.f;
-    if (lane < D) {
-        float o4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int s = wave;
-        for (; s + 28 < n; s += 32) {          // 8 keys in flight per lane
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o4[u] += sc[s + 4 * u] * vp[(long long)(s + 4 * u) * C + lane];
-        }
-        for (; s < n; s += 4) o4[0] += sc[s] * vp[(long long)s * C + lane];
-        o = ((o4[0] + o4[1]) + (o4[2] + o4[3])) + ((o4[4] + o4[5]) + (o4[6] + o4[7]));
-    }
-    if (lane < D) part[wave][lane] = o;
-    __syncthreads();
-    if (tid < D) out[(long long)b * C + h * D + tid] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / l;
-}
-
-void launch_decode_attention(const float* qbuf, const float* cache, long long cache_bs, int cache_cs, const int* klen, int B, int H,
-                             int D, float* out, hipStream_t s) {
-    DTTS_REQUIRE(D == 48, "decode attention head dim");
-    hipLaunchKernelGGL(decode_attention_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, qbuf, cache, cache_bs, cache_cs,
-                       klen, H, out);
-    DTTS_CHECK_HIP(hipGetLastError());
-}
-
-// Same attention with c_attn's finish folded in: the workgroup of (head, sample) sums the qkv GEMV partials of its own 3*D
-// columns (+ bias), appends k and v to the cache for the later steps and uses them from LDS for this one.
+// cache layout per (layer, sample): K [C][cap] (channel-major, keys contiguous) then V [cap][C] (token-major).
+// One workgroup per (head, sample).  c_attn's finish is folded in: the workgroup sums the qkv GEMV partials of its own 3*D columns,
+// applies the LayerNorm algebra (row statistics from the producing GEMV), appends k and v to the cache for the later steps and uses
+// them from LDS for this one.  The token position comes from the device-side control block.
 template <int D>
 __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* __restrict__ part, int slices, int B, int CoutP,
-                                                                   const float* __restrict__ bias, float* cache, long long cache_bs,
-                                                                   int cap, const int* pos, const int* klen, int H, float* out) {
+                                                                   const float* __restrict__ stats, int stats_slices,
+                                                                   const float* __restrict__ fold_c, const float* __restrict__ fold_d,
+                                                                   float* cache, long long cache_bs, int cap, const GptCtl* ctl, int H,
+                                                                   float* out) {
     extern __shared__ float sc[];            // [cap] scores / probabilities
     __shared__ float red[4];
     __shared__ float qkv_s[3][D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = H * D;
-    const int n = klen[b];                   // keys including the new one (at column pos[b] == n - 1)
+    const int n = ctl->lp[b] + ctl->step[b];      // keys including the new one, which sits at column n - 1
+    const int pos = n - 1;
     float* cb = cache + (long long)b * cache_bs;
     if (tid < 3 * D) {
         const int which = tid / D, c = tid - which * D, col = which * C + h * D + c;
-        float v = bias[col];
-        for (int sl = 0; sl < slices; ++sl) v += part[((long long)sl * B + b) * CoutP + col];
+        float mean, rstd;
+        ln_row_stats(stats, stats_slices, B, b, C, mean, rstd);
+        const float a = sum_parts(part, slices, (long long)B * CoutP, (long long)b * CoutP + col);
+        const float v = rstd * (a - mean * fold_c[col]) + fold_d[col];
         qkv_s[which][c] = v;
-        if (which == 1) cb[(long long)(h * D + c) * cap + pos[b]] = v;
-        else if (which == 2) cb[(long long)C * cap + (long long)pos[b] * C + h * D + c] = v;
+        if (which == 1) cb[(long long)(h * D + c) * cap + pos] = v;
+        else if (which == 2) cb[(long long)C * cap + (long long)pos * C + h * D + c] = v;
     }
     __syncthreads();
     const float* kp = cb + (long long)(h * D) * cap;       // K [C][cap]
@@ -645,11 +403,13 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
     }
 }
 
-void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* bias, float* cache, long long cache_bs,
-                                 int cache_cs, const int* pos, const int* klen, int B, int H, int D, float* out, hipStream_t s) {
+void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* stats, int stats_slices, const float* fold_c,
+                                 const float* fold_d, float* cache, long long cache_bs, int cache_cs, const GptCtl* ctl, int B, int H, int D,
+                                 float* out, hipStream_t s) {
     DTTS_REQUIRE(D == 48, "decode attention head dim");
-    hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, part, slices, B, CoutP, bias,
-                       cache, cache_bs, cache_cs, pos, klen, H, out);
+    DTTS_REQUIRE(sizeof(float) * (size_t)cache_cs <= 60 * 1024, "decode attention: KV cache too long for the LDS score buffer");
+    hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, part, slices, B, CoutP, stats,
+                       stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -781,24 +541,31 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     __shared__ int sh_i[4];
 
     const int tid = threadIdx.x, b = blockIdx.x, V = p.V;
+    GptCtl* ctl = p.ctl;
+    const int step = ctl->step[b];
+    if (step >= ctl->max_steps) return;                  // a replayed graph may run past the requested length: no-op
+    const int top_k = ctl->top_k;
+    const float top_p = ctl->top_p;
     int token;
-    if (p.forced_tokens) {
-        token = p.forced_tokens[(long long)b * p.f_stride + p.step];
+    if (ctl->forced_tokens) {
+        token = ctl->forced_tokens[(long long)b * ctl->f_stride + step];
     } else {
-        // 1. repetition penalty over every id in the row's input_ids, temperature
-        const float* lg = p.logits + (long long)b * p.Vs;
+        // 1. logits = head GEMV partials + bias (its finish), repetition penalty over every id in the row's input_ids, temperature
         const unsigned char* seen = p.seen + (long long)b * V;
+        const float rp = ctl->repetition_penalty, temp = ctl->temperature;
+        const int eos_off = ctl->suppress_eos ? p.eos : -1;
         for (int v = tid; v < V; v += SAMP_THREADS) {
-            float x = lg[v];
-            if (p.suppress_eos && v == p.eos) x = -INFINITY;
-            if (seen[v]) x = x < 0.f ? x * p.repetition_penalty : x / p.repetition_penalty;
-            sv[v] = x / p.temperature;
+            float x = p.bias ? p.bias[v] : 0.f;
+            x += sum_parts(p.parts, p.slices, (long long)p.B * p.Vs, (long long)b * p.Vs + v);
+            if (v == eos_off) x = -INFINITY;
+            if (seen[v]) x = x < 0.f ? x * rp : x / rp;
+            sv[v] = x / temp;
         }
         __syncthreads();
         // 2. top-k: threshold = k-th largest value (radix select on order-preserving keys)
-        if (p.top_k > 0 && p.top_k < V) {
+        if (top_k > 0 && top_k < V) {
             unsigned prefix = 0, mask = 0;
-            int krem = p.top_k;
+            int krem = top_k;
             for (int pass = 3; pass >= 0; --pass) {
                 if (tid < 256) hist[tid] = 0;
                 __syncthreads();
@@ -855,7 +622,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, sv[v]);
         mx = block_reduce_max(mx, red);
         // 4. top-p (nucleus): ascending sort of the kept candidates, drop the tail whose cumulative prob <= 1 - top_p
-        if (p.top_p < 1.0f) {
+        if (top_p < 1.0f) {
             if (tid == 0) sh_i[1] = 0;
             __syncthreads();
             for (int v = tid; v < V; v += SAMP_THREADS)
@@ -917,7 +684,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             for (int i = i0; i < i0 + per && i < M; ++i) loc += expf(skey[i] - mx) / z;
             float tot;
             float run = block_exclusive_scan(loc, red, &tot);
-            const float cut = 1.0f - p.top_p;
+            const float cut = 1.0f - top_p;
             for (int i = i0; i < i0 + per && i < M; ++i) {
                 run += expf(skey[i] - mx) / z;
                 if (run <= cut && i != M - 1) sv[sidx[i]] = -INFINITY;
@@ -932,10 +699,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         float tot;
         float run = block_exclusive_scan(loc, red, &tot);
         float u;
-        if (p.forced_u) u = p.forced_u[(long long)b * p.u_stride + p.step];
+        if (ctl->forced_u) u = ctl->forced_u[(long long)b * ctl->u_stride + step];
         else {
             float uu[4];
-            philox_uniform4(p.seed, (unsigned)p.sample_ids[b], STAGE_GPT_SAMPLE, p.step, 0u, uu);
+            philox_uniform4(ctl->seed, (unsigned)ctl->sample_id[b], STAGE_GPT_SAMPLE, step, 0u, uu);
             u = uu[0];
         }
         const float target = u * tot;
@@ -957,29 +724,15 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     if (fin) token = p.eos;
     __syncthreads();
     if (tid == 0) {
-        p.codes[(long long)b * p.codes_stride + p.step] = token;
+        p.codes[(long long)b * p.codes_stride + step] = token;
         p.seen[(long long)b * V + token] = 1;
         if (token == p.eos) p.finished[b] = 1;
+        ctl->step[b] = step + 1;                 // only this workgroup reads or writes step[b] inside this launch
     }
     // next input embedding: mel_embedding[token] + mel_pos_embedding[step + 1]   (gpt/model.py:134-136 with position k)
-    // + the per-64-column (sum, sum of squares) the first layer's GEMV prologue rebuilds its LayerNorm from (same layout as
-    // gemv_finish_kernel's statistics: [B][ceil(C/64)][2]) - the first layer needs no LayerNorm kernel of its own
-    for (int c0 = 0; c0 < p.C; c0 += SAMP_THREADS) {
-        const int c = c0 + tid;
-        float v = 0.f;
-        if (c < p.C) {
-            v = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(p.step + 1) * p.C + c];
-            p.x_next[(long long)b * p.C + c] = v;
-        }
-        if (p.x_stats) {
-            const float s1 = wsum(v), s2 = wsum(v * v);
-            if ((tid & 63) == 0 && c < p.C) {
-                float* st = p.x_stats + ((long long)b * ((p.C + 63) / 64) + (c >> 6)) * 2;
-                st[0] = s1;
-                st[1] = s2;
-            }
-        }
-    }
+    if (p.x_next)
+        for (int c = tid; c < p.C; c += SAMP_THREADS)
+            p.x_next[(long long)b * p.C + c] = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(step + 1) * p.C + c];
 }
 
 void launch_sampler(const SamplerParams& p, hipStream_t s) {

@@ -11,6 +11,7 @@
 #include "attention.h"
 #include "common.h"
 #include "conv_gemm.h"
+#include "gpt_kernels.h"
 #include "ops.h"
 #include "../../include/detail_hip.h"
 
@@ -60,6 +61,20 @@ struct CouplingW {           // ResidualCouplingLayer + WN (vqvae/modules/module
 struct GptLayerW {
     const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
     PackedConv attn, proj, fc, fc2;
+    // LayerNorm-algebra vectors of the decode step (gpt_kernels.h): c = W^T gamma, d = W^T beta + bias for c_attn / c_fc
+    const float *attn_c = nullptr, *attn_d = nullptr, *fc_c = nullptr, *fc_d = nullptr;
+};
+
+// A GPT decode session (dtts_gpt_prefill .. dtts_gpt_finish): device state of <= 8 sequences in the handle's own arena
+struct GptSession {
+    int B = 0, cap = 0, G = 0, steps = 0;      // rows, KV capacity (columns), max_generate_length, tokens generated so far
+    bool active = false;
+    long long kv_bs = 0, kv_layer = 0;
+    float *kv = nullptr, *x = nullptr, *y = nullptr, *ab = nullptr, *lat = nullptr, *xa = nullptr, *part = nullptr, *part2 = nullptr,
+          *st1 = nullptr, *st2 = nullptr;
+    unsigned char* seen = nullptr;
+    int *finished = nullptr, *codes = nullptr, *forced = nullptr;
+    GptCtl* ctl = nullptr;
 };
 
 struct ResBlock1W {
@@ -84,6 +99,7 @@ public:
     int* i32(size_t n) { return static_cast<int*>(raw(n * sizeof(int))); }
     void* raw(size_t bytes);
     size_t capacity() const { return cap_; }
+    void swap(Arena& o) { std::swap(base_, o.base_); std::swap(cap_, o.cap_); std::swap(off_, o.off_); }
 
 private:
     char* base_ = nullptr;
@@ -106,10 +122,23 @@ public:
                       float* out, hipStream_t s);
     void diff_sample(const float* code_emb, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
                      int n_steps, const float* x_init, const float* step_noise, float* mel_out, int denorm, hipStream_t s);
+    // one p_sample at `step` on x in place (unit entry of the sampler parity tests)
+    void diff_p_sample(float* x, const float* code_emb, const int* lens_host, int B, int T, int step, unsigned long long seed,
+                       const int* sample_ids_host, const float* noise, float* x0_out, hipStream_t s);
     // ---- stage A
     void gpt_generate(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
                       int Lt_max, int B, const dtts_gpt_options& o, int* codes_host, int* ncodes_host, float* latents_cm,
                       int lat_stride, hipStream_t s);
+    // decode session: prefill (+ first token) -> decode steps (eager / captured hipGraphs) -> results
+    void gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host, int Lt_max,
+                     int B, const dtts_gpt_options& o, float* latents_cm, int lat_stride, hipStream_t s);
+    void gpt_decode_step(hipStream_t s);
+    int gpt_decode(int n_steps, hipStream_t s);
+    int gpt_all_finished(hipStream_t s);
+    void gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s);
+    int gpt_steps() const { return gs_.active ? gs_.steps : 0; }
+    void op_sample_logits(const float* logits, int R, int V, const int* history_host, int hist_len, const float* uniforms, int top_k,
+                          float top_p, float temperature, float repetition_penalty, int* tokens_host, hipStream_t s);
     void gpt_latents(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
                      int Lt_max, const int* codes_host, const int* ncodes_host, int n_max, int B, float* latents_cm, int lat_stride,
                      hipStream_t s);
@@ -118,8 +147,9 @@ public:
                    hipStream_t s);
     void op_mel_style(const char* which, const float* mel, const int* lens_host, int B, int T, float* g_out, hipStream_t s);
     void vocoder(const float* mel, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
-                 float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s);
-    void generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
+                 float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s, int gen_chunk = 0);
+    void generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs = 0,
+                   int z_cs = 0);
     void op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
     // ---- VQ decode path (infer_gpt)
     void vq_decode(const int* codes_host, const int* ncodes_host, int nmax, const float* refer, const int* refer_lens_host, int Tr,
@@ -141,6 +171,7 @@ public:
     void set_option(const std::string& key, int value) {
         if (key == "two_streams") opt_two_streams_ = value != 0;
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
+        else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -156,7 +187,11 @@ private:
     ResBlockW res_block(const std::string& prefix, int C, int index) const;
     void build_diffusion(hipStream_t s);
     void build_vocoder();
-    void build_gpt();
+    void build_gpt(hipStream_t s);
+    void gpt_head_and_sample(hipStream_t s);
+    void gpt_step_launches(hipStream_t s);
+    hipGraphExec_t gpt_capture(int n);
+    void gpt_drop_graphs();
     void build_vq();
     void build_frontend();
     void gpt_prefill_layers(float* x, const int* lens, int B, int L, float* kv_cache, long long kv_layer_stride, long long kv_bs,
@@ -213,6 +248,15 @@ private:
     const float *lnf_g_ = nullptr, *lnf_b_ = nullptr, *fin_g_ = nullptr, *fin_b_ = nullptr;
     const float *text_emb_ = nullptr, *mel_emb_ = nullptr, *text_pos_ = nullptr, *mel_pos_ = nullptr;
 
+    Arena gpt_persist_;                   // LayerNorm-algebra vectors (bind time)
+    Arena gpt_state_;                     // decode session state (fixed addresses: the captured graphs point into it)
+    GptSession gs_;
+    GptCtl ctl_host_;
+    hipGraphExec_t gpt_graph_[2] = {nullptr, nullptr};   // [0]: a chunk of decode steps, [1]: one step
+    hipStream_t sg_ = nullptr;            // capture / replay stream of the decode graphs
+    hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;
+    bool opt_gpt_graph_ = true;
+
     bool opt_two_streams_ = true;
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies
@@ -235,6 +279,7 @@ private:
     const float *vqe_ln_g_ = nullptr, *vqe_ln_b_ = nullptr, *vq_embed_ = nullptr, *vq_embed_sq_ = nullptr;
 
     Arena ws_;        // per-call activations
+    Arena ws_voc_;    // stage C's own scratch (swapped in for the duration of a vocoder call)
     Arena persist_;   // tables built at bind time
     int* lens_dev_ = nullptr;   // small ring of device int buffers
     size_t lens_off_ = 0;

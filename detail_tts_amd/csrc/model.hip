@@ -39,7 +39,12 @@ Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) {
 }
 
 Model::~Model() {
+    gpt_drop_graphs();
     if (lens_dev_) (void)hipFree(lens_dev_);
+    for (hipStream_t st : {s2_, sg_})
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : {ev_fork_, ev_join_, ev_g0_, ev_g1_})
+        if (e) (void)hipEventDestroy(e);
 }
 
 const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
@@ -118,7 +123,7 @@ void Model::bind_weights(const void* blob, size_t nbytes, const char* const* nam
     has_vocoder_ = weights_.count("dec.conv_pre.wp") != 0;
     if (has_vocoder_) build_vocoder();
     has_gpt_ = weights_.count("gpt.mel_head.wp") != 0;
-    if (has_gpt_) build_gpt();
+    if (has_gpt_) build_gpt(stream);
     has_vq_ = weights_.count("quantizer.table") != 0;
     if (has_vq_) build_vq();
     has_frontend_ = weights_.count("frontend.dft.wp") != 0;
@@ -754,6 +759,26 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
         launch_diff_update(x, xbs, T, out2, (long long)OC * T, T, lens2, T, B, MC, step_coefs_[i], seed, sids, i,
                            step_noise ? step_noise + (size_t)k * B * MC * T : nullptr, (denorm && last) ? 1 : 0, s);
     }
+}
+
+// GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at one sampling step, x in place
+void Model::diff_p_sample(float* x, const float* code_emb, const int* lens_host, int B, int T, int step, unsigned long long seed,
+                          const int* sample_ids_host, const float* noise, float* x0_out, hipStream_t s) {
+    DTTS_REQUIRE(bound_, "weights not bound");
+    DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
+    DTTS_REQUIRE(sample_ids_host, "sample_ids");
+    const int C = cfg.diff_channels, OC = cfg.diff_out_channels, MC = cfg.mel_channels;
+    ws_.ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
+    const PairPlan pl = plan_pair(lens_host, B, T, s);
+    const int* sids = upload_ints(sample_ids_host, B, s);
+    float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
+    float* out2 = ws_.f32((size_t)2 * B * OC * T);
+    const size_t half = (size_t)B * C * T;
+    DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
+    launch_broadcast_channels(uncond_, pl.Nu, C, T, cbuf0 + half, (long long)C * T, T, s);
+    diff_forward_pair(x, cbuf0, pl.lens2, pl.lens_i, pl.umap, B, pl.Nu, T, step, out2, s);
+    launch_diff_update(x, (long long)MC * T, T, out2, (long long)OC * T, T, pl.lens2, T, B, MC, step_coefs_[step], seed, sids, step, noise, 0, s,
+                       x0_out);
 }
 
 void Model::diff_conditioning(const float* refer, const int* lens_host, int B, int Tmax, float* cond_out, hipStream_t s) {

@@ -10,11 +10,6 @@
 
 namespace dtts {
 
-__global__ void store_column_kernel(const float* src, int C, float* dst, long long dst_bs, int dst_cs, int col) {
-    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) dst[(long long)b * dst_bs + (long long)c * dst_cs + col] = src[(long long)b * C + c];
-}
-
 __global__ void copy_columns_kernel(const float* src, long long s_bs, int s_cs, const int* col0, const int* ncols, int C, float* dst,
                                     long long d_bs, int d_cs) {
     const int c = blockIdx.y, b = blockIdx.z;
@@ -23,7 +18,7 @@ __global__ void copy_columns_kernel(const float* src, long long s_bs, int s_cs, 
         dst[(long long)b * d_bs + (long long)c * d_cs + t] = src[(long long)b * s_bs + (long long)c * s_cs + c0 + t];
 }
 
-void Model::build_gpt() {
+void Model::build_gpt(hipStream_t s) {
     const int C = cfg.gpt_dim;
     gpt_cond_ = mel_style_w("gpt.conditioning_encoder", cfg.mel_channels, C / 2, C);
     gpt_layers_.clear();
@@ -49,6 +44,22 @@ void Model::build_gpt() {
     mel_emb_ = W("gpt.mel_embedding.weight", (size_t)cfg.gpt_mel_codes * C);
     text_pos_ = W("gpt.text_pos_embedding.emb.weight", (size_t)cfg.gpt_max_text_pos * C);
     mel_pos_ = W("gpt.mel_pos_embedding.emb.weight", (size_t)cfg.gpt_max_mel_pos * C);
+    // LayerNorm-algebra vectors of the two GEMVs of every layer that sit behind a LayerNorm (gpt_kernels.h): the decode step applies
+    // ln_1 / ln_2 as two scalars per row in the CONSUMER of c_attn / c_fc
+    size_t tot = 0;
+    for (auto& w : gpt_layers_) tot += 2 * ((size_t)w.attn.CoutP + w.fc.CoutP) + 256;
+    gpt_persist_.ensure(sizeof(float) * tot + 4096);
+    for (auto& w : gpt_layers_) {
+        float* ca = gpt_persist_.f32(w.attn.CoutP);
+        float* da = gpt_persist_.f32(w.attn.CoutP);
+        float* cf = gpt_persist_.f32(w.fc.CoutP);
+        float* df = gpt_persist_.f32(w.fc.CoutP);
+        launch_ln_fold_vectors(w.attn.w, C, w.attn.CoutP, w.ln1_g, w.ln1_b, w.attn.b, ca, da, s);
+        launch_ln_fold_vectors(w.fc.w, C, w.fc.CoutP, w.ln2_g, w.ln2_b, w.fc.b, cf, df, s);
+        w.attn_c = ca; w.attn_d = da; w.fc_c = cf; w.fc_d = df;
+    }
+    gpt_drop_graphs();      // captured graphs hold the old weight pointers
+    gs_ = GptSession();
 }
 
 // HF GPT-2 stack (without ln_f) over x [B, C, L] in place; optionally fills the KV cache.
@@ -108,12 +119,20 @@ void Model::gpt_prefill_layers(float* x, const int* lens, int B, int L, float* k
 static size_t prefill_ws(int B, int C, int L) { return sizeof(float) * (size_t)9 * B * C * L + 16 * 256; }
 
 // text [B][Lt_max] as api.py passes it (trailing 0 included) -> ids [255, text..., 0]  (gpt/model.py:517-518)
-static void text_prefix_ids(const int* text, const int* text_lens, int B, int Lt_max, std::vector<int>& ids, std::vector<int>& tl,
-                            int& tl_max) {
+// Ids index device embedding tables: they are range-checked here, on the host where they live (nn.Embedding raises on these).
+static void text_prefix_ids(const int* text, const int* text_lens, int B, int Lt_max, int n_text_tokens, std::vector<int>& ids,
+                            std::vector<int>& tl, int& tl_max) {
+    DTTS_REQUIRE(text && B >= 1 && Lt_max >= 0, "text ids");
     tl.resize(B);
     tl_max = 0;
     for (int b = 0; b < B; ++b) {
-        tl[b] = (text_lens ? text_lens[b] : Lt_max) + 2;
+        const int n = text_lens ? text_lens[b] : Lt_max;
+        DTTS_REQUIRE(n >= 0 && n <= Lt_max, "text length outside [0, Lt_max]");
+        for (int j = 0; j < n; ++j) {
+            const int id = text[(size_t)b * Lt_max + j];
+            DTTS_REQUIRE(id >= 0 && id < n_text_tokens, "text id outside the text_embedding table");
+        }
+        tl[b] = n + 2;
         tl_max = std::max(tl_max, tl[b]);
     }
     ids.assign((size_t)B * tl_max, 0);
@@ -125,18 +144,22 @@ static void text_prefix_ids(const int* text, const int* text_lens, int B, int Lt
     }
 }
 
-void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
-                         int Lt_max, int B, const dtts_gpt_options& o, int* codes_host, int* ncodes_host, float* latents_cm,
-                         int lat_stride, hipStream_t s) {
+// ---- decode session ------------------------------------------------------------------------------------------------------------
+// dtts_gpt_prefill: conditioning encoder + [cond | text | start_mel] prefill (KV cache filled) + the first sampled token.  The session
+// (KV cache, residual rows, sampler state, device control block) lives in the handle's own arena, whose addresses stay fixed from call
+// to call, so the captured decode graphs stay valid.
+void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
+                        int Lt_max, int B, const dtts_gpt_options& o, float* latents_cm, int lat_stride, hipStream_t s) {
     DTTS_REQUIRE(bound_ && has_gpt_, "gpt weights not bound");
-    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB, "gpt batch must be 1..16 per call");
+    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB, "a GPT decode session holds 1..8 sequences (dtts_gpt_generate groups larger batches)");
     DTTS_REQUIRE(o.max_generate_length >= 1 && o.max_generate_length + 1 <= cfg.gpt_max_mel_pos, "max_generate_length");
-    DTTS_REQUIRE(lat_stride >= o.max_generate_length, "latent buffer too small");
-    const int C = cfg.gpt_dim, H = cfg.gpt_heads, D = C / H, V = cfg.gpt_mel_codes, G = o.max_generate_length;
+    DTTS_REQUIRE(!latents_cm || lat_stride >= o.max_generate_length, "latent buffer too small");
+    DTTS_REQUIRE(o.sample_ids, "sample_ids");
+    const int C = cfg.gpt_dim, V = cfg.gpt_mel_codes, G = o.max_generate_length;
     const int NL = (int)gpt_layers_.size();
     std::vector<int> ids, tl;
     int tl_max;
-    text_prefix_ids(text_host, text_lens_host, B, Lt_max, ids, tl, tl_max);
+    text_prefix_ids(text_host, text_lens_host, B, Lt_max, cfg.gpt_text_tokens, ids, tl, tl_max);
     DTTS_REQUIRE(tl_max <= cfg.gpt_max_text_pos, "text too long");
     std::vector<int> lp(B), ml(B, 1), mel0(B, 8192);
     int Lp = 0;
@@ -144,41 +167,49 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         lp[b] = 1 + tl[b] + 1;
         Lp = std::max(Lp, lp[b]);
     }
-    const int cap = Lp + G;                                   // KV cache columns
+    if (o.forced_codes)
+        for (size_t i = 0; i < (size_t)B * G; ++i)
+            DTTS_REQUIRE(o.forced_codes[i] >= 0 && o.forced_codes[i] < V, "forced code outside the mel_embedding table");
+    // ---- session storage.  The KV capacity is rounded up so that sessions of similar lengths share one arena layout (and graph).
+    const int cap = round_up(Lp + G, 128);
     const long long kv_bs = (long long)2 * C * cap, kv_layer = kv_bs * B;
-    const int VP = mel_head_.CoutP;
-    const size_t PART_FLOATS = 262144;     // >= slices * CoutP for every decode GEMV (see gemv_slices)
-    const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * C * Lp + (size_t)B * (7 * C + 4 * C + VP) +
-                                         (size_t)2 * B * PART_FLOATS) +
-                        (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + (size_t)2 * G * B + B) + 64 * 256 +
-                        std::max(prefill_ws(B, C, Lp), sizeof(float) * ((size_t)5 * B * (C / 2) * Tr + (size_t)B * C * Tr) + 4096);
-    ws_.ensure(need + 65536);
-
-    float* kv = ws_.f32((size_t)NL * kv_layer);
+    const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * 5 * C + (size_t)2 * B * GEMV_PART_FLOATS + 2 * 64 * GEMV_MAXB * 2) +
+                        (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + 64) + sizeof(GptCtl) + 64 * 256;
+    if (need > gpt_state_.capacity() || gs_.B != B || gs_.cap != cap || gs_.G != G) {
+        gpt_drop_graphs();
+        gpt_state_.ensure(need);
+        gpt_state_.reset();
+        GptSession n;
+        n.B = B; n.cap = cap; n.G = G;
+        n.kv = gpt_state_.f32((size_t)NL * kv_layer);
+        n.x = gpt_state_.f32((size_t)B * C);
+        n.y = gpt_state_.f32((size_t)B * C);
+        n.ab = gpt_state_.f32((size_t)B * C);
+        n.lat = gpt_state_.f32((size_t)B * C);
+        n.xa = gpt_state_.f32((size_t)B * C);
+        n.part = gpt_state_.f32((size_t)B * GEMV_PART_FLOATS);
+        n.part2 = gpt_state_.f32((size_t)B * GEMV_PART_FLOATS);
+        n.st1 = gpt_state_.f32((size_t)64 * GEMV_MAXB * 2);
+        n.st2 = gpt_state_.f32((size_t)64 * GEMV_MAXB * 2);
+        n.seen = static_cast<unsigned char*>(gpt_state_.raw((size_t)B * V));
+        n.finished = gpt_state_.i32(B);
+        n.codes = gpt_state_.i32((size_t)B * G);
+        n.forced = gpt_state_.i32((size_t)B * G);
+        n.ctl = static_cast<GptCtl*>(gpt_state_.raw(sizeof(GptCtl)));
+        gs_ = n;
+    }
+    gs_.kv_bs = kv_bs;
+    gs_.kv_layer = kv_layer;
+    gs_.steps = 0;
+    gs_.active = false;
+    ws_.ensure(std::max(prefill_ws(B, C, Lp) + sizeof(float) * (size_t)B * C * Lp,
+                        sizeof(float) * ((size_t)5 * B * (C / 2) * Tr + (size_t)B * C * Tr + (size_t)B * C)) + 65536);
     float* emb = ws_.f32((size_t)B * C * Lp);
     float* cond = ws_.f32((size_t)B * C);
-    float* xa = ws_.f32((size_t)B * C);
-    float* xb = ws_.f32((size_t)B * C);
-    float* hn = ws_.f32((size_t)B * C);
-    float* qb = ws_.f32((size_t)B * C);
-    float* ab = ws_.f32((size_t)B * C);
-    float* mb = ws_.f32((size_t)B * 4 * C);
-    float* lat = ws_.f32((size_t)B * C);
-    float* logits = ws_.f32((size_t)B * VP);
-    float* part = ws_.f32((size_t)B * PART_FLOATS);
-    float* part2 = ws_.f32((size_t)B * PART_FLOATS);
-    float* lnst = ws_.f32((size_t)B * 64 * 2);
-    unsigned char* seen = static_cast<unsigned char*>(ws_.raw((size_t)B * V));
-    int* finished = ws_.i32(B);
-    int* codes = ws_.i32((size_t)B * G);
-    int* pos_tab = ws_.i32((size_t)G * B);
-    int* klen_tab = ws_.i32((size_t)G * B);
-
-    const int* d_rl;
     {
         std::vector<int> rl(B);
         for (int b = 0; b < B; ++b) rl[b] = refer_lens_host ? refer_lens_host[b] : Tr;
-        d_rl = upload_ints(rl.data(), B, s);
+        const int* d_rl = upload_ints(rl.data(), B, s);
         const size_t m = ws_.mark();
         mel_style(gpt_cond_, refer, d_rl, rl.data(), B, Tr, cond, s);        // gpt/model.py:521-524
         ws_.rewind(m);
@@ -188,152 +219,307 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
     const int* d_ml = upload_ints(ml.data(), B, s);
     const int* d_mel0 = upload_ints(mel0.data(), B, s);
     const int* d_lp = upload_ints(lp.data(), B, s);
-    const int* d_sid = upload_ints(o.sample_ids, B, s);
-    {
-        std::vector<int> pt((size_t)G * B), kt((size_t)G * B);
-        for (int t = 0; t < G; ++t)
-            for (int b = 0; b < B; ++b) {
-                pt[(size_t)t * B + b] = lp[b] + t - 1;     // column of the token fed at decode step t (t >= 1)
-                kt[(size_t)t * B + b] = lp[b] + t;
-            }
-        DTTS_CHECK_HIP(hipMemcpyAsync(pos_tab, pt.data(), sizeof(int) * pt.size(), hipMemcpyHostToDevice, s));
-        DTTS_CHECK_HIP(hipMemcpyAsync(klen_tab, kt.data(), sizeof(int) * kt.size(), hipMemcpyHostToDevice, s));
-        DTTS_CHECK_HIP(hipStreamSynchronize(s));            // pt/kt are stack temporaries
-    }
-    int* d_forced = nullptr;
-    if (o.forced_codes) {
-        d_forced = ws_.i32((size_t)B * G);
-        DTTS_CHECK_HIP(hipMemcpyAsync(d_forced, o.forced_codes, sizeof(int) * (size_t)B * G, hipMemcpyHostToDevice, s));
-        DTTS_CHECK_HIP(hipStreamSynchronize(s));
-    }
+    // control block (host copy kept in the handle: the asynchronous upload reads it)
+    GptCtl& c = ctl_host_;
+    std::memset(&c, 0, sizeof(c));
+    for (int b = 0; b < B; ++b) { c.lp[b] = lp[b]; c.sample_id[b] = o.sample_ids[b]; }
+    c.seed = o.seed;
+    c.repetition_penalty = o.repetition_penalty;
+    c.temperature = o.temperature;
+    c.top_p = o.top_p;
+    c.top_k = o.top_k;
+    c.suppress_eos = o.suppress_eos;
+    c.max_steps = G;
+    c.forced_u = o.forced_uniforms;
+    c.u_stride = G;
+    c.forced_tokens = o.forced_codes ? gs_.forced : nullptr;
+    c.f_stride = G;
+    c.latents = latents_cm;
+    c.lat_bs = (long long)C * lat_stride;
+    c.lat_cs = lat_stride;
+    DTTS_CHECK_HIP(hipMemcpyAsync(gs_.ctl, &c, sizeof(c), hipMemcpyHostToDevice, s));
+    if (o.forced_codes) DTTS_CHECK_HIP(hipMemcpyAsync(gs_.forced, o.forced_codes, sizeof(int) * (size_t)B * G, hipMemcpyHostToDevice, s));
     // seen = ids of the fake prefix: 1 (all prefix slots) and start_mel 8192  (gpt/model.py:528-530)
-    DTTS_CHECK_HIP(hipMemsetAsync(seen, 0, (size_t)B * V, s));
-    DTTS_CHECK_HIP(hipMemsetAsync(finished, 0, sizeof(int) * B, s));
+    DTTS_CHECK_HIP(hipMemsetAsync(gs_.seen, 0, (size_t)B * V, s));
+    DTTS_CHECK_HIP(hipMemsetAsync(gs_.finished, 0, sizeof(int) * B, s));
     for (int b = 0; b < B; ++b) {
-        DTTS_CHECK_HIP(hipMemsetAsync(seen + (size_t)b * V + 1, 1, 1, s));
-        DTTS_CHECK_HIP(hipMemsetAsync(seen + (size_t)b * V + 8192, 1, 1, s));
+        DTTS_CHECK_HIP(hipMemsetAsync(gs_.seen + (size_t)b * V + 1, 1, 1, s));
+        DTTS_CHECK_HIP(hipMemsetAsync(gs_.seen + (size_t)b * V + 8192, 1, 1, s));
+    }
+    {   // rows that finish early are padded with 8193 (HF pad_token_id)
+        std::vector<int> pad((size_t)B * G, 8193);
+        DTTS_CHECK_HIP(hipMemcpyAsync(gs_.codes, pad.data(), sizeof(int) * pad.size(), hipMemcpyHostToDevice, s));
+        DTTS_CHECK_HIP(hipStreamSynchronize(s));          // host temporaries (ids, pad, forced codes) are consumed
     }
     // ---- prefill over [cond | text | start_mel]
     DTTS_CHECK_HIP(hipMemsetAsync(emb, 0, sizeof(float) * (size_t)B * C * Lp, s));
     launch_build_prefix(cond, d_ids, tl_max, d_tl, text_emb_, text_pos_, mel_emb_, mel_pos_, d_mel0, 1, d_ml, B, C, Lp, emb, s);
-    gpt_prefill_layers(emb, d_lp, B, Lp, kv, kv_layer, kv_bs, cap, s);
-    launch_gather_last(emb, (long long)C * Lp, Lp, d_lp, 0, B, C, xa, s);
+    gpt_prefill_layers(emb, d_lp, B, Lp, gs_.kv, kv_layer, kv_bs, cap, s);
+    launch_gather_last(emb, (long long)C * Lp, Lp, d_lp, 0, B, C, gs_.xa, s);
+    // first token: lm_head = (final_norm, mel_head) applied to ln_f(h)   (gpt/model.py:41, 173)
+    launch_gpt_final_ln(gs_.xa, nullptr, nullptr, 0, 0, B, lnf_g_, lnf_b_, fin_g_, fin_b_, gs_.lat, C, gs_.ctl, s);
+    gpt_head_and_sample(s);
+    gs_.steps = 1;
+    gs_.active = true;
+}
 
+// mel_head GEMV on `lat` + sampler (the GEMV's finish is the sampler's prologue); the sampler leaves the next input embedding in y
+void Model::gpt_head_and_sample(hipStream_t s) {
+    const int C = cfg.gpt_dim, V = cfg.gpt_mel_codes, VP = mel_head_.CoutP, B = gs_.B;
+    GemvIn in;
+    in.x = gs_.lat;
+    in.x_stride = C;
+    launch_gemv_block(GP_PLAIN, mel_head_.w, C, VP, in, B, gs_.part, s);
     SamplerParams sp;
-    sp.logits = logits;
+    sp.parts = gs_.part;
+    sp.slices = gemv_block_slices(C, VP);
+    sp.bias = mel_head_.b;
     sp.Vs = VP;
     sp.V = V;
     sp.B = B;
+    sp.seen = gs_.seen;
+    sp.finished = gs_.finished;
+    sp.codes = gs_.codes;
+    sp.codes_stride = gs_.G;
+    sp.eos = 8193;
+    sp.ctl = gs_.ctl;
+    sp.mel_emb = mel_emb_;
+    sp.mel_pos = mel_pos_;
+    sp.x_next = gs_.y;
+    sp.C = C;
+    launch_sampler(sp, s);
+}
+
+// One token for every row of the session: 5 launches per layer + final LayerNorms + mel_head + sampler, all with fixed arguments
+// (the step index, positions and sampling state are read from the device control block) -> safe to capture in a hipGraph.
+void Model::gpt_step_launches(hipStream_t s) {
+    const int C = cfg.gpt_dim, H = cfg.gpt_heads, D = C / H, B = gs_.B, NL = (int)gpt_layers_.size();
+    const int st_sl = gemv_block_slices(C, gpt_layers_[0].attn.CoutP);      // statistics slices of a K = C RESSUM GEMV
+    for (int l = 0; l < NL; ++l) {
+        const GptLayerW& w = gpt_layers_[l];
+        float* cache = gs_.kv + (size_t)l * gs_.kv_layer;
+        const int sq = gemv_block_slices(C, w.attn.CoutP), spj = gemv_block_slices(C, w.proj.CoutP);
+        const int sf = gemv_block_slices(C, w.fc.CoutP), s4 = gemv_block_slices(4 * C, w.fc2.CoutP);
+        DTTS_REQUIRE(gemv_block_slices(C, w.fc.CoutP) == st_sl && st_sl <= 64, "statistics slices");
+        GemvIn a;                                        // K1: X = Y + (previous layer's mlp projection) ; c_attn(gamma1 . X)
+        a.x = gs_.y;
+        a.x_stride = C;
+        if (l > 0) {
+            a.parts = gs_.part2;
+            a.in_slices = s4;
+            a.in_stride = gpt_layers_[l - 1].fc2.CoutP;
+            a.in_bias = gpt_layers_[l - 1].fc2.b;
+        }
+        a.gamma = w.ln1_g;
+        a.y_out = gs_.x;
+        a.stats_out = gs_.st1;
+        launch_gemv_block(GP_RESSUM, w.attn.w, C, w.attn.CoutP, a, B, gs_.part, s);
+        launch_decode_attention_qkv(gs_.part, sq, w.attn.CoutP, gs_.st1, st_sl, w.attn_c, w.attn_d, cache, gs_.kv_bs, gs_.cap, gs_.ctl, B, H, D,
+                                    gs_.ab, s);
+        GemvIn p;                                        // K3: attention projection
+        p.x = gs_.ab;
+        p.x_stride = C;
+        launch_gemv_block(GP_PLAIN, w.proj.w, C, w.proj.CoutP, p, B, gs_.part2, s);
+        GemvIn f;                                        // K4: Y = X + proj ; c_fc(gamma2 . Y)
+        f.x = gs_.x;
+        f.x_stride = C;
+        f.parts = gs_.part2;
+        f.in_slices = spj;
+        f.in_stride = w.proj.CoutP;
+        f.in_bias = w.proj.b;
+        f.gamma = w.ln2_g;
+        f.y_out = gs_.y;
+        f.stats_out = gs_.st2;
+        launch_gemv_block(GP_RESSUM, w.fc.w, C, w.fc.CoutP, f, B, gs_.part, s);
+        GemvIn m;                                        // K5: c_proj(gelu(ln_2 finish of c_fc))
+        m.parts = gs_.part;
+        m.in_slices = sf;
+        m.in_stride = w.fc.CoutP;
+        m.in_act = ACT_GELU_NEW;
+        m.stats_in = gs_.st2;
+        m.stats_slices = st_sl;
+        m.K_ln = C;
+        m.fold_c = w.fc_c;
+        m.fold_d = w.fc_d;
+        launch_gemv_block(GP_LNPARTS, w.fc2.w, 4 * C, w.fc2.CoutP, m, B, gs_.part2, s);
+    }
+    const GptLayerW& wl = gpt_layers_[NL - 1];
+    launch_gpt_final_ln(gs_.y, wl.fc2.b, gs_.part2, gemv_block_slices(4 * C, wl.fc2.CoutP), wl.fc2.CoutP, B, lnf_g_, lnf_b_, fin_g_, fin_b_,
+                        gs_.lat, C, gs_.ctl, s);
+    gpt_head_and_sample(s);
+}
+
+void Model::gpt_decode_step(hipStream_t s) {
+    DTTS_REQUIRE(gs_.active, "dtts_gpt_decode_step: no session (call dtts_gpt_prefill first)");
+    gpt_step_launches(s);
+    gs_.steps += 1;
+}
+
+void Model::gpt_drop_graphs() {
+    for (auto& g : gpt_graph_)
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
+
+static int gpt_graph_chunk() {
+    static const int n = []() { const char* v = getenv("DTTS_GPT_GRAPH_CHUNK"); const int k = v ? atoi(v) : 16; return k < 1 ? 1 : (k > 64 ? 64 : k); }();
+    return n;
+}
+
+// captures `n` decode steps on the internal stream (kernel nodes only; the stream is not the legacy default stream, which cannot be
+// captured) and instantiates them
+hipGraphExec_t Model::gpt_capture(int n) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    DTTS_CHECK_HIP(hipStreamBeginCapture(sg_, hipStreamCaptureModeRelaxed));
+    try {
+        for (int i = 0; i < n; ++i) gpt_step_launches(sg_);
+    } catch (...) {
+        (void)hipStreamEndCapture(sg_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    DTTS_CHECK_HIP(hipStreamEndCapture(sg_, &graph));
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    DTTS_CHECK_HIP(e);
+    return exec;
+}
+
+// n more tokens (clamped to the session's max_generate_length) through the captured graphs: chunks of 16 steps + single steps, on the
+// handle's internal stream, ordered after / before `s` by events.  Asynchronous; no host work per token.
+int Model::gpt_decode(int n_steps, hipStream_t s) {
+    DTTS_REQUIRE(gs_.active, "dtts_gpt_decode: no session (call dtts_gpt_prefill first)");
+    int n = std::min(n_steps, gs_.G - gs_.steps);
+    if (n <= 0) return 0;
+    static const bool env_graph = []() { const char* v = getenv("DTTS_GPT_GRAPH"); return !(v && v[0] == '0'); }();
+    if (!(env_graph && opt_gpt_graph_)) {
+        for (int i = 0; i < n; ++i) gpt_step_launches(s);
+        gs_.steps += n;
+        return n;
+    }
+    if (!sg_) {
+        DTTS_CHECK_HIP(hipStreamCreateWithFlags(&sg_, hipStreamNonBlocking));
+        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_g0_, hipEventDisableTiming));
+        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_g1_, hipEventDisableTiming));
+    }
+    const int chunk = gpt_graph_chunk();
+    DTTS_CHECK_HIP(hipEventRecord(ev_g0_, s));
+    DTTS_CHECK_HIP(hipStreamWaitEvent(sg_, ev_g0_, 0));
+    int left = n;
+    if (left >= chunk && chunk > 1) {
+        if (!gpt_graph_[0]) gpt_graph_[0] = gpt_capture(chunk);
+        for (; left >= chunk; left -= chunk) DTTS_CHECK_HIP(hipGraphLaunch(gpt_graph_[0], sg_));
+    }
+    if (left > 0) {
+        if (!gpt_graph_[1]) gpt_graph_[1] = gpt_capture(1);
+        for (; left > 0; --left) DTTS_CHECK_HIP(hipGraphLaunch(gpt_graph_[1], sg_));
+    }
+    DTTS_CHECK_HIP(hipEventRecord(ev_g1_, sg_));
+    DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_g1_, 0));
+    gs_.steps += n;
+    return n;
+}
+
+// != 0 when every row has drawn the stop token (synchronises the stream)
+int Model::gpt_all_finished(hipStream_t s) {
+    DTTS_REQUIRE(gs_.active, "no GPT session");
+    int fin[GEMV_MAXB];
+    DTTS_CHECK_HIP(hipMemcpyAsync(fin, gs_.finished, sizeof(int) * gs_.B, hipMemcpyDeviceToHost, s));
+    DTTS_CHECK_HIP(hipStreamSynchronize(s));
+    return std::all_of(fin, fin + gs_.B, [](int f) { return f != 0; }) ? 1 : 0;
+}
+
+// results: codes include the stop token; rows that finished early are padded with 8193 (HF pad_token_id).  Synchronises.
+void Model::gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s) {
+    DTTS_REQUIRE(gs_.active, "dtts_gpt_finish: no session");
+    const int B = gs_.B, G = gs_.G, Ga = gs_.G, done = gs_.steps;
+    std::vector<int> hc((size_t)B * Ga, 8193);
+    DTTS_CHECK_HIP(hipMemcpyAsync(hc.data(), gs_.codes, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, s));
+    DTTS_CHECK_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+        int n = done;
+        for (int t = 0; t < done; ++t)
+            if (hc[(size_t)b * Ga + t] == 8193) { n = t + 1; break; }
+        if (ncodes_host) ncodes_host[b] = n;
+        if (codes_host)
+            for (int t = 0; t < G; ++t) codes_host[(size_t)b * G + t] = t < done ? hc[(size_t)b * Ga + t] : 8193;
+    }
+    gs_.active = false;
+}
+
+// UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545): prefill + decode loop + results.  Batches larger than one session
+// (8 rows) run group after group; the finish flags are polled once per 16-token graph (never per token).
+void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
+                         int Lt_max, int B, const dtts_gpt_options& o, int* codes_host, int* ncodes_host, float* latents_cm,
+                         int lat_stride, hipStream_t s) {
+    DTTS_REQUIRE(B >= 1, "gpt batch");
+    DTTS_REQUIRE(o.sample_ids, "sample_ids");
+    const int C = cfg.gpt_dim, G = o.max_generate_length, chunk = gpt_graph_chunk();
+    for (int g0 = 0; g0 < B; g0 += GEMV_MAXB) {
+        const int nb = std::min(GEMV_MAXB, B - g0);
+        dtts_gpt_options og = o;
+        og.sample_ids = o.sample_ids + g0;
+        if (o.forced_uniforms) og.forced_uniforms = o.forced_uniforms + (size_t)g0 * G;
+        if (o.forced_codes) og.forced_codes = o.forced_codes + (size_t)g0 * G;
+        gpt_prefill(refer + (size_t)g0 * cfg.mel_channels * Tr, refer_lens_host ? refer_lens_host + g0 : nullptr, Tr,
+                    text_host + (size_t)g0 * Lt_max, text_lens_host ? text_lens_host + g0 : nullptr, Lt_max, nb, og,
+                    latents_cm ? latents_cm + (size_t)g0 * C * lat_stride : nullptr, lat_stride, s);
+        while (gs_.steps < G) {
+            if (!o.suppress_eos && gpt_all_finished(s)) break;
+            gpt_decode(chunk, s);
+        }
+        gpt_finish(codes_host + (size_t)g0 * G, ncodes_host + g0, s);
+    }
+}
+
+// unit entry: the device sampler on given logits rows (HF logits processors + inverse-CDF draw), one token per row
+void Model::op_sample_logits(const float* logits, int R, int V, const int* history_host, int hist_len, const float* uniforms, int top_k,
+                             float top_p, float temperature, float repetition_penalty, int* tokens_host, hipStream_t s) {
+    DTTS_REQUIRE(R >= 1 && R <= GEMV_MAXB && V >= 2 && V < 65535, "op_sample_logits: rows 1..8");
+    ws_.ensure((size_t)R * V + sizeof(int) * 4 * R + sizeof(GptCtl) + 16 * 256);
+    unsigned char* seen = static_cast<unsigned char*>(ws_.raw((size_t)R * V));
+    int* finished = ws_.i32(R);
+    int* codes = ws_.i32(R);
+    GptCtl* dctl = static_cast<GptCtl*>(ws_.raw(sizeof(GptCtl)));
+    std::vector<unsigned char> hs((size_t)R * V, 0);
+    for (int r = 0; r < R; ++r)
+        for (int j = 0; j < hist_len; ++j) {
+            const int id = history_host[(size_t)r * hist_len + j];
+            DTTS_REQUIRE(id >= 0 && id < V, "history id");
+            hs[(size_t)r * V + id] = 1;
+        }
+    GptCtl c;
+    std::memset(&c, 0, sizeof(c));
+    c.repetition_penalty = repetition_penalty;
+    c.temperature = temperature;
+    c.top_p = top_p;
+    c.top_k = top_k;
+    c.max_steps = 1;
+    c.forced_u = uniforms;
+    c.u_stride = 1;
+    DTTS_CHECK_HIP(hipMemcpyAsync(dctl, &c, sizeof(c), hipMemcpyHostToDevice, s));
+    DTTS_CHECK_HIP(hipMemcpyAsync(seen, hs.data(), hs.size(), hipMemcpyHostToDevice, s));
+    DTTS_CHECK_HIP(hipMemsetAsync(finished, 0, sizeof(int) * R, s));
+    SamplerParams sp;
+    sp.parts = logits;
+    sp.slices = 1;
+    sp.bias = nullptr;
+    sp.Vs = V;
+    sp.V = V;
+    sp.B = R;
     sp.seen = seen;
     sp.finished = finished;
     sp.codes = codes;
-    sp.codes_stride = G;
-    sp.repetition_penalty = o.repetition_penalty;
-    sp.temperature = o.temperature;
-    sp.top_p = o.top_p;
-    sp.top_k = o.top_k;
-    sp.eos = 8193;
-    sp.suppress_eos = o.suppress_eos;
-    sp.seed = o.seed;
-    sp.sample_ids = d_sid;
-    sp.forced_u = o.forced_uniforms;
-    sp.u_stride = G;
-    sp.forced_tokens = d_forced;
-    sp.f_stride = G;
-    sp.mel_emb = mel_emb_;
-    sp.mel_pos = mel_pos_;
-    sp.C = C;
-    sp.n_unfinished = nullptr;
-    sp.x_stats = nullptr;
-
-    // decode GEMVs in workgroup form with the finishes folded into the consumers' prologues (B <= 8; DTTS_GPT_FAST=0: the older
-    // one-wave split-K kernels, also used for 9..16 sequences)
-    static const bool env_fast = []() { const char* v = getenv("DTTS_GPT_FAST"); return !(v && v[0] == '0'); }();
-    const bool fast = env_fast && B <= 8;
-    // lat = final_norm(ln_f(hidden)) must already be in `lat` (fused into the producing kernel)
-    auto head_and_sample = [&](int step, float* x_next) {
-        // lm_head = (final_norm, mel_head) applied to ln_f(h)   (gpt/model.py:41, 173)
-        if (!fast)
-            hipLaunchKernelGGL(store_column_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, lat, C, latents_cm, (long long)C * lat_stride,
-                               lat_stride, step);
-        if (fast) {
-            launch_gemv_block(mel_head_.w, C, VP, lat, C, B, part, s);
-            launch_gemv_finish(part, gemv_block_slices(C, VP), B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
-        } else {
-            const int sl = gemv_slices(C, VP);
-            launch_gemv_partial(mel_head_.w, C, VP, lat, C, B, part, sl, s);
-            launch_gemv_finish(part, sl, B, V, VP, mel_head_.b, ACT_NONE, nullptr, 0, logits, VP, s);
-        }
-        sp.step = step;
-        sp.x_next = x_next;
-        sp.x_stats = fast ? lnst : nullptr;       // layer 0 of the next token normalises x_next from these (no LayerNorm kernel)
-        launch_sampler(sp, s);
-    };
-    launch_vec_layernorm2(xa, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s, fast ? latents_cm : nullptr, (long long)C * lat_stride, lat_stride, 0);
-    head_and_sample(0, xb);
-
-    std::vector<int> fin(B, 0);
-    int steps_done = 1;
-    float* x = xb;
-    float* y = xa;
-    for (int t = 1; t < G; ++t) {
-        if ((t & 15) == 0 && !o.suppress_eos) {        // poll the finish flags every 16 tokens (no per-token host sync)
-            DTTS_CHECK_HIP(hipMemcpyAsync(fin.data(), finished, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-            DTTS_CHECK_HIP(hipStreamSynchronize(s));
-            if (std::all_of(fin.begin(), fin.end(), [](int f) { return f != 0; })) break;
-        }
-        const int* pos = pos_tab + (size_t)t * B;
-        const int* klen = klen_tab + (size_t)t * B;
-        const int nblk = cdiv(C, 64);
-        // the sampler wrote x (next input embedding) without LN statistics: one small LN for layer 0
-        if (!fast) launch_vec_layernorm(x, gpt_layers_[0].ln1_g, gpt_layers_[0].ln1_b, hn, B, C, s);
-        for (int l = 0; l < NL; ++l) {
-            const GptLayerW& w = gpt_layers_[l];
-            float* cache = kv + (size_t)l * kv_layer;
-            if (fast) {
-                const int sq = gemv_block_slices(C, w.attn.CoutP), spj = gemv_block_slices(C, w.proj.CoutP);
-                const int sf = gemv_block_slices(C, w.fc.CoutP), s4 = gemv_block_slices(4 * C, w.fc2.CoutP);
-                launch_gemv_block_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, lnst, nblk, w.ln1_g, w.ln1_b, s);
-                launch_decode_attention_qkv(part, sq, w.attn.CoutP, w.attn.b, cache, kv_bs, cap, pos, klen, B, H, D, ab, s);
-                launch_gemv_block(w.proj.w, C, w.proj.CoutP, ab, C, B, part2, s);
-                launch_gemv_finish(part2, spj, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);   // y = x + attn ; stats for ln_2
-                launch_gemv_block_ln(w.fc.w, C, w.fc.CoutP, y, C, B, part, lnst, nblk, w.ln2_g, w.ln2_b, s);
-                // c_proj(gelu(c_fc + bias)): c_fc's finish is this GEMV's prologue
-                launch_gemv_block_parts(w.fc2.w, 4 * C, w.fc2.CoutP, part, sf, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, B, part2, s);
-                launch_gemv_finish(part2, s4, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s, lnst);     // x = y + mlp ; stats for next ln_1
-                continue;
-            }
-            int sl = gemv_slices(C, w.attn.CoutP);
-            if (l == 0) launch_gemv_partial(w.attn.w, C, w.attn.CoutP, hn, C, B, part, sl, s);
-            else launch_gemv_partial_ln(w.attn.w, C, w.attn.CoutP, x, C, B, part, sl, lnst, nblk, w.ln1_g, w.ln1_b, s);
-            launch_gemv_finish_qkv(part, sl, B, C, w.attn.CoutP, w.attn.b, qb, cache, kv_bs, cap, pos, s);
-            launch_decode_attention(qb, cache, kv_bs, cap, klen, B, H, D, ab, s);
-            sl = gemv_slices(C, w.proj.CoutP);
-            launch_gemv_partial(w.proj.w, C, w.proj.CoutP, ab, C, B, part, sl, s);
-            launch_gemv_finish(part, sl, B, C, w.proj.CoutP, w.proj.b, ACT_NONE, x, C, y, C, s, lnst);      // y = x + attn ; stats for ln_2
-            sl = gemv_slices(C, w.fc.CoutP);
-            launch_gemv_partial_ln(w.fc.w, C, w.fc.CoutP, y, C, B, part, sl, lnst, nblk, w.ln2_g, w.ln2_b, s);
-            launch_gemv_finish(part, sl, B, 4 * C, w.fc.CoutP, w.fc.b, ACT_GELU_NEW, nullptr, 0, mb, 4 * C, s);
-            sl = gemv_slices(4 * C, w.fc2.CoutP);
-            launch_gemv_partial(w.fc2.w, 4 * C, w.fc2.CoutP, mb, 4 * C, B, part, sl, s);
-            launch_gemv_finish(part, sl, B, C, w.fc2.CoutP, w.fc2.b, ACT_NONE, y, C, x, C, s, lnst);        // x = y + mlp ; stats for next ln_1
-        }
-        launch_vec_layernorm2(x, lnf_g_, lnf_b_, fin_g_, fin_b_, lat, B, C, s, fast ? latents_cm : nullptr, (long long)C * lat_stride, lat_stride, t);
-        head_and_sample(t, y);
-        std::swap(x, y);
-        steps_done = t + 1;
-    }
-    // results: codes include the stop token; rows that finished early are padded with 8193 (HF pad_token_id)
-    std::vector<int> hc((size_t)B * G, 8193);
-    DTTS_CHECK_HIP(hipMemcpyAsync(hc.data(), codes, sizeof(int) * (size_t)B * G, hipMemcpyDeviceToHost, s));
+    sp.codes_stride = 1;
+    sp.eos = V - 1;
+    sp.ctl = dctl;
+    sp.mel_emb = nullptr;
+    sp.mel_pos = nullptr;
+    sp.x_next = nullptr;
+    sp.C = 0;
+    launch_sampler(sp, s);
+    DTTS_CHECK_HIP(hipMemcpyAsync(tokens_host, codes, sizeof(int) * R, hipMemcpyDeviceToHost, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
-    for (int b = 0; b < B; ++b) {
-        int n = steps_done;
-        for (int t = 0; t < steps_done; ++t)
-            if (hc[(size_t)b * G + t] == 8193) { n = t + 1; break; }
-        ncodes_host[b] = n;
-        for (int t = 0; t < G; ++t) codes_host[(size_t)b * G + t] = t < steps_done ? hc[(size_t)b * G + t] : 8193;
-    }
 }
 
 // UnifiedVoice.forward(..., return_latent=True) as called at vqvae/model_24k.py:796-799.
@@ -345,11 +531,13 @@ void Model::gpt_latents(const float* refer, const int* refer_lens_host, int Tr, 
     const int C = cfg.gpt_dim;
     std::vector<int> ids, tl;
     int tl_max;
-    text_prefix_ids(text_host, text_lens_host, B, Lt_max, ids, tl, tl_max);
+    text_prefix_ids(text_host, text_lens_host, B, Lt_max, cfg.gpt_text_tokens, ids, tl, tl_max);
+    DTTS_REQUIRE(tl_max <= cfg.gpt_max_text_pos, "text too long");
     std::vector<int> ml(B), lt(B), c0(B), nn(B);
     int ml_max = 0, L = 0;
     for (int b = 0; b < B; ++b) {
         nn[b] = ncodes_host ? ncodes_host[b] : n_max;
+        DTTS_REQUIRE(nn[b] >= 0 && nn[b] <= n_max, "ncodes outside [0, n_max]");
         ml[b] = nn[b] + 2;                                  // start + codes + stop  (gpt/model.py:464, 470)
         ml_max = std::max(ml_max, ml[b]);
         lt[b] = 1 + tl[b] + ml[b];
@@ -361,7 +549,11 @@ void Model::gpt_latents(const float* refer, const int* refer_lens_host, int Tr, 
     for (int b = 0; b < B; ++b) {
         int* r = mids.data() + (size_t)b * ml_max;
         r[0] = 8192;
-        for (int k = 0; k < nn[b]; ++k) r[1 + k] = codes_host[(size_t)b * n_max + k];
+        for (int k = 0; k < nn[b]; ++k) {
+            const int c = codes_host[(size_t)b * n_max + k];
+            DTTS_REQUIRE(c >= 0 && c < cfg.gpt_mel_codes, "mel code outside the mel_embedding table");
+            r[1 + k] = c;
+        }
         r[nn[b] + 1] = 8193;
     }
     ws_.ensure(sizeof(float) * ((size_t)2 * B * C * L + (size_t)B * C) + prefill_ws(B, C, L) + sizeof(int) * mids.size() +

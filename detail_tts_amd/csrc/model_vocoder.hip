@@ -168,7 +168,9 @@ void Model::op_mel_style(const char* which, const float* mel, const int* lens_ho
 }
 
 // Generator.forward (vqvae/model_24k.py:269-288).  z [B,192,T], g [B,768] -> wav [B,1,256*T]
-void Model::generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s) {
+// z may be a window of a longer buffer: element (b, c, t) at z[b * z_bs + c * z_cs + t]
+void Model::generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs,
+                      int z_cs) {
     DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
     const int c0 = cfg.upsample_initial_channel;
     // workspace: every stage holds C_i * T_i = c0*T*(rate product)/2^i floats per sample; 6 live buffers of the largest
@@ -192,22 +194,31 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
 
-    // cond(g): 1x1 conv on a length-1 sequence -> per-sample additive rows for conv_pre
+    // cond(g): 1x1 conv on a length-1 sequence -> per-sample additive rows for conv_pre; g == null: unconditioned generator
+    // (`if g is not None`, vqvae/model_24k.py:271-273)
     ConvParams p;
-    p.B = B;
-    p.Tin = 1;
-    p.Nout = 1;
-    p.x = g;
-    p.x_bs = cfg.gin_channels;
-    p.x_cs = 1;
-    p.y = gc;
-    p.y_bs = dec_cond_.CoutP;
-    p.y_cs = 1;
-    run_conv(dec_cond_, p, s);
+    if (g) {
+        p.B = B;
+        p.Tin = 1;
+        p.Nout = 1;
+        p.x = g;
+        p.x_bs = cfg.gin_channels;
+        p.x_cs = 1;
+        p.y = gc;
+        p.y_bs = dec_cond_.CoutP;
+        p.y_cs = 1;
+        run_conv(dec_cond_, p, s);
+    }
     p = cp(z, cfg.inter_channels, X, c0, B, T, T, dl);
+    if (z_cs) {
+        p.x_bs = z_bs;
+        p.x_cs = z_cs;
+    }
     p.pad = 3;
-    p.badd = gc;
-    p.badd_bs = dec_cond_.CoutP;
+    if (g) {
+        p.badd = gc;
+        p.badd_bs = dec_cond_.CoutP;
+    }
     run_conv(dec_pre_, p, s);
 
     int ch = c0, Tc = T;
@@ -283,15 +294,26 @@ void Model::op_generator(const float* z, const float* g, const int* lens_host, i
 }
 
 // SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863), batched with per-sample lengths.
+// gen_chunk > 0: the generator (purely convolutional, receptive field 13.2 frames) runs window by window - gen_chunk frames + a
+// 16-frame halo on each side, only the interior is kept - so its scratch is one window instead of the whole utterance (60 s
+// utterances, BASELINE configs[4]); enc_p / flow need the whole sequence and run once.  Stage C owns its own arena: a vocoder call
+// on a second stream may overlap the next batch's GPT / diffusion calls on the first.
 void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
-                    float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s) {
+                    float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s, int gen_chunk) {
     DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
     DTTS_REQUIRE(T % 4 == 0, "mel length must be a multiple of 4 (assert y.shape[-1]%4==0, model_24k.py:851)");
+    DTTS_REQUIRE(gen_chunk >= 0, "generator chunk");
+    struct ArenaSwap {
+        Arena &a, &b;
+        ArenaSwap(Arena& x, Arena& y) : a(x), b(y) { a.swap(b); }
+        ~ArenaSwap() { a.swap(b); }
+    } use_stage_c_arena(ws_, ws_voc_);
+    const int HALO = 16, Tg = gen_chunk > 0 ? std::min(T, gen_chunk + 2 * HALO) : T;
     const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
     const int H = cfg.enc_heads, dk = hid / H;
     const size_t a192 = (size_t)B * hid * T;
     const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256;
-    ws_.ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, T)) + 8192);
+    ws_.ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, Tg) + sizeof(float) * (size_t)B * 256 * Tg) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -426,7 +448,25 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     if (trace_z) DTTS_CHECK_HIP(hipMemcpyAsync(trace_z, zc, sizeof(float) * a192, hipMemcpyDeviceToDevice, s));
     // o = dec(z, g)  (:862)
     DTTS_CHECK_HIP(hipMemsetAsync(wav, 0, sizeof(float) * (size_t)B * 256 * T, s));
-    generator(zc, g, l.data(), B, T, wav, s);
+    if (gen_chunk <= 0 || gen_chunk >= T) {
+        generator(zc, g, l.data(), B, T, wav, s);
+        return;
+    }
+    float* tmp = ws_.f32((size_t)B * 256 * Tg);
+    std::vector<int> lw(B);
+    for (int t0 = 0; t0 < T; t0 += gen_chunk) {
+        const int t1 = std::min(T, t0 + gen_chunk), a = std::max(0, t0 - HALO), e = std::min(T, t1 + HALO), W = e - a;
+        bool any = false;
+        for (int b = 0; b < B; ++b) {
+            lw[b] = std::min(std::max(l[b] - a, 0), W);
+            any = any || l[b] > t0;
+        }
+        if (!any) break;                                   // every row ends before this window's interior
+        DTTS_CHECK_HIP(hipMemsetAsync(tmp, 0, sizeof(float) * (size_t)B * 256 * W, s));
+        generator(zc + a, g, lw.data(), B, W, tmp, s, (long long)inter * T, T);
+        DTTS_CHECK_HIP(hipMemcpy2DAsync(wav + (size_t)t0 * 256, sizeof(float) * (size_t)256 * T, tmp + (size_t)(t0 - a) * 256,
+                                        sizeof(float) * (size_t)256 * W, sizeof(float) * (size_t)(t1 - t0) * 256, B, hipMemcpyDeviceToDevice, s));
+    }
 }
 
 // ------------------------------------------------------------------------------------------ VQ decode path

@@ -45,7 +45,7 @@ struct DiffStepCoefs {   // fp32 casts of the float64 tables (vqvae/utils/diffus
 // When `final_denorm` the result is mapped through denormalize_torch_mel (vqvae/model_24k.py:508-509).
 void launch_diff_update(float* x, long long x_bs, int x_cs, const float* model_out, long long m_bs, int m_cs, const int* lens,
                         int T, int B, int C, DiffStepCoefs k, unsigned long long seed, const int* sample_ids, int step,
-                        const float* noise_override, int final_denorm, hipStream_t s);
+                        const float* noise_override, int final_denorm, hipStream_t s, float* x0_out = nullptr);   // x0_out: pred_xstart [B,C,T]
 
 // y = a*x + b*z (generic elementwise with optional exp on second operand) used by the flow prior:
 // z_p = m + noise * exp(logs) * noise_scale  (vqvae/model_24k.py:860)

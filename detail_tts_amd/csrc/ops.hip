@@ -251,7 +251,7 @@ void launch_philox_normal(float* out, long long bs, int n, int B, unsigned long 
 // with T_b the sample's own length (a sample's noise never depends on batch padding).
 __global__ void diff_update_kernel(float* x, long long x_bs, int x_cs, const float* mo, long long m_bs, int m_cs, const int* lens,
                                    int T, int B, int C, DiffStepCoefs k, unsigned long long seed, const int* sample_ids, int step,
-                                   const float* noise_override, int final_denorm) {
+                                   const float* noise_override, int final_denorm, float* x0_out) {
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : T;
     const unsigned sample = (unsigned)sample_ids[b];
@@ -276,6 +276,7 @@ __global__ void diff_update_kernel(float* x, long long x_bs, int x_cs, const flo
             const float eps = (1.f + k.cfk) * eps_c - k.cfk * eps_u;
             float x0 = k.sqrt_recip_ac * xv - k.sqrt_recipm1_ac * eps;
             x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            if (x0_out) x0_out[(long long)b * C * T + (long long)c * T + t] = x0;
             float v = k.coef1 * x0 + k.coef2 * xv;
             if (k.nonzero) {
                 const float nz = noise_override ? noise_override[(long long)b * C * T + (long long)c * T + t] : z[i];
@@ -289,10 +290,10 @@ __global__ void diff_update_kernel(float* x, long long x_bs, int x_cs, const flo
 
 void launch_diff_update(float* x, long long x_bs, int x_cs, const float* model_out, long long m_bs, int m_cs, const int* lens,
                         int T, int B, int C, DiffStepCoefs k, unsigned long long seed, const int* sample_ids, int step,
-                        const float* noise_override, int final_denorm, hipStream_t s) {
+                        const float* noise_override, int final_denorm, hipStream_t s, float* x0_out) {
     const int nblk = (C * T + 3) / 4;
     hipLaunchKernelGGL(diff_update_kernel, dim3(cdiv(nblk, 256) > 64 ? 64 : cdiv(nblk, 256), B), dim3(256), 0, s, x, x_bs, x_cs,
-                       model_out, m_bs, m_cs, lens, T, B, C, k, seed, sample_ids, step, noise_override, final_denorm);
+                       model_out, m_bs, m_cs, lens, T, B, C, k, seed, sample_ids, step, noise_override, final_denorm, x0_out);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

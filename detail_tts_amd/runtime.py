@@ -160,6 +160,57 @@ class Runtime:
                                             self._stream()))
         return codes, ncodes, lat
 
+    # decode session (include/detail_hip.h: dtts_gpt_prefill / _decode_step / _decode / _all_finished / _finish), <= 8 rows
+    def gpt_prefill(self, refer, refer_lens, texts, seed, sample_ids, max_generate_length=600, top_k=50, top_p=0.8, temperature=0.8,
+                    repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None):
+        """conditioning encoder + prefill + first token; returns the latents tensor [B,768,G] the steps fill column by column"""
+        _check(refer, "refer"); _check(forced_uniforms, "forced_uniforms")
+        B, _, Tr = refer.shape
+        text, tl = self._pad_text(texts)
+        G = int(max_generate_length)
+        si = _ints(sample_ids)
+        rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
+        o = _lib.DttsGptOptions()
+        o.seed, o.sample_ids, o.max_generate_length, o.top_k = int(seed), si[0], G, int(top_k or 0)
+        o.top_p, o.temperature, o.repetition_penalty = float(top_p if top_p is not None else 1.0), float(temperature), float(repetition_penalty)
+        o.suppress_eos = 1 if suppress_eos else 0
+        o.forced_uniforms = forced_uniforms.data_ptr() if forced_uniforms is not None else None
+        if forced_codes is not None:
+            fc = np.full((B, G), 8193, np.int32)
+            for b, c in enumerate(forced_codes):
+                fc[b, :len(c)] = np.asarray(c, np.int32)
+            o.forced_codes = fc.ctypes.data_as(_lib.c_int_p)
+        lat = torch.zeros((B, self.cfg["gpt"]["model_dim"], G), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_gpt_prefill(self.h, _ptr(refer), rl[0], Tr, text.ctypes.data_as(_lib.c_int_p), tl.ctypes.data_as(_lib.c_int_p),
+                                           text.shape[1], B, C.byref(o), _ptr(lat), G, self._stream()))
+        self._session = (B, G, lat, forced_uniforms)      # keeps the device buffers of the session alive
+        return lat
+
+    def gpt_decode_step(self):
+        self._rc(self.lib.dtts_gpt_decode_step(self.h, self._stream()))
+
+    def gpt_decode(self, n_steps):
+        n = C.c_int(0)
+        self._rc(self.lib.dtts_gpt_decode(self.h, int(n_steps), C.byref(n), self._stream()))
+        return n.value
+
+    def gpt_steps(self):
+        return int(self.lib.dtts_gpt_steps(self.h))
+
+    def gpt_all_finished(self):
+        f = C.c_int(0)
+        self._rc(self.lib.dtts_gpt_all_finished(self.h, C.byref(f), self._stream()))
+        return bool(f.value)
+
+    def gpt_finish(self):
+        """-> (codes int32 [B,G] incl. stop, ncodes [B], latents cuda [B,768,G])"""
+        B, G, lat, _ = self._session
+        codes = np.zeros((B, G), np.int32)
+        ncodes = np.zeros((B,), np.int32)
+        self._rc(self.lib.dtts_gpt_finish(self.h, codes.ctypes.data_as(_lib.c_int_p), ncodes.ctypes.data_as(_lib.c_int_p), self._stream()))
+        self._session = None
+        return codes, ncodes, lat
+
     def gpt_latents(self, refer, refer_lens, texts, codes_list):
         """teacher-forced latents (UnifiedVoice.forward(return_latent=True)) -> cuda [B,768,n_max] channel-major"""
         _check(refer, "refer")
@@ -214,10 +265,16 @@ class Runtime:
         return out
 
     # ------------------------------------------------------------------ stage C
-    def vocoder(self, mel, seed, sample_ids, lens=None, noise_scale=0.667, noise_override=None, return_z=False):
+    def vocoder(self, mel, seed, sample_ids, lens=None, noise_scale=0.667, noise_override=None, return_z=False, stream_chunk=0):
+        """infer_flowvae; stream_chunk > 0: the generator runs in windows of that many frames (+ 16-frame halo), dtts_vocoder_stream"""
         _check(mel, "mel"); _check(noise_override, "noise_override")
         B, _, T = mel.shape
         wav = torch.empty((B, 1, 256 * T), device=self.device, dtype=torch.float32)
+        if stream_chunk:
+            li, si = _ints(lens), _ints(sample_ids)
+            self._rc(self.lib.dtts_vocoder_stream(self.h, _ptr(mel), li[0] if li else None, B, T, int(seed), si[0], float(noise_scale),
+                                                  _ptr(noise_override), int(stream_chunk), _ptr(wav), self._stream()))
+            return wav
         z = torch.zeros((B, self.cfg["vaegan"]["inter_channels"], T), device=self.device, dtype=torch.float32) if return_z else None
         li, si = _ints(lens), _ints(sample_ids)
         self._rc(self.lib.dtts_vocoder(self.h, _ptr(mel), li[0] if li else None, B, T, int(seed), si[0], float(noise_scale),
@@ -325,6 +382,28 @@ class Runtime:
         self._rc(self.lib.dtts_op_conv1d(self.h, name.encode(), _ptr(x), li[0] if li else None, B, Cin, Tin, cout, kw, stride, dil, pad,
                                          pro_act, epi_act, gate, phases, _ptr(res), _ptr(y), tout, self._stream()))
         return y
+
+    def diff_p_sample(self, x, code_emb, step, seed, sample_ids, lens=None, noise=None, return_x0=False):
+        """one GaussianDiffusion.p_sample at sampling step `step` (49 = first): returns the new x (and pred_xstart)"""
+        _check(x, "x"); _check(code_emb, "code_emb"); _check(noise, "noise")
+        B, _, T = x.shape
+        xo = x.clone()
+        x0 = torch.zeros_like(x) if return_x0 else None
+        li, si = _ints(lens), _ints(sample_ids)
+        self._rc(self.lib.dtts_diff_p_sample(self.h, _ptr(xo), _ptr(code_emb), li[0] if li else None, B, T, int(step), int(seed), si[0],
+                                             _ptr(noise), _ptr(x0), self._stream()))
+        return (xo, x0) if return_x0 else xo
+
+    def op_sample_logits(self, logits, history, uniforms, top_k=50, top_p=0.8, temperature=0.8, repetition_penalty=2.0):
+        """device sampler on logits rows [R, V] (R <= 8) with the rows' input_ids history [R, n] and one uniform per row -> token ids"""
+        _check(logits, "logits"); _check(uniforms, "uniforms")
+        R, V = logits.shape
+        hist = np.ascontiguousarray(np.asarray(history, np.int32).reshape(R, -1))
+        out = np.zeros((R,), np.int32)
+        self._rc(self.lib.dtts_op_sample_logits(self.h, _ptr(logits), R, V, hist.ctypes.data_as(_lib.c_int_p), hist.shape[1], _ptr(uniforms),
+                                                int(top_k or 0), float(top_p if top_p is not None else 1.0), float(temperature),
+                                                float(repetition_penalty), out.ctypes.data_as(_lib.c_int_p), self._stream()))
+        return out
 
     def op_philox_normal(self, n, seed, sample_ids, stage, step):
         si = _ints(sample_ids)

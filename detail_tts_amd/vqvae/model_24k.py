@@ -27,14 +27,24 @@ def denormalize_torch_mel(norm_mel):
 
 def do_spectrogram_diffusion(diffusion_model, diffuser, latents, conditioning_latents, temperature=1, verbose=True, *, seed=0,
                              sample_ids=None, lengths=None):
-    """vqvae/model_24k.py:479-492: latents [B,n,768], conditioning_latents [B,1536] -> normalised mel [B,128,4n]"""
-    if temperature != 1:
-        raise NotImplementedError("temperature != 1 is not used by infer (vqvae/model_24k.py:803)")
+    """vqvae/model_24k.py:479-492: latents [B,n,768], conditioning_latents [B,1536] -> normalised mel [B,128,4n].
+    temperature scales the initial noise (`torch.randn(output_shape) * temperature`, :488)."""
     out_len = latents.shape[1] * 4
     emb = diffusion_model.timestep_independent(latents, conditioning_latents, out_len, False, lengths=lengths)
     lens = None if lengths is None else [4 * int(n) for n in lengths]
-    mel = diffuser.p_sample_loop(diffusion_model, (latents.shape[0], 128, out_len), model_kwargs={"precomputed_aligned_embeddings": emb},
-                                 progress=verbose, seed=seed, sample_ids=sample_ids, lens=lens)
+    noise = None
+    if temperature != 1:
+        rt = diffusion_model.rt
+        B = latents.shape[0]
+        ids = list(range(B)) if sample_ids is None else list(sample_ids)
+        noise = torch.zeros((B, 128, out_len), device=rt.device, dtype=torch.float32)
+        for b in range(B):                  # each row's noise is indexed over its own [128, len] (the single-utterance order)
+            L = out_len if lens is None else lens[b]
+            z = rt.op_philox_normal(128 * L, seed, [ids[b]], 2, 0)           # STAGE_DIFF_INIT
+            noise[b, :, :L] = z.reshape(128, L) * float(temperature)
+    mel = diffuser.p_sample_loop(diffusion_model, (latents.shape[0], 128, out_len), noise=noise,
+                                 model_kwargs={"precomputed_aligned_embeddings": emb}, progress=verbose, seed=seed,
+                                 sample_ids=sample_ids, lens=lens)
     return mel[:, :, :out_len]
 
 
@@ -45,9 +55,8 @@ class Generator:
         self.rt = rt
 
     def forward(self, x, g=None, lengths=None):
-        if g is None:
-            raise NotImplementedError("the inference path always conditions the generator on g (gin_channels=768)")
-        return self.rt.generator(x.float().contiguous(), g.reshape(g.shape[0], -1).float().contiguous(), lengths)
+        g2 = None if g is None else g.reshape(g.shape[0], -1).float().contiguous()      # `if g is not None` (:271-273)
+        return self.rt.generator(x.float().contiguous(), g2, lengths)
 
     __call__ = forward
 
@@ -94,6 +103,8 @@ class SynthesizerTrn:
                                               conditioning_free=True, conditioning_free_k=COND_FREE_K)
         self.rt.timestep_map = list(self.infer_diffuser.timestep_map)
         self.stage_ms = None          # set to {} to collect per-stage hipEvent timings of the next infer() call
+        self._voc_stream = None       # second stream of infer(stream_vocoder=True)
+        self.vocoder_done = None
 
     def eval(self):
         return self
@@ -105,8 +116,14 @@ class SynthesizerTrn:
 
     # ------------------------------------------------------------------------------------------------------------
     def infer(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
-              forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False, return_lengths=False):
-        """vqvae/model_24k.py:774-810.  Returns wav [B,1,1024*n_max] (B=1 unless batch=True)."""
+              forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False, return_lengths=False,
+              stream_vocoder=False, vocoder_chunk=256, wait=True):
+        """vqvae/model_24k.py:774-810.  Returns wav [B,1,1024*n_max] (B=1 unless batch=True).
+
+        stream_vocoder: stage C runs on a second HIP stream, its generator window by window (`vocoder_chunk` mel frames + halo,
+        dtts_vocoder_stream).  With wait=False the call returns while stage C is still running - `self.vocoder_done` is the event
+        to wait on before reading the waveform - so the NEXT call's GPT decode and diffusion (first stream) overlap this call's
+        vocoder (BASELINE configs[4]: long-form batches, overlapped diffusion / vocoder streams)."""
         text = torch.as_tensor(text)
         refer = torch.as_tensor(refer)
         tl = torch.as_tensor(text_length).reshape(-1).tolist()
@@ -152,7 +169,23 @@ class SynthesizerTrn:
         mel = self.rt.diff_sample(code_emb, seed, sample_ids, lens=lens_t, denorm=True)
         mark("diff_sample")
         # ---- stage C (:805-809)
-        wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
+        if stream_vocoder:
+            cur = torch.cuda.current_stream(self.device)
+            if self._voc_stream is None:
+                self._voc_stream = torch.cuda.Stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            with torch.cuda.stream(self._voc_stream):
+                self._voc_stream.wait_event(ready)
+                wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk))
+                mel.record_stream(self._voc_stream)
+                self.vocoder_done = torch.cuda.Event()
+                self.vocoder_done.record(self._voc_stream)
+            wav.record_stream(cur)
+            if wait:
+                cur.wait_event(self.vocoder_done)
+        else:
+            wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
         mark("vocoder")
         if self.stage_ms is not None:
             torch.cuda.synchronize(self.device)

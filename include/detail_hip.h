@@ -98,14 +98,40 @@ typedef struct dtts_gpt_options {
 
 /* UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF GenerationMixin._sample, with a real KV cache
  * (mel position k for the k-th code) and the sampler on the device.  refer [B,128,Tr] device, refer_lens HOST,
- * text HOST int32 [B][Lt_max] exactly as api.py passes it (trailing 0 included), text_lens HOST.
+ * text HOST int32 [B][Lt_max] exactly as api.py passes it (trailing 0 included; ids are range-checked), text_lens HOST.
  * Outputs: codes HOST int32 [B][max_generate_length] (stop token included, rows padded with 8193), ncodes HOST [B],
  * latents_cm DEVICE [B,768,lat_stride]: column k = final_norm(ln_f(h)) at decode step k, i.e. the same values the
- * reference recomputes with UnifiedVoice.forward(return_latent=True).  Synchronises the stream
- * once every 16 tokens (finish flags) and at the end (codes). */
+ * reference recomputes with UnifiedVoice.forward(return_latent=True).
+ * = dtts_gpt_prefill + dtts_gpt_decode in 16-token hipGraph replays + dtts_gpt_finish; any B (groups of 8 rows run one
+ * after the other).  Synchronises once per 16 tokens (finish flags; never when suppress_eos) and at the end (codes). */
 int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
                       int Lt_max, int B, const dtts_gpt_options* opts, int* codes_out, int* ncodes_out, float* latents_cm,
                       int lat_stride, void* stream);
+
+/* ---- the same loop as a decode SESSION (state in the handle: KV cache, sampler state, device control block) --------------
+ * The per-token Python/HF loop of the reference (gpt/model.py:542-544 generate() -> :68-185 forward per token) becomes a
+ * fixed launch sequence: every step-dependent value (token index, positions, seed, sampling options, output pointers) is
+ * read from a device control block, so one step has constant arguments and is graph-capturable.
+ *
+ * dtts_gpt_prefill: conditioning encoder (gpt/model.py:521-524), prefix embeddings, GPT-2 prefill over
+ *   [cond | text | start_mel] filling the KV cache, and the FIRST sampled token.  B <= 8 rows per session.
+ *   latents_cm DEVICE [B,768,lat_stride] (may be NULL) receives one column per generated token as the steps run. */
+int dtts_gpt_prefill(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
+                     int Lt_max, int B, const dtts_gpt_options* opts, float* latents_cm, int lat_stride, void* stream);
+/* One more token for every row: 5 launches per GPT-2 layer + final LayerNorms + mel_head + sampler on `stream`, no host
+ * synchronisation, no host-side state that a replay would miss except the step count reported by dtts_gpt_steps - the caller
+ * may capture it in its own hipGraph.  Steps beyond max_generate_length are no-ops on the device. */
+int dtts_gpt_decode_step(dtts_handle* h, void* stream);
+/* n_steps more tokens (clamped to max_generate_length) by replaying the handle's own captured hipGraphs (16-step chunks +
+ * single steps) on an internal stream ordered after / before `stream` by events.  Asynchronous.  Returns the number of
+ * steps enqueued through *n_done (may be NULL). */
+int dtts_gpt_decode(dtts_handle* h, int n_steps, int* n_done, void* stream);
+/* tokens generated so far per row (prefill counts 1); 0 without a session */
+int dtts_gpt_steps(dtts_handle* h);
+/* *all_finished != 0 when every row has drawn the stop token.  Synchronises the stream. */
+int dtts_gpt_all_finished(dtts_handle* h, int* all_finished, void* stream);
+/* codes HOST int32 [B][max_generate_length] / ncodes HOST [B] as dtts_gpt_generate; ends the session.  Synchronises. */
+int dtts_gpt_finish(dtts_handle* h, int* codes_out, int* ncodes_out, void* stream);
 
 /* UnifiedVoice.forward(..., return_latent=True) (gpt/model.py:429-491) as called at vqvae/model_24k.py:796-799:
  * teacher-forced pass over [cond | text | start, codes, stop]; codes HOST [B][n_max], ncodes HOST [B] ->
@@ -139,6 +165,12 @@ int dtts_diff_sample(dtts_handle* h, const float* code_emb, const int* lens, int
                      const int* sample_ids, int n_steps, const float* x_init, const float* step_noise, float* mel_out,
                      int denorm, void* stream);
 
+/* One GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at sampling step `step` (49 = first): both model
+ * forwards, CFG combine, x0 clamp, posterior mean, learned-range variance, noise (Philox spec, or `noise` [B,128,T] if given).
+ * x [B,128,T] is updated IN PLACE; x0_out (may be NULL) receives pred_xstart.  Unit entry of the sampler parity tests. */
+int dtts_diff_p_sample(dtts_handle* h, float* x, const float* code_emb, const int* lens, int B, int T, int step,
+                       unsigned long long seed, const int* sample_ids, const float* noise, float* x0_out, void* stream);
+
 /* ---- stage C: flow-VAE front + HiFiGAN generator -------------------------------------------------- */
 
 /* SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863): ref_enc -> in_proj -> enc_p -> z_p -> flow^-1 -> dec.
@@ -147,7 +179,14 @@ int dtts_diff_sample(dtts_handle* h, const float* code_emb, const int* lens, int
 int dtts_vocoder(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
                  float noise_scale, const float* noise_override, float* wav, float* trace_z, void* stream);
 
-/* Generator.forward (vqvae/model_24k.py:269-288): z [B,192,T], g [B,768] -> wav [B,1,256*T] */
+/* dtts_vocoder with the HiFiGAN generator (vqvae/model_24k.py:269-288) run window by window: chunk_frames mel frames + a 16-frame
+ * halo per window (its receptive field is 13.2 frames), interiors concatenated = the one-shot waveform to fp32 rounding, generator
+ * scratch of one window (60 s utterances, BASELINE configs[4]).  ref_enc / enc_p / flow^-1 need the whole sequence and run once.
+ * Stage C uses its own scratch arena: this call may run on a second stream while stage A/B calls of the next batch run on the first. */
+int dtts_vocoder_stream(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
+                        float noise_scale, const float* noise_override, int chunk_frames, float* wav, void* stream);
+
+/* Generator.forward (vqvae/model_24k.py:269-288): z [B,192,T], g [B,768] (NULL: `g is None`, no conditioning) -> wav [B,1,256*T] */
 int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* lens, int B, int T, float* wav, void* stream);
 
 /* MelStyleEncoder.forward (vqvae/modules/modules.py:696-720) of "ref_enc" or "gpt.conditioning_encoder":
@@ -179,6 +218,7 @@ int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int 
 
 /* Runtime options:
  *   "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams;
+ *   "gpt_graph"   (default 1): dtts_gpt_decode replays captured hipGraphs; 0 = the same launches issued eagerly;
  *   "conv_x3"     (default 1): diffusion-trunk convs and attention on the split-precision path (every fp32 operand as three
  *                 bf16 planes, six bf16 MFMA products per fp32 product, fp32 accumulate: fp32-class error at 1.7-2.3x the fp32
  *                 MFMA rate); 0 = the exact fp32-MFMA kernels. */
@@ -210,6 +250,12 @@ int dtts_op_resblock(dtts_handle* h, const char* prefix, const float* x, const i
 int dtts_op_conv1d(dtts_handle* h, const char* name, const float* x, const int* lens_in, int B, int Cin, int Tin, int Cout,
                    int KW, int stride, int dil, int pad, int pro_act, int epi_act, int gate, int phases, const float* res,
                    float* y, int Tout_alloc, void* stream);
+/* The device sampler on given logits rows: HF RepetitionPenalty / Temperature / TopK / TopP processors as the reference's
+ * generate() applies them (vqvae/model_24k.py:786-792) + the inverse-CDF draw on uniforms[r].  logits DEVICE [R][V] (R <= 8),
+ * history HOST [R][hist_len] ids present in the row's input_ids, uniforms DEVICE [R] -> tokens HOST [R].  Synchronises. */
+int dtts_op_sample_logits(dtts_handle* h, const float* logits, int R, int V, const int* history, int hist_len,
+                          const float* uniforms, int top_k, float top_p, float temperature, float repetition_penalty,
+                          int* tokens_out, void* stream);
 /* Philox normal fill: out[b, 0..n) for (seed, sample_ids[b], stage, step) */
 int dtts_op_philox_normal(dtts_handle* h, float* out, int n, int B, unsigned long long seed, const int* sample_ids, int stage,
                           int step, void* stream);

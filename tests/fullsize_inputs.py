@@ -1,0 +1,28 @@
+"""Seeded inputs of tests/golden/fullsize.npz (same recipe as tests/golden/make_golden_fullsize.py::inputs; the reference's
+outputs for them are stored subsampled in the fixture)."""
+import numpy as np
+
+T = 936
+N_CODES = 234
+T_LONG = 5624
+L_TEXT = 60
+
+
+def inputs(seed=11):
+    rs = np.random.RandomState(seed)
+    d = {}
+    d["x"] = rs.randn(1, 128, T).astype(np.float32)
+    d["code_emb"] = (rs.randn(1, 768, T) * 0.5).astype(np.float32)
+    d["xa"] = rs.randn(1, 768, T).astype(np.float32)
+    d["xa_long"] = rs.randn(1, 768, T_LONG).astype(np.float32)
+    d["mel"] = (rs.randn(1, 128, T) * 2 - 5).astype(np.float32)
+    d["refer"] = (rs.randn(1, 128, T) * 2 - 5).astype(np.float32)
+    d["text"] = np.concatenate([rs.randint(3, 255, (1, L_TEXT)), [[0]]], 1).astype(np.int32)
+    d["codes"] = rs.randint(0, 8192, (1, N_CODES)).astype(np.int64)
+    return d
+
+
+def sub(a, g, ch_stride=None):
+    """[C, T] -> the fixture's (strided block, tail block)"""
+    cs = int(g["ch_stride"]) if ch_stride is None else ch_stride
+    return a[::cs, ::int(g["t_stride"])], a[:, -int(g["tail"]):]

@@ -1,0 +1,292 @@
+"""GPU parity at the HEADLINE sizes (BASELINE.json configs[1]/[2]/[4]): T = 936 mel frames, 234 codes, batch 8, and the 60 s
+attention length T = 5624.  Two checkers: `tests/golden/fullsize.npz` = subsampled outputs of the REFERENCE ITSELF at these sizes
+(make_golden_fullsize.py), and the numpy oracle densely (every element) on the same inputs.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+from fullsize_inputs import N_CODES, T, inputs, sub
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def I():
+    return inputs()
+
+
+@pytest.fixture(scope="module")
+def G(golden):
+    return golden("fullsize")
+
+
+@pytest.fixture(scope="module")
+def rt(weights):
+    from detail_tts_amd.runtime import Runtime
+    return Runtime(weights, folded=True, parts=("diffusion", "gpt", "vocoder"))
+
+
+def check_sub(out, G, key, tol, ch_stride=None):
+    s, t = sub(out, G, ch_stride)
+    e = max(maxabs(s, G[key + "_s"]), maxabs(t, G[key + "_t"]))
+    assert e < tol, (key, e)
+    return e
+
+
+@pytest.mark.parametrize("step", [47, 0])
+@pytest.mark.parametrize("x3", [1, 0])
+def test_diffusion_forward_T936_vs_reference(rt, I, G, step, x3):
+    """DiffusionTts.forward (vqvae/diff_model.py:262-322) at T = 936 (8 N-tiles, 15 key tiles): split-precision AND exact-fp32
+    kernels vs the reference's own output, cond + uncond, first and last sampling step."""
+    rt.set_option("conv_x3", x3)
+    try:
+        oc = host(rt.diff_forward(dev(I["x"]), step, dev(I["code_emb"])))[0]
+        ou = host(rt.diff_forward(dev(I["x"]), step, cond_free=True))[0]
+    finally:
+        rt.set_option("conv_x3", 1)
+    check_sub(oc, G, f"fwd{step}_cond", 3e-4)
+    check_sub(ou, G, f"fwd{step}_uncond", 3e-4)
+
+
+def test_diffusion_forward_T936_batch2_vs_oracle_dense(rt, weights, I):
+    """B = 2 (one full-length row, one ragged row) at step 47: EVERY output element vs the oracle, cond and uncond."""
+    from oracle import diffusion as D
+    sched = D.make_schedule()
+    rs = np.random.RandomState(12)
+    lens = [T, 871]
+    x = np.concatenate([I["x"], rs.randn(1, 128, T).astype(np.float32)])
+    ce = np.concatenate([I["code_emb"], (rs.randn(1, 768, T) * 0.5).astype(np.float32)])
+    oc = host(rt.diff_forward(dev(x), 47, dev(ce), lens=lens))
+    ou = host(rt.diff_forward(dev(x), 47, cond_free=True, lens=lens))
+    ts = [sched["timestep_map"][47]]
+    for b, L in enumerate(lens):
+        rc = D.diffusion_forward(weights, x[b:b + 1, :, :L], ts, ce[b:b + 1, :, :L])[0]
+        ru = D.diffusion_forward(weights, x[b:b + 1, :, :L], ts, conditioning_free=True)[0]
+        assert maxabs(oc[b, :, :L], rc) < 3e-4, (b, maxabs(oc[b, :, :L], rc))
+        assert maxabs(ou[b, :, :L], ru) < 3e-4, (b, maxabs(ou[b, :, :L], ru))
+
+
+def test_p_sample_T936_vs_reference(rt, I, G):
+    """One GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at i = 49, T = 936, Philox noise on the device."""
+    x1, x0 = rt.diff_p_sample(dev(I["x"]), dev(I["code_emb"]), 49, 1234, [2], return_x0=True)
+    # eps errors are amplified 153x into pred_xstart at i = 49 before the clamp
+    check_sub(host(x0)[0], G, "ps49_x0", 5e-3)
+    check_sub(host(x1)[0], G, "ps49_x", 1e-3)
+
+
+def test_attention_block_T936_and_T5624_vs_reference(rt, weights, I, G):
+    """AttentionBlock (vqvae/utils/diff_util.py:146-169, 209-215) at the 10 s and the 60 s (configs[4]) lengths."""
+    from oracle import diffusion as D
+    p = "diffusion.layers.3.attn"
+    y = host(rt.op_attention_block(p, dev(I["xa"])))[0]
+    check_sub(y, G, "attn", 1e-4)
+    assert maxabs(y, D.attention_block(weights, p, I["xa"], 16)[0]) < 1e-4          # dense, every element
+    yl = host(rt.op_attention_block(p, dev(I["xa_long"])))[0]
+    check_sub(yl, G, "attn_long", 1e-4, ch_stride=16)
+    # ragged batch at the long length: rows of a batch equal the rows alone
+    rs = np.random.RandomState(13)
+    xb = np.concatenate([I["xa_long"], rs.randn(1, 768, 5624).astype(np.float32)])
+    yb = host(rt.op_attention_block(p, dev(xb), [5624, 5001]))
+    assert maxabs(yb[0], yl) < 1e-6
+    alone = host(rt.op_attention_block(p, dev(xb[1:2, :, :5001])))[0]
+    assert maxabs(yb[1, :, :5001], alone) < 1e-6
+
+
+def test_vocoder_T936_vs_reference_and_oracle(rt, weights, I, G):
+    """infer_flowvae (vqvae/model_24k.py:848-863) at T = 936: z and the 24 kHz waveform vs the reference; waveform vs the oracle."""
+    from oracle import vocoder as V
+    wav, z = rt.vocoder(dev(I["mel"]), 1234, [3], return_z=True)
+    wav, z = host(wav)[0, 0], host(z)[0]
+    check_sub(z, G, "voc_z", 2e-4)
+    ref_rms = float(G["voc_wav_rms"])
+    assert rms(wav[::97], G["voc_wav_s"]) < 1e-4 and rms(wav[-2048:], G["voc_wav_t"]) < 1e-4
+    assert ref_rms > 100 * rms(wav[::97], G["voc_wav_s"])
+    ref = V.infer_flowvae(weights, I["mel"], [T], 1234, [3])
+    assert rms(wav, np.asarray(ref).reshape(-1)) < 1e-4
+
+
+def test_gpt_decode_latents_234_codes_vs_reference(rt, I, G):
+    """KV-cache decode over 234 forced codes (L grows to ~300 keys): the per-step latents equal the reference's
+    UnifiedVoice.forward(return_latent=True) values, at the LAST positions too; teacher-forced pass alike."""
+    codes, ncodes, lat = rt.gpt_generate(dev(I["refer"]), None, [I["text"][0]], 1, [0], max_generate_length=N_CODES + 1,
+                                         forced_codes=[I["codes"][0]])
+    assert np.array_equal(codes[0, :N_CODES], I["codes"][0]) and ncodes[0] == N_CODES + 1
+    lat = host(lat)[0].T                                   # [G, 768]
+    assert maxabs(lat[:N_CODES][::9], G["gpt_lat_s"]) < 2e-4, maxabs(lat[:N_CODES][::9], G["gpt_lat_s"])
+    assert maxabs(lat[N_CODES - 8:N_CODES], G["gpt_lat_t"]) < 2e-4
+    tf = host(rt.gpt_latents(dev(I["refer"]), None, [I["text"][0]], [I["codes"][0]]))[0].T
+    assert maxabs(tf[::9], G["gpt_lat_s"]) < 2e-4 and maxabs(tf[-8:], G["gpt_lat_t"]) < 2e-4
+
+
+def test_gpt_graph_replay_equals_eager_and_session_api(rt, I):
+    """dtts_gpt_prefill / _decode (captured hipGraphs) / _decode_step (eager launches) / _finish: same codes and latents whichever
+    way the steps are issued; steps past max_generate_length are no-ops."""
+    B, Gn = 3, 41
+    rs = np.random.RandomState(14)
+    refer = dev((rs.randn(B, 128, 200) * 2 - 5).astype(np.float32))
+    texts = [np.concatenate([rs.randint(3, 255, n), [0]]) for n in (12, 30, 7)]
+    kw = dict(max_generate_length=Gn, suppress_eos=True)
+    ref_codes, ref_n, ref_lat = rt.gpt_generate(refer, [200, 150, 90], texts, 5, [1, 2, 3], **kw)
+    for mode in ("eager", "graph", "mixed"):
+        rt.gpt_prefill(refer, [200, 150, 90], texts, 5, [1, 2, 3], **kw)
+        assert rt.gpt_steps() == 1
+        if mode == "eager":
+            for _ in range(Gn - 1):
+                rt.gpt_decode_step()
+        elif mode == "graph":
+            assert rt.gpt_decode(1000) == Gn - 1              # clamped to the session length
+        else:
+            assert rt.gpt_decode(17) == 17
+            for _ in range(5):
+                rt.gpt_decode_step()
+            assert rt.gpt_decode(1000) == Gn - 1 - 22
+        assert rt.gpt_steps() == Gn and not rt.gpt_all_finished()
+        codes, n, lat = rt.gpt_finish()
+        assert np.array_equal(codes, ref_codes) and np.array_equal(n, ref_n), mode
+        assert torch.equal(lat, ref_lat), mode
+    rt.set_option("gpt_graph", 0)
+    try:
+        codes, n, lat = rt.gpt_generate(refer, [200, 150, 90], texts, 5, [1, 2, 3], **kw)
+    finally:
+        rt.set_option("gpt_graph", 1)
+    assert np.array_equal(codes, ref_codes) and torch.equal(lat, ref_lat)
+
+
+def test_gpt_batch_above_one_session(rt, weights):
+    """11 rows = two decode sessions (8 + 3): every row equals the row generated alone."""
+    rs = np.random.RandomState(15)
+    B = 11
+    refer = dev((rs.randn(B, 128, 60) * 2 - 5).astype(np.float32))
+    texts = [np.concatenate([rs.randint(3, 255, 4 + b), [0]]) for b in range(B)]
+    codes, n, lat = rt.gpt_generate(refer, None, texts, 9, list(range(20, 20 + B)), max_generate_length=7, suppress_eos=True)
+    for b in (0, 7, 8, 10):
+        c1, _, l1 = rt.gpt_generate(refer[b:b + 1], None, [texts[b]], 9, [20 + b], max_generate_length=7, suppress_eos=True)
+        assert np.array_equal(codes[b], c1[0]), b
+        assert float((lat[b] - l1[0]).abs().max()) < 1e-5
+
+
+@pytest.fixture(scope="module")
+def model(weights):
+    from detail_tts_amd.vqvae.model_24k import SynthesizerTrn
+    return SynthesizerTrn(weights, folded=True)
+
+
+def test_configs2_batch8_full_size_batch_invariance(model):
+    """BASELINE configs[2] as the bench runs it (B = 8, 10 s prompts, 234 free-sampled codes -> T = 936): rows of the batch equal
+    the rows generated alone (same seed / stream id), and a second run is bit-identical."""
+    rs = np.random.RandomState(1)
+    B = 8
+    refer = torch.from_numpy((rs.randn(B, 128, 936) * 2 - 5).astype(np.float32))
+    text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, 60)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+    kw = dict(seed=1234, max_generate_length=235, suppress_eos=True, return_lengths=True)
+    ids = list(range(B))
+    wav, lens = model.infer(text, torch.full((B,), 61), refer, torch.full((B,), 936), batch=True, sample_ids=ids, **kw)
+    assert lens == [234 * 1024] * B and torch.isfinite(wav).all()
+    wav2, _ = model.infer(text, torch.full((B,), 61), refer, torch.full((B,), 936), batch=True, sample_ids=ids, **kw)
+    assert torch.equal(wav, wav2)
+    for b in (0, 5, 7):
+        alone, _ = model.infer(text[b:b + 1], torch.tensor([61]), refer[b:b + 1], torch.tensor([936]), batch=True, sample_ids=[b], **kw)
+        d = (wav[b] - alone[0]).double()
+        assert float(d.pow(2).mean().sqrt()) < 1e-5, (b, float(d.abs().max()))
+        assert float(wav[b].double().pow(2).mean().sqrt()) > 1e-3
+
+
+def test_configs4_long_form_60s_batch4(model):
+    """BASELINE configs[4]: 60 s utterances (n = 1406 codes, T = 5624), batch 4 with ragged lengths, vocoder streamed: the streamed
+    waveform equals the one-shot one, rows equal rows alone, nothing overflows at the long length."""
+    rs = np.random.RandomState(78)
+    B, n = 4, 1406
+    ns = [1406, 1406, 1333, 1190]
+    refer = torch.from_numpy((rs.randn(B, 128, 300) * 2 - 5).astype(np.float32))
+    text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, 30)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+    codes = [rs.randint(0, 8192, size=k) for k in ns]
+    kw = dict(batch=True, seed=11, return_lengths=True)
+    wav, lens = model.infer(text, torch.full((B,), 31), refer, torch.full((B,), 300), sample_ids=list(range(B)), forced_codes=codes, **kw)
+    assert tuple(wav.shape) == (B, 1, n * 1024) and lens == [k * 1024 for k in ns]
+    for b in range(B):
+        w = wav[b, 0, :lens[b]]
+        assert bool(torch.isfinite(w).all()) and float(w.pow(2).mean().sqrt()) > 1e-4
+    ws, _ = model.infer(text, torch.full((B,), 31), refer, torch.full((B,), 300), sample_ids=list(range(B)), forced_codes=codes,
+                        stream_vocoder=True, **kw)
+    for b in range(B):
+        assert float((ws[b, 0, :lens[b]] - wav[b, 0, :lens[b]]).abs().max()) < 1e-5, b
+    alone, _ = model.infer(text[3:4], torch.tensor([31]), refer[3:4], torch.tensor([300]), sample_ids=[3], forced_codes=codes[3:4], **kw)
+    d = (wav[3, 0, :lens[3]] - alone[0, 0]).double()
+    assert float(d.pow(2).mean().sqrt()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ device sampler
+@pytest.mark.parametrize("top_k", [50, None])
+def test_device_sampler_on_peaked_logits_fixture(rt, golden, top_k):
+    """The reference's HF processors on peaked logits (tests/golden/sampler_filter.npz): the DEVICE sampler returns, for uniforms
+    swept through the kept tokens' CDF (interval mid-points, near both edges, and a random sweep), exactly the token of the
+    oracle's inverse-CDF draw; tokens the processors removed are never drawn."""
+    from oracle import gpt as Gm
+    g = golden("sampler_filter")
+    rs = np.random.RandomState(3)
+    for r in range(3):
+        f = Gm.process_logits(g["scores"][r], g["history"][r], top_k=top_k)
+        ref_f = g["filtered_k50" if top_k else "filtered_none"][r]
+        assert np.array_equal(np.isfinite(f), np.isfinite(ref_f))
+        p = np.exp((f - f[np.isfinite(f)].max()).astype(np.float64))
+        p[~np.isfinite(f)] = 0.0
+        c = np.cumsum(p) / p.sum()
+        kept = np.nonzero(p > 0)[0]
+        us, want = [], []
+        lo = np.concatenate([[0.0], c[:-1]])
+        for v in kept:
+            w = c[v] - lo[v]
+            if w < 2e-5:                       # narrower than the fp32 resolution of the device's own CDF: edge order undefined
+                continue
+            for frac in (0.5, 0.02, 0.98):
+                us.append(lo[v] + frac * w)
+                want.append(v)
+        for u in rs.rand(64):
+            v = int(min(np.searchsorted(c, u, side="right"), c.size - 1))
+            if min(u - lo[v], c[v] - u) > 1e-5:
+                us.append(u)
+                want.append(v)
+        us, want = np.array(us, np.float32), np.array(want)
+        assert len(us) > 40
+        got = []
+        logits = dev(np.repeat(g["scores"][r:r + 1], 8, 0))
+        hist = np.repeat(g["history"][r:r + 1], 8, 0)
+        for i in range(0, len(us), 8):
+            u8 = np.resize(us[i:i + 8], 8).astype(np.float32)
+            got.extend(rt.op_sample_logits(logits, hist, dev(u8), top_k=top_k or 0).tolist()[:len(us[i:i + 8])])
+        got = np.array(got)
+        assert np.array_equal(got, want), (r, top_k, np.nonzero(got != want)[0][:5], got[got != want][:5], want[got != want][:5])
+        assert set(got.tolist()) <= set(kept.tolist())
+
+
+def test_sampler_steps_teacher_forced_golden(rt, golden):
+    """Every p_sample of the reference's trace with x TEACHER-FORCED from the fixture: steps 49, 48, 47 (device Philox noise) and
+    the last step i = 0 (no noise): x_after and pred_xstart per step (vqvae/utils/diffusion.py:445-485)."""
+    g = golden("diff_sampler_steps")
+    ce = dev(g["code_emb"])
+    seed, sid = int(g["seed"]), [int(g["sample_id"])]
+    x = g["x_init"]
+    for i in (49, 48, 47):
+        x1, x0 = rt.diff_p_sample(dev(x), ce, i, seed, sid, return_x0=True)
+        e0, e1 = maxabs(host(x0), g[f"x0_after_{i}"]), maxabs(host(x1), g[f"x_after_{i}"])
+        assert e0 < 5e-3 and e1 < 2e-3, (i, e0, e1)
+        x = g[f"x_after_{i}"]                                    # teacher forcing: the reference's own x
+    x1 = rt.diff_p_sample(dev(g["x_before_0"]), ce, 0, seed, sid)
+    assert maxabs(host(x1), g["x_after_0"]) < 2e-4, maxabs(host(x1), g["x_after_0"])

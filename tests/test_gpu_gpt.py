@@ -91,5 +91,12 @@ def test_single_token_and_limits(rt, golden):
     from detail_tts_amd.runtime import DttsError
     with pytest.raises(DttsError):
         rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], 3, [9], max_generate_length=5000)      # > max_mel_tokens
+    # ids index device embedding tables: out-of-range ids are rejected on the host (nn.Embedding raises in the reference)
+    bad = g["text"][0].copy()
+    bad[2] = 300
     with pytest.raises(DttsError):
-        rt.gpt_generate(dev(np.repeat(g["refer"], 17, 0)), None, [g["text"][0]] * 17, 3, list(range(17)), max_generate_length=2)
+        rt.gpt_generate(dev(g["refer"]), None, [bad], 3, [9], max_generate_length=2)
+    with pytest.raises(DttsError):
+        rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], 3, [9], max_generate_length=3, forced_codes=[np.array([5, 9000, 7])])
+    with pytest.raises(DttsError):
+        rt.gpt_latents(dev(g["refer"]), None, [g["text"][0]], [np.array([5, 8194])])

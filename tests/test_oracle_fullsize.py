@@ -1,0 +1,59 @@
+"""The oracle against the REFERENCE at the headline sizes (tests/golden/fullsize.npz: subsampled reference outputs at T = 936,
+234 codes, T = 5624; make_golden_fullsize.py).  CPU only; pins the oracle where the GPU parity tests use it densely."""
+import numpy as np
+import pytest
+
+from fullsize_inputs import N_CODES, T, inputs, sub
+from oracle import diffusion as D, gpt as G, philox, vocoder as V
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+@pytest.fixture(scope="module")
+def I():
+    return inputs()
+
+
+@pytest.fixture(scope="module")
+def F(golden):
+    return golden("fullsize")
+
+
+def check(out, F, key, tol, ch_stride=None):
+    s, t = sub(out, F, ch_stride)
+    assert max(maxabs(s, F[key + "_s"]), maxabs(t, F[key + "_t"])) < tol, key
+
+
+def test_forward_and_p_sample_T936(weights, I, F):
+    sched = D.make_schedule()
+    ts = [sched["timestep_map"][47]]
+    oc = D.diffusion_forward(weights, I["x"], ts, I["code_emb"])
+    ou = D.diffusion_forward(weights, I["x"], ts, conditioning_free=True)
+    check(oc[0], F, "fwd47_cond", 5e-5)
+    check(ou[0], F, "fwd47_uncond", 5e-5)
+    ts = [sched["timestep_map"][49]]
+    oc = D.diffusion_forward(weights, I["x"], ts, I["code_emb"])
+    ou = D.diffusion_forward(weights, I["x"], ts, conditioning_free=True)
+    z = philox.normal(1234, 2, philox.STAGE_DIFF_STEP, 49, I["x"].size).reshape(I["x"].shape)
+    x1, x0 = D.p_sample_update(sched, 49, I["x"], oc, ou, z)
+    check(x1[0], F, "ps49_x", 5e-4)
+    check(x0[0], F, "ps49_x0", 2e-3)
+
+
+def test_attention_T936(weights, I, F):
+    check(D.attention_block(weights, "diffusion.layers.3.attn", I["xa"], 16)[0], F, "attn", 2e-5)
+
+
+def test_gpt_latents_234_codes(weights, I, F):
+    lat = G.latents_teacher_forced(weights, I["refer"], [T], I["text"], I["codes"])[0]
+    assert lat.shape == (N_CODES, 768)
+    assert maxabs(lat[::9], F["gpt_lat_s"]) < 5e-5 and maxabs(lat[-8:], F["gpt_lat_t"]) < 5e-5
+
+
+def test_vocoder_T936(weights, I, F):
+    wav = np.asarray(V.infer_flowvae(weights, I["mel"], [T], 1234, [3])).reshape(-1)
+    assert wav.shape[0] == 256 * T
+    r = float(np.sqrt(np.mean((wav[::97].astype(np.float64) - F["voc_wav_s"]) ** 2)))
+    assert r < 2e-5 and float(F["voc_wav_rms"]) > 1000 * r
