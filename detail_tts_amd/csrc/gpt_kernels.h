@@ -39,11 +39,13 @@ void launch_ln_fold_vectors(const float* W, int K, int CoutP, const float* gamma
 
 // Decode GEMV against a K-major packed weight W[K][CoutP], workgroup form (8 waves x RPW rows x 64/256 columns), B <= 8:
 //   part[slice][b][col] = sum_{k in slice} in(b, k) * W[k][col],   gemv_block_slices(K, CoutP) slices, summed by the consumer.
-enum { GP_PLAIN = 0, GP_RESSUM = 1, GP_LNPARTS = 2 };
+enum { GP_PLAIN = 0, GP_RESSUM = 1, GP_LNPARTS = 2, GP_ATTN = 3 };
+constexpr int ATT_REC = 64;      // floats per (sample, head, key split) record of the decode attention: m, l, o[48], padding
 struct GemvIn {
     const float* x = nullptr;        // PLAIN: input rows [B][x_stride]; RESSUM: residual rows
     int x_stride = 0;
-    const float* parts = nullptr;    // RESSUM / LNPARTS: the producing GEMV's partials [in_slices][B][in_stride]
+    const float* parts = nullptr;    // RESSUM / LNPARTS: the producing GEMV's partials [in_slices][B][in_stride];
+                                     // ATTN: the attention's key-split records [B][H][in_slices][ATT_REC], in_stride = head dim
     int in_slices = 0, in_stride = 0, in_act = 0;
     const float* in_bias = nullptr;  // RESSUM: bias of the producing GEMV
     const float* gamma = nullptr;    // RESSUM: weight of the LayerNorm this GEMV sits behind
@@ -58,7 +60,8 @@ int gemv_block_slices(int K, int CoutP);
 void launch_gemv_block(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s);
 
 // single-query attention with c_attn's LN-algebra finish folded in (sums the qkv partials of its head, appends k/v to the cache at
-// the row's position lp[b] + step[b] - 1)
+// the row's position lp[b] + step[b] - 1); out = key-split records [B][H][decode_attention_splits()][ATT_REC] for a GP_ATTN GEMV
+int decode_attention_splits();
 void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* stats, int stats_slices, const float* fold_c,
                                  const float* fold_d, float* cache, long long cache_bs, int cache_cs, const GptCtl* ctl, int B, int H, int D,
                                  float* out, hipStream_t s);

@@ -68,9 +68,30 @@ __device__ __forceinline__ void ln_row_stats(const float* __restrict__ st, int n
     rstd = rsqrtf(fmaxf(Q / (float)K - mean * mean, 0.f) + 1e-5f);
 }
 
-// sum over split-K slices of element (b, k): 4 independent loads per round
+// Sum over the split-K slices of element (b, k).  The partials were written by the previous kernel's other CUs, so every load is
+// an L2 / fabric round trip: ALL loads of the element are issued before the first add (slice counts are 6, 12 or 24: a switch on
+// the uniform count selects a fully unrolled body; a rolled loop would expose one round trip per 4 slices).
+template <int N>
+__device__ __forceinline__ float sum_parts_n(const float* __restrict__ p, long long slice_stride) {
+    float v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[(long long)i * slice_stride];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) { a0 += v[i]; a1 += v[i + 1]; a2 += v[i + 2]; a3 += v[i + 3]; }
+#pragma unroll
+    for (int i = N & ~3; i < N; ++i) a0 += v[i];
+    return (a0 + a1) + (a2 + a3);
+}
 __device__ __forceinline__ float sum_parts(const float* __restrict__ parts, int nsl, long long slice_stride, long long off) {
     const float* p = parts + off;
+    switch (nsl) {
+        case 1: return p[0];
+        case 6: return sum_parts_n<6>(p, slice_stride);
+        case 12: return sum_parts_n<12>(p, slice_stride);
+        case 24: return sum_parts_n<24>(p, slice_stride);
+        default: break;
+    }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int sl = 0;
     for (; sl + 4 <= nsl; sl += 4) {
@@ -88,9 +109,11 @@ __global__ __launch_bounds__(256) void gpt_final_ln_kernel(const float* res, con
                                                            float* y, int C, const GptCtl* ctl) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    float v[8];
+    constexpr int NPER = 4;                  // C <= 1024; every element's loads are issued before the first LayerNorm barrier
+    float v[NPER];
     const int n_per = (C + 255) / 256;
-    for (int i = 0; i < n_per; ++i) {
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
         const int c = tid + i * 256;
         float a = 0.f;
         if (c < C) {
@@ -103,7 +126,8 @@ __global__ __launch_bounds__(256) void gpt_final_ln_kernel(const float* res, con
     block_ln_256(v, n_per, C, g2, b2, red);
     const int step = ctl->step[b];
     float* col = (ctl->latents && step < ctl->max_steps) ? ctl->latents + (long long)b * ctl->lat_bs + step : nullptr;
-    for (int i = 0; i < n_per; ++i) {
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
         const int c = tid + i * 256;
         if (c < C) {
             y[(long long)b * C + c] = v[i];
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(256) void gpt_final_ln_kernel(const float* res, con
 
 void launch_gpt_final_ln(const float* res, const float* bias, const float* parts, int in_slices, int in_stride, int B, const float* g1,
                          const float* b1, const float* g2, const float* b2, float* y, int C, const GptCtl* ctl, hipStream_t s) {
-    DTTS_REQUIRE(C <= 2048, "final LayerNorm width");
+    DTTS_REQUIRE(C <= 1024, "final LayerNorm width");
     hipLaunchKernelGGL(gpt_final_ln_kernel, dim3(B), dim3(256), 0, s, res, bias, parts, in_slices, in_stride, B, g1, b1, g2, b2, y, C, ctl);
     DTTS_CHECK_HIP(hipGetLastError());
 }
@@ -150,6 +174,7 @@ void launch_ln_fold_vectors(const float* W, int K, int CoutP, const float* gamma
 //              column-block-0 workgroups store v to y_out and their rows' (sum, sum sq) to stats_out[slice][b]; GEMV input gamma[k] v
 //   GP_LNPARTS v = act(r_b (sum_slices parts[sl][b][k] - mu_b c[k]) + d[k]) with (mu_b, r_b) from stats_in: the LN-algebra finish
 //              of the producing GEMV (c_fc) + GELU
+//   GP_ATTN    v = the attention output: the key-split partial results (m, l, o) of decode_attention_qkv_kernel combined
 template <int PRO, int VEC, int RPW>
 __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict__ W, int K, int CoutP, GemvIn in, int B,
                                                          float* __restrict__ part) {
@@ -195,6 +220,19 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
         if (PRO == GP_LNPARTS) {
             const float a = sum_parts(in.parts, in.in_slices, pstride, (long long)bb * in.in_stride + k);
             v = act_apply(smr[bb][1] * (a - smr[bb][0] * in.fold_c[k]) + in.fold_d[k], in.in_act, 0.f);
+        } else if (PRO == GP_ATTN) {
+            // parts = [B][H][KS][ATT_REC]: per key split (m, l, o[0..D-1]); in_stride = D, in_slices = KS
+            const int D = in.in_stride, h = k / D, c = k - h * D, H = K / D, KS = in.in_slices;
+            const float* rec = in.parts + ((long long)(bb * H + h) * KS) * ATT_REC;
+            float m = -INFINITY;
+            for (int j = 0; j < KS; ++j) m = fmaxf(m, rec[j * ATT_REC]);
+            float num = 0.f, den = 0.f;
+            for (int j = 0; j < KS; ++j) {
+                const float wj = __expf(rec[j * ATT_REC] - m);        // an empty split has m = -inf, l = 0, o = 0 -> weight 0
+                num += wj * rec[j * ATT_REC + 2 + c];
+                den += wj * rec[j * ATT_REC + 1];
+            }
+            v = num / den;
         } else if (PRO == GP_RESSUM) {
             v = in.x[(long long)bb * in.x_stride + k] + (in.in_bias ? in.in_bias[k] : 0.f);
             if (in.in_slices) v += sum_parts(in.parts, in.in_slices, pstride, (long long)bb * in.in_stride + k);
@@ -263,6 +301,7 @@ template <int VEC, int RPW>
 static void gemv_block_launch_v(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
     const dim3 grid(cdiv(CoutP, 64 * VEC), K / (8 * RPW));
     if (pro == GP_PLAIN) hipLaunchKernelGGL((gemv_block_kernel<GP_PLAIN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else if (pro == GP_ATTN) hipLaunchKernelGGL((gemv_block_kernel<GP_ATTN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
     else if (pro == GP_RESSUM) hipLaunchKernelGGL((gemv_block_kernel<GP_RESSUM, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
     else hipLaunchKernelGGL((gemv_block_kernel<GP_LNPARTS, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
 }
@@ -294,22 +333,29 @@ void launch_gemv_block(int pro, const float* W, int K, int CoutP, const GemvIn& 
 
 // ------------------------------------------------------------------------------------------ decode attention
 // cache layout per (layer, sample): K [C][cap] (channel-major, keys contiguous) then V [cap][C] (token-major).
-// One workgroup per (head, sample).  c_attn's finish is folded in: the workgroup sums the qkv GEMV partials of its own 3*D columns,
-// applies the LayerNorm algebra (row statistics from the producing GEMV), appends k and v to the cache for the later steps and uses
-// them from LDS for this one.  The token position comes from the device-side control block.
+// One workgroup per (head, sample, key split): a (head, sample) streams 2 * 48 * n floats (~115 KB at n = 300) and one CU pulls
+// ~24 GB/s, so the keys are split over KS workgroups (flash-decoding); each leaves (running max, denominator, unnormalised output)
+// and the attention projection's GEMV prologue (GP_ATTN) combines them.  c_attn's finish is folded in: every split sums the qkv GEMV
+// partials of its head and applies the LayerNorm algebra (row statistics from the producing GEMV); the LAST split appends k and v to
+// the cache and owns the new key.  The token position comes from the device-side control block.
 template <int D>
 __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* __restrict__ part, int slices, int B, int CoutP,
                                                                    const float* __restrict__ stats, int stats_slices,
                                                                    const float* __restrict__ fold_c, const float* __restrict__ fold_d,
                                                                    float* cache, long long cache_bs, int cap, const GptCtl* ctl, int H,
                                                                    float* out) {
-    extern __shared__ float sc[];            // [cap] scores / probabilities
+    extern __shared__ float sc[];            // [keys of this split] scores / probabilities
     __shared__ float red[4];
     __shared__ float qkv_s[3][D];
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, ks = blockIdx.z, KS = gridDim.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = H * D;
     const int n = ctl->lp[b] + ctl->step[b];      // keys including the new one, which sits at column n - 1
-    const int pos = n - 1;
+    const int pos = n - 1, nc = n - 1;            // nc cached keys; the new key / value come from LDS
+    const bool last = ks == KS - 1;
+    const int per = (nc + KS - 1) / KS;
+    const int s_lo = ks * per, s_hi = min(nc, s_lo + per);        // cached keys of this split
+    const int nk = max(s_hi - s_lo, 0) + (last ? 1 : 0);          // + the new key
     float* cb = cache + (long long)b * cache_bs;
     if (tid < 3 * D) {
         const int which = tid / D, c = tid - which * D, col = which * C + h * D + c;
@@ -318,23 +364,25 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
         const float a = sum_parts(part, slices, (long long)B * CoutP, (long long)b * CoutP + col);
         const float v = rstd * (a - mean * fold_c[col]) + fold_d[col];
         qkv_s[which][c] = v;
-        if (which == 1) cb[(long long)(h * D + c) * cap + pos] = v;
-        else if (which == 2) cb[(long long)C * cap + (long long)pos * C + h * D + c] = v;
+        if (last) {
+            if (which == 1) cb[(long long)(h * D + c) * cap + pos] = v;
+            else if (which == 2) cb[(long long)C * cap + (long long)pos * C + h * D + c] = v;
+        }
     }
     __syncthreads();
-    const float* kp = cb + (long long)(h * D) * cap;       // K [C][cap]
-    const float* vp = cb + (long long)C * cap + h * D;      // V [cap][C]
+    const float* kp = cb + (long long)(h * D) * cap + s_lo;            // K [C][cap]
+    const float* vp = cb + (long long)C * cap + (long long)s_lo * C + h * D;      // V [cap][C]
     float q[D];
     const float scale = rsqrtf((float)D);
 #pragma unroll
     for (int c = 0; c < D; ++c) q[c] = qkv_s[0][c] * scale;
     float mx = -INFINITY;
-    const int nc = n - 1;                     // cached keys; the new key / value come from LDS
-    for (int s = tid; s < n; s += 256) {
+    const int ncl = nk - (last ? 1 : 0);      // cached keys of this split
+    for (int s = tid; s < nk; s += 256) {
         float kv[D];
-        if (s < nc) {
+        if (s < ncl) {
 #pragma unroll
-            for (int c = 0; c < D; ++c) kv[c] = kp[(long long)c * cap + s];
+            for (int c = 0; c < D; ++c) kv[c] = kp[(long long)c * cap + s];      // D independent coalesced loads in flight
         } else {
 #pragma unroll
             for (int c = 0; c < D; ++c) kv[c] = qkv_s[1][c];
@@ -352,7 +400,7 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float l = 0.f;
-    for (int s = tid; s < n; s += 256) {
+    for (int s = tid; s < nk; s += 256) {
         const float pr = expf(sc[s] - mx);
         sc[s] = pr;
         l += pr;
@@ -362,8 +410,8 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
     __syncthreads();
     l = red[0] + red[1] + red[2] + red[3];
     // PV: thread (slot = tid / 12, c4 = tid % 12) owns the float4 channel group c4 of the keys s = slot, slot + 21, ... (V rows are
-    // token-major: 12 consecutive lanes read one 192-byte row); every load of a thread is independent, so a ~300-key cache is two
-    // batches of loads instead of ~10 dependent rounds.  The 21 slots are then combined through LDS in a fixed order.
+    // token-major: 12 consecutive lanes read one 192-byte row); 8 independent loads per round.  The 21 slots are then combined
+    // through LDS in a fixed order.
     constexpr int D4 = D / 4, SLOTS = 256 / D4;          // 12 float4 per row, 21 key slots (252 threads)
     __shared__ float4 pvs[SLOTS][D4];
     {
@@ -371,36 +419,52 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot < SLOTS) {
             int s = slot;
-            for (; s + 3 * SLOTS < nc; s += 4 * SLOTS) {
-                float4 v[4];
+            for (; s + 7 * SLOTS < ncl; s += 8 * SLOTS) {
+                float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(vp + (long long)(s + u * SLOTS) * C + c4 * 4);
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(vp + (long long)(s + u * SLOTS) * C + c4 * 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const float pr = sc[s + u * SLOTS];
                     acc.x += pr * v[u].x; acc.y += pr * v[u].y; acc.z += pr * v[u].z; acc.w += pr * v[u].w;
                 }
             }
-            for (; s < nc; s += SLOTS) {
-                const float4 v = *reinterpret_cast<const float4*>(vp + (long long)s * C + c4 * 4);
-                const float pr = sc[s];
-                acc.x += pr * v.x; acc.y += pr * v.y; acc.z += pr * v.z; acc.w += pr * v.w;
+            {   // tail: up to 7 keys, loads issued together
+                float4 v[7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const int su = s + u * SLOTS;
+                    v[u] = su < ncl ? *reinterpret_cast<const float4*>(vp + (long long)su * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const int su = s + u * SLOTS;
+                    const float pr = su < ncl ? sc[su] : 0.f;
+                    acc.x += pr * v[u].x; acc.y += pr * v[u].y; acc.z += pr * v[u].z; acc.w += pr * v[u].w;
+                }
             }
-            if (slot == 0) {                                  // the key just produced (value row in LDS)
-                const float pr = sc[nc];
+            if (slot == 0 && last) {                          // the key just produced (value row in LDS)
+                const float pr = sc[ncl];
                 acc.x += pr * qkv_s[2][c4 * 4]; acc.y += pr * qkv_s[2][c4 * 4 + 1]; acc.z += pr * qkv_s[2][c4 * 4 + 2]; acc.w += pr * qkv_s[2][c4 * 4 + 3];
             }
             pvs[slot][c4] = acc;
         }
     }
     __syncthreads();
+    float* rec = out + ((long long)(b * H + h) * KS + ks) * ATT_REC;
     if (tid < D) {
         const int c4 = tid >> 2, e = tid & 3;
         float o = 0.f;
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) o += reinterpret_cast<const float*>(&pvs[q][c4])[e];
-        out[(long long)b * C + h * D + tid] = o / l;
+        rec[2 + tid] = o;                      // unnormalised: sum_s exp(score_s - mx) v_s
     }
+    if (tid == 0) { rec[0] = mx; rec[1] = l; }           // an empty split leaves (-inf, 0, 0): weight 0 in the combine
+}
+
+int decode_attention_splits() {
+    static const int n = []() { const char* v = getenv("DTTS_GPT_KSPLIT"); const int k = v ? atoi(v) : 2; return k < 1 ? 1 : (k > 8 ? 8 : k); }();
+    return n;
 }
 
 void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* stats, int stats_slices, const float* fold_c,
@@ -408,8 +472,8 @@ void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const
                                  float* out, hipStream_t s) {
     DTTS_REQUIRE(D == 48, "decode attention head dim");
     DTTS_REQUIRE(sizeof(float) * (size_t)cache_cs <= 60 * 1024, "decode attention: KV cache too long for the LDS score buffer");
-    hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B), dim3(256), sizeof(float) * cache_cs, s, part, slices, B, CoutP, stats,
-                       stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out);
+    hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B, decode_attention_splits()), dim3(256), sizeof(float) * cache_cs, s, part,
+                       slices, B, CoutP, stats, stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -554,6 +618,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         const unsigned char* seen = p.seen + (long long)b * V;
         const float rp = ctl->repetition_penalty, temp = ctl->temperature;
         const int eos_off = ctl->suppress_eos ? p.eos : -1;
+#pragma unroll 4
         for (int v = tid; v < V; v += SAMP_THREADS) {
             float x = p.bias ? p.bias[v] : 0.f;
             x += sum_parts(p.parts, p.slices, (long long)p.B * p.Vs, (long long)b * p.Vs + v);

@@ -173,7 +173,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     // ---- session storage.  The KV capacity is rounded up so that sessions of similar lengths share one arena layout (and graph).
     const int cap = round_up(Lp + G, 128);
     const long long kv_bs = (long long)2 * C * cap, kv_layer = kv_bs * B;
-    const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * 5 * C + (size_t)2 * B * GEMV_PART_FLOATS + 2 * 64 * GEMV_MAXB * 2) +
+    const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * (4 * C + cfg.gpt_heads * 8 * ATT_REC) + (size_t)2 * B * GEMV_PART_FLOATS + 2 * 64 * GEMV_MAXB * 2) +
                         (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + 64) + sizeof(GptCtl) + 64 * 256;
     if (need > gpt_state_.capacity() || gs_.B != B || gs_.cap != cap || gs_.G != G) {
         gpt_drop_graphs();
@@ -184,7 +184,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
         n.kv = gpt_state_.f32((size_t)NL * kv_layer);
         n.x = gpt_state_.f32((size_t)B * C);
         n.y = gpt_state_.f32((size_t)B * C);
-        n.ab = gpt_state_.f32((size_t)B * C);
+        n.ab = gpt_state_.f32((size_t)B * cfg.gpt_heads * 8 * ATT_REC);
         n.lat = gpt_state_.f32((size_t)B * C);
         n.xa = gpt_state_.f32((size_t)B * C);
         n.part = gpt_state_.f32((size_t)B * GEMV_PART_FLOATS);
@@ -316,10 +316,11 @@ void Model::gpt_step_launches(hipStream_t s) {
         launch_gemv_block(GP_RESSUM, w.attn.w, C, w.attn.CoutP, a, B, gs_.part, s);
         launch_decode_attention_qkv(gs_.part, sq, w.attn.CoutP, gs_.st1, st_sl, w.attn_c, w.attn_d, cache, gs_.kv_bs, gs_.cap, gs_.ctl, B, H, D,
                                     gs_.ab, s);
-        GemvIn p;                                        // K3: attention projection
-        p.x = gs_.ab;
-        p.x_stride = C;
-        launch_gemv_block(GP_PLAIN, w.proj.w, C, w.proj.CoutP, p, B, gs_.part2, s);
+        GemvIn p;                                        // K3: attention projection (combines the key splits)
+        p.parts = gs_.ab;
+        p.in_slices = decode_attention_splits();
+        p.in_stride = D;
+        launch_gemv_block(GP_ATTN, w.proj.w, C, w.proj.CoutP, p, B, gs_.part2, s);
         GemvIn f;                                        // K4: Y = X + proj ; c_fc(gamma2 . Y)
         f.x = gs_.x;
         f.x_stride = C;
