@@ -3,12 +3,14 @@
 
 One "step" = one full pass of the hot path (GPT prefill + 234-token KV-cache decode with on-device sampling ->
 50-step classifier-free-guided diffusion -> flow-VAE + HiFiGAN vocoder) over a batch of 8 synthetic utterances per GPU,
-inputs resident in HBM.  Multi-GPU: one process per GPU (torchrun), utterances sharded with no data-path collective,
-one RCCL broadcast of the packed weight blob at start-up (weak scaling).  Prints ONE JSON line on rank 0.
+inputs resident in HBM.  Multi-GPU: one process per GPU (torchrun), the global batch of 8 x N utterances sharded by
+detail_tts_amd.sharding with no data-path collective, one RCCL broadcast of the packed weight blob at start-up (weak scaling).
+Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,19 +26,29 @@ T_REF = 936              # 10 s prompt
 L_TEXT = 60
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (no sparsity)
+HBM_PEAK_GBS = 8000.0           # same guide: HBM3E 8 TB/s (6.3 TB/s achievable)
+PMC_TRAFFIC = "r02_pmc_layer_traffic.json"      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the trunk kernels (this round)
 
 
 def cpu_baseline(W, seed=1234):
     """The oracle (CPU restatement of the reference, validated against it by tests/golden) timed on the host cores on a
     BOUNDED sample of the same workload: one utterance (10 s prompt, T=936): GPT prefill + 8 KV-cache decode steps,
     1 of the 50 diffusion steps (2 forwards), and the full vocoder pass; GPT-decode and diffusion are scaled to
-    234 tokens / 50 steps."""
+    234 tokens / 50 steps.  Also the reference's own NO-KV-CACHE decode (gpt/model.py:79-80 recomputes the whole prefix every
+    token): one uncached step at the mean sequence length, scaled."""
     from oracle import diffusion as D, gpt as G, vocoder as V
+    blas = 0
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        blas = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count()
+        pass
+    try:
+        import torch
+        torch_threads = torch.get_num_threads()
+    except Exception:
+        torch_threads = 0
+    cores = blas or os.cpu_count()
     rs = np.random.RandomState(1)
     refer = (rs.randn(1, 128, T_REF) * 2 - 5).astype(np.float32)
     text = np.concatenate([rs.randint(3, 255, (1, L_TEXT)), [[0]]], 1)
@@ -47,6 +59,13 @@ def cpu_baseline(W, seed=1234):
     G.generate(W, refer, [T_REF], text, seed, [0], max_generate_length=1, suppress_eos=True)
     t_prefill = time.time() - t0
     t_decode = max(t_gpt9 - t_prefill, 0.0) / 8.0
+    # no KV cache: a full forward over [prefix (63) | start + k codes] per token; cost ~ linear in the length -> one forward at the
+    # mean length (63 + 118 = 181 positions) x 234 tokens
+    prefix = G.prefix_embeddings(W, refer, [T_REF], text)
+    mel_ids = np.concatenate([[[G.START_MEL]], rs.randint(0, 8192, (1, N_CODES // 2))], 1)
+    t0 = time.time()
+    G.logits_nocache(W, prefix, mel_ids)
+    t_nocache_step = time.time() - t0
     sched = D.make_schedule()
     code_emb = rs.randn(1, 768, 4 * N_CODES).astype(np.float32)
     x = rs.randn(1, 128, 4 * N_CODES).astype(np.float32)
@@ -59,12 +78,27 @@ def cpu_baseline(W, seed=1234):
     t0 = time.time()
     V.infer_flowvae(W, mel, [4 * N_CODES], seed, [0])
     t_voc = time.time() - t0
-    total = t_prefill + t_decode * (N_CODES) + t_step * 50 + t_voc
+    rest = t_step * 50 + t_voc
+    total = t_prefill + t_decode * N_CODES + rest
+    total_nocache = t_prefill + t_nocache_step * N_CODES + rest
     audio = N_CODES * 1024 / 24000.0
     return {"value": audio / total, "unit": "audio_s/s", "cores": int(cores), "kind": "port",
+            "threads": {"os_cpu_count": os.cpu_count(), "blas_threads": int(blas), "torch_get_num_threads": int(torch_threads)},
+            "no_kv_cache": {"value": audio / total_nocache, "unit": "audio_s/s",
+                            "note": f"the reference's own decode (no KV cache): one uncached forward at the mean length {t_nocache_step:.2f}s x 234 tokens"},
             "sample": (f"1 utterance, T=936: GPT prefill {t_prefill:.2f}s + 8 decode steps ({t_decode*1e3:.0f} ms/token, scaled x234), "
                        f"1/50 diffusion steps ({t_step:.2f}s, scaled x50), full vocoder {t_voc:.2f}s; "
-                       f"measured {t_gpt9 + t_step + t_voc:.1f}s of CPU work -> est. {total:.0f}s per 9.98 s utterance")}
+                       f"measured {t_gpt9 + t_nocache_step + t_step + t_voc:.1f}s of CPU work -> est. {total:.0f}s (KV cache) / "
+                       f"{total_nocache:.0f}s (no KV cache) per 9.98 s utterance; numpy port of the reference, not the reference's torch code")}
+
+
+def decode_bytes_per_token(cfg, B, lp_mean, n_codes):
+    """Algorithmic HBM bytes of ONE decode step: every GPT-2 weight matrix + the mel head once (fp32), + the KV cache
+    of all rows at the mean cached length."""
+    C, NL, V = cfg["model_dim"], cfg["layers"], cfg["number_mel_codes"]
+    weights = NL * (C * 3 * C + C * C + C * 4 * C + 4 * C * C) * 4 + C * V * 4
+    kv = NL * B * 2 * C * (lp_mean + n_codes / 2.0) * 4
+    return weights, kv
 
 
 def main():
@@ -73,8 +107,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--codes", type=int, default=N_CODES, help="codes per utterance (234 = the BASELINE config; smaller only for dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-out", help="write <path>.rank<k>.json: hashes of the bound weights and of a shared probe utterance")
     args = ap.parse_args()
+    n_codes = args.codes
 
     import torch
     import torch.distributed as dist
@@ -84,7 +121,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("DTTS_BENCH_BACKEND", "nccl")          # "gloo" + DTTS_BENCH_ONE_GPU=1: dry-run of the N>1 path on one GPU
+        backend = os.environ.get("DTTS_BENCH_BACKEND", "nccl")          # "gloo" + DTTS_BENCH_ONE_GPU=1: the N>1 path on one GPU (tests)
         if os.environ.get("DTTS_BENCH_ONE_GPU") == "1":
             local = 0
         if backend == "nccl":
@@ -94,6 +131,7 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
+    from detail_tts_amd.sharding import gather_results, shard_utterances
     from detail_tts_amd.vqvae.model_24k import SynthesizerTrn
     from detail_tts_amd.weights import inference_param_spec, select_inference_params, synthetic_state_dict
     if rank == 0:
@@ -107,19 +145,40 @@ def main():
         W = select_inference_params(zero)
     model = SynthesizerTrn(W, folded=True, device=dev)
     if world > 1:
-        model.rt.broadcast_weights(src=0)
-        model.rt.rebind()                  # rebuild the device-side timestep tables from the broadcast weights
+        if dist.get_backend() == "gloo":            # gloo moves host tensors: stage the blob through the host (tests only)
+            host = model.rt.blob.cpu()
+            dist.broadcast(host, src=0)
+            model.rt.blob.copy_(host)
+        else:
+            model.rt.broadcast_weights(src=0)       # one RCCL broadcast of the 1.07 GB blob over xGMI
+        model.rt.rebind()                           # rebuild the device-side tables (timestep MLPs, LN-algebra vectors, split planes)
         dist.barrier()
+    model.rt.set_option("gpt_graph", 1 if os.environ.get("DTTS_BENCH_GPT_GRAPH") == "1" else 0)
     B = args.batch
-    rs = np.random.RandomState(1 + rank)
-    refer = torch.from_numpy((rs.randn(B, 128, T_REF) * 2 - 5).astype(np.float32)).to(dev)
-    text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, L_TEXT)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+    # the global batch: 8 x N utterances of equal expected length, sharded over the ranks (no data-path collective)
+    mine = shard_utterances([n_codes] * (B * world), world)[rank]
+    assert len(mine) == B
+    rs_all = np.random.RandomState(1)
+    refer_all = (rs_all.randn(B * world, 128, T_REF) * 2 - 5).astype(np.float32)
+    text_all = np.concatenate([rs_all.randint(3, 255, (B * world, L_TEXT)), np.zeros((B * world, 1), np.int64)], 1).astype(np.int32)
+    refer = torch.from_numpy(refer_all[mine]).to(dev)
+    text = torch.from_numpy(text_all[mine])
     tl = torch.full((B,), L_TEXT + 1)
     rl = torch.full((B,), T_REF)
-    sample_ids = [rank * B + b for b in range(B)]
+    sample_ids = list(mine)
+
+    if args.probe_out:
+        # the same (seed, stream id, inputs) on every rank -> bit-identical waveforms iff the broadcast weights were bound correctly
+        pw = model.infer(torch.from_numpy(text_all[:1]), torch.tensor([L_TEXT + 1]), torch.from_numpy(refer_all[:1, :, :200]).to(dev),
+                         torch.tensor([200]), batch=True, seed=7, sample_ids=[1000], max_generate_length=6, suppress_eos=True)
+        pw = pw.cpu().numpy()
+        blob = model.rt.blob.cpu().numpy()
+        json.dump({"rank": rank, "utterances": sample_ids, "blob_sha256": hashlib.sha256(blob.tobytes()).hexdigest(),
+                   "wav_sha256": hashlib.sha256(pw.tobytes()).hexdigest(), "wav_rms": float(np.sqrt(np.mean(pw.astype(np.float64) ** 2)))},
+                  open(f"{args.probe_out}.rank{rank}.json", "w"))
 
     def step(i):
-        return model.infer(text, tl, refer, rl, batch=True, seed=1234 + i, sample_ids=sample_ids, max_generate_length=N_CODES + 1,
+        return model.infer(text, tl, refer, rl, batch=True, seed=1234 + i, sample_ids=sample_ids, max_generate_length=n_codes + 1,
                            suppress_eos=True, return_lengths=True)
 
     for i in range(args.warmup):
@@ -144,16 +203,38 @@ def main():
     dt = time.perf_counter() - t0
     prof = model.rt.profile_report()
     model.rt.profile_enable(False)
-    assert all(l == N_CODES * 1024 for l in lens) and torch.isfinite(wav).all()
+    assert all(l == n_codes * 1024 for l in lens) and torch.isfinite(wav).all()
+    # stage C alone under the all-kernel profiler (untimed): TFLOP/s and algorithmic GB/s of the vocoder stage
+    voc = None
+    if rank == 0 and os.environ.get("DTTS_BENCH_NO_PROF") != "1":
+        mel = torch.from_numpy((np.random.RandomState(5).randn(B, 128, 4 * n_codes) * 2 - 5).astype(np.float32)).to(dev)
+        model.rt.vocoder(mel, 1, sample_ids)
+        model.rt.profile_enable(2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model.rt.vocoder(mel, 1, sample_ids)
+        e1.record()
+        torch.cuda.synchronize()
+        vp = model.rt.profile_report()
+        model.rt.profile_enable(False)
+        vms = e0.elapsed_time(e1)
+        vf, vb = sum(p["flops"] for p in vp), sum(p["bytes"] for p in vp)
+        voc = {"ms": round(vms, 2), "tflops": round(vf / vms / 1e9, 2), "gbs_algorithmic": round(vb / vms / 1e6, 1),
+               "frac_fp32_mfma": round(vf / vms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4), "frac_hbm": round(vb / vms / 1e6 / HBM_PEAK_GBS, 4),
+               "note": "whole stage C (ref_enc, enc_p, flow^-1, HiFiGAN) under the hipEvent profiler with launch brackets on every kernel "
+                       "(slower than the unprofiled stage_ms); fp32 MFMA arithmetic"}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        gather_results([(i, rank) for i in mine], world)          # every utterance accounted for exactly once
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    audio_per_utt = N_CODES * 1024 / 24000.0
+    audio_per_utt = n_codes * 1024 / 24000.0
     total_audio = audio_per_utt * B * world * args.steps
     value = total_audio / dt
     # dominant kernel = the conv-GEMM instantiation with the largest total time
@@ -161,8 +242,8 @@ def main():
     dom = max(convs, key=lambda p: p["total_ms"]) if convs else None
     roof = None
     if dom:
-        # The cond / uncond halves of every diffusion forward run on two HIP streams, so two launches of this kernel are usually
-        # co-resident: the chip-level rate is flops / (union of the launch intervals); avg_launch_us is the raw per-launch mean.
+        # chip-level rate = flops / (union of the launch intervals): equals the per-launch mean when the cond | uncond halves run
+        # merged (one 2B-sample launch per layer, the default); with DTTS_MERGE_CFG=0 two launches are co-resident on two streams
         ach = dom["flops"] / (dom["union_ms"] * 1e-3) / 1e12
         x3 = dom["name"].startswith("conv_x3")
         # conv_x3 computes every fp32 product as 6 bf16 MFMA products (3 x bf16 split operands, detail_tts_amd/csrc/conv_x3.h):
@@ -172,17 +253,20 @@ def main():
         if x3:
             ach *= 6.0
         # HBM-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
-        # same kernel at the bench's per-launch shapes; bench.py cannot attach rocprof to itself).  Launch mix of one diffusion
-        # layer: in_layers 1x1, out_layers k3, qkv 1x1 (M=2304), proj 1x1.
-        traffic = None
+        # same kernel at the bench's per-launch shapes; bench.py cannot attach rocprof to itself).  FETCH_SIZE under-reports 16 B/lane
+        # streams 2x on gfx950 (MI355X_MICROARCH.md, HBM section): corrected here.  Launch mix of one diffusion layer.
+        traffic = ratio = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_layer_traffic.json" if x3 else "r01_pmc_conv_traffic.json")))
-            mix = ["768->768 k1", "768->768 k3", "768->2304 k1", "768->768 k1 (proj)" if x3 else "768->768 k1"]
-            traffic = round(sum((tj[k]["fetch_MB"] + tj[k]["write_MB"]) for k in mix) / len(mix) * 1e6)
+            tj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)))
+            mix = [k for k in tj if "->" in k]
+            traffic = round(sum((2.0 * tj[k]["fetch_MB"] + tj[k]["write_MB"]) for k in mix) / len(mix) * 1e6)
+            alg = sum((tj[k]["alg_in_MB"] + tj[k]["alg_w_MB"] + tj[k]["alg_out_MB"]) for k in mix) / len(mix) * 1e6
+            ratio = round(traffic / alg, 2)
         except Exception:
             pass
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_over_algorithmic": ratio,
+                "traffic_source": f"profiles/{PMC_TRAFFIC}: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction), mean over the layer's launch mix",
                 "arithmetic": "bf16 MFMA x 6 products per fp32 product (fp32-exact split), fp32 accumulate" if x3 else "fp32 MFMA",
                 "fp32_equivalent_tflops": round(fp32_equiv, 2),
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
@@ -190,6 +274,24 @@ def main():
                 "busy_share_of_timed_region": round(dom["union_ms"] * 1e-3 / dt, 3),
                 "overlap": round(dom["total_ms"] / max(dom["union_ms"], 1e-9), 3),
                 "measured": "hipEvents on the launch streams around every launch of the timed region; achieved = flops / union of launch intervals"}
+    # the other stages' rooflines
+    att = next((p for p in prof if p["name"].startswith("flash_attn_x3")), None)
+    roof_att = None
+    if att:
+        a = att["flops"] / (att["union_ms"] * 1e-3) / 1e12
+        roof_att = {"bound": "mfma", "kernel": att["name"], "achieved": round(6 * a, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(6 * a / BF16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_tflops": round(a, 2),
+                    "avg_launch_us": round(att["total_ms"] * 1e3 / att["launches"], 2)}
+    roof_dec = None
+    if "gpt_decode" in stage_ms:
+        wb, kvb = decode_bytes_per_token(model.cfg["gpt"], B, L_TEXT + 4, n_codes)
+        tok_ms = stage_ms["gpt_decode"] / max(n_codes, 1)
+        gbs = (wb + kvb) / (tok_ms * 1e-3) / 1e9
+        roof_dec = {"bound": "hbm", "kernel": "GPT decode step (53 launches: 5 per layer + final LayerNorms + mel_head + sampler)",
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "ms_per_token": round(tok_ms, 4), "weight_bytes_per_token": wb, "kv_bytes_per_token_mean": round(kvb),
+                    "launch_mode": "hipGraph replay" if os.environ.get("DTTS_BENCH_GPT_GRAPH") == "1" else "eager launches (graph replay measured slower)",
+                    "note": "latency-bound chain of short dependent kernels, not bandwidth-bound: DESIGN.md section 4"}
     out = {
         "metric": "generated audio seconds/sec (24 kHz), 10 s prompt, batch 8 per GPU", "value": round(value, 3), "unit": "audio_s/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -197,9 +299,12 @@ def main():
         "rtf": round(dt / total_audio, 5), "per_gpu": round(value / world, 3),
         "config": {"workload": "configs[2]: 1xMI355X batch-8, 10 s prompts (T_ref=936), 234 codes -> 9.984 s audio per utterance; "
                                "GPT KV-cache decode + 50-step CFG diffusion + flow-VAE/HiFiGAN vocoder, seed-0 random-init weights",
-                   "batch_per_gpu": B, "codes": N_CODES, "diffusion_steps": 50, "parallelism": f"replica x{world}"},
+                   "batch_per_gpu": B, "codes": n_codes, "diffusion_steps": 50, "parallelism": f"replica x{world}"},
         "stage_ms": stage_ms,
         "roofline": roof,
+        "roofline_attention": roof_att,
+        "roofline_decode": roof_dec,
+        "roofline_vocoder": voc,
         "kernels": sorted([{"name": p["name"], "launches": p["launches"], "ms": round(p["total_ms"], 2),
                             "busy_ms": round(p["union_ms"], 2),
                             "tflops": round(p["flops"] / max(p["union_ms"], 1e-9) / 1e9, 2)} for p in prof], key=lambda k: -k["ms"])[:8],

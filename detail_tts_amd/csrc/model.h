@@ -172,6 +172,7 @@ public:
         if (key == "two_streams") opt_two_streams_ = value != 0;
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
+        else if (key == "merge_cfg") opt_merge_cfg_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -255,9 +256,11 @@ private:
     hipGraphExec_t gpt_graph_[2] = {nullptr, nullptr};   // [0]: a chunk of decode steps, [1]: one step
     hipStream_t sg_ = nullptr;            // capture / replay stream of the decode graphs
     hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;
-    bool opt_gpt_graph_ = true;
+    bool opt_gpt_graph_ = false;          // dtts_gpt_decode: replay captured hipGraphs (measured 0.8 us per kernel node SLOWER than the
+                                          // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
+    bool opt_merge_cfg_ = true;           // cond | uncond halves of a diffusion forward as ONE 2B-sample launch per layer
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies
     hipStream_t s2_ = nullptr;            // second stream of the two-stream diffusion forward

@@ -522,51 +522,69 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
             run_conv(integ1_, q, s);
         }
     }
+    // Both CFG halves are the same B-sample stack on the same weights.  Merged (default): ONE 2B-sample launch per layer - at B = 8
+    // a 768-channel conv is 768 workgroups = exactly one resident wave of the chip (3 per CU) instead of two half-empty launches that
+    // need a second stream to fill it.  Split (DTTS_MERGE_CFG=0): the halves as two B-sample launch sequences on two streams.
     struct Half {
         hipStream_t st;
-        int nb_integ;
+        int nb;               // samples of the main stack
+        int nb_integ;         // samples of the conditioning_timestep_integrator / its precomputed output
         const float* cin;
+        const float* integ;   // precomputed integrator output for these samples (or null)
+        const int* lens;      // [nb]
         const int* lens_integ;
         const int* xmap;      // integrator-output sample of main-stack sample b (null: identity)
         float* out;
     };
-    hipStream_t sb = two_streams ? s2_ : s;
-    Half halves[2] = {{s, B, cbuf0, lens_i, nullptr, out2},
-                      {sb, Nu, cbuf0 + (size_t)B * C * Ta, lens_i + B, umap_local_, out2 + (size_t)B * OC * T}};
-    (void)umap;
-    if (two_streams) {
+    static const bool env_merge = []() { const char* v = getenv("DTTS_MERGE_CFG"); return !(v && v[0] == '0'); }();
+    const bool merged = env_merge && opt_merge_cfg_;
+    hipStream_t sb = (two_streams && !merged) ? s2_ : s;
+    const size_t hoff = (size_t)B * C * Ta;
+    Half halves[2];
+    int nh;
+    if (merged) {
+        nh = 1;
+        halves[0] = {s, 2 * B, B + Nu, cbuf0, integ, lens2, lens_i, umap, out2};
+    } else {
+        nh = 2;
+        halves[0] = {s, B, B, cbuf0, integ, lens2, lens_i, nullptr, out2};
+        halves[1] = {sb, B, Nu, cbuf0 + hoff, integ ? integ + hoff : nullptr, lens2 + B, lens_i + B, umap_local_, out2 + (size_t)B * OC * T};
+    }
+    const bool forked = two_streams && !merged;
+    if (forked) {
         DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
         DTTS_CHECK_HIP(hipStreamWaitEvent(s2_, ev_fork_, 0));
     }
-    for (int hi = 0; hi < 2; ++hi) {
+    for (int hi = 0; hi < nh; ++hi) {
         const Half& hf = halves[hi];
         hipStream_t st = hf.st;
-        const int nbi = hf.nb_integ;
-        const size_t act = (size_t)B * C * Ta;
+        const int nb = hf.nb, nbi = hf.nb_integ, nbw = std::max(nb, nbi);
+        const size_t act = (size_t)nbw * C * Ta;
         float* bufA = ws_.f32(act);
         float* bufB = ws_.f32(act);
         float* bufC = ws_.f32(act);
         float* qkv = ws_.f32(3 * act);
-        float* ab = ws_.f32((size_t)B * C * 2);
-        void* xs = x3 ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
-        auto dlayer_n = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp, const int* lens, int nb) {
-            res_block_fwd(l.rb, in, tmp, mid, ab, lens, nb, T, Ta, step, st, xs);
-            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, nb, T, Ta, st, xs);
+        float* ab = ws_.f32((size_t)nbw * C * 2);
+        void* xs = x3 ? ws_.raw(x3_bytes(nbw, C, T)) : nullptr;
+        auto dlayer_n = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp, const int* lens, int n) {
+            res_block_fwd(l.rb, in, tmp, mid, ab, lens, n, T, Ta, step, st, xs);
+            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, n, T, Ta, st, xs);
         };
         // conditioning_timestep_integrator (vqvae/diff_model.py:295): B code embeddings | Nu unconditional inputs
         const float* code_path = bufA;
-        if (integ) {
-            code_path = integ + (hi ? (size_t)B * C * Ta : 0);                    // evaluated before the loop (precompute_integrator)
+        if (hf.integ) {
+            code_path = hf.integ;                                              // evaluated before the loop (precompute_integrator)
         } else {
             dlayer_n(integ_[0], hf.cin, bufB, bufC, bufA, hf.lens_integ, nbi);
             dlayer_n(integ_[1], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
             dlayer_n(integ_[2], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
         }
         // integrating_conv, code half, accumulated onto the shared x-path term
-        ConvParams r = cp(code_path, C, bufB, C, B, T, Ta, lens2);
+        ConvParams r = cp(code_path, C, bufB, C, nb, T, Ta, hf.lens);
         r.res = xpath;
         r.res_bs = bs;
         r.res_cs = Ta;
+        r.res_bmod = B;
         r.x_bidx = hf.xmap;
         if (x3) {
             launch_split_planes(code_path, bs, Ta, nullptr, ACT_NONE, hf.lens_integ, T, nbi, C, xs, st);
@@ -578,15 +596,15 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* cur = bufB;
         float* t1 = bufA;
         float* t2 = bufC;
-        for (auto& l : layers_) dlayer_n(l, cur, t1, t2, cur, lens2, B);   // output back into `cur` (x is dead after the residual add)
+        for (auto& l : layers_) dlayer_n(l, cur, t1, t2, cur, hf.lens, nb);   // output back into `cur` (x is dead after the residual add)
         for (auto& rb : tail_) {
-            res_block_fwd(rb, cur, t1, t2, ab, lens2, B, T, Ta, step, st, xs);
+            res_block_fwd(rb, cur, t1, t2, ab, hf.lens, nb, T, Ta, step, st, xs);
             std::swap(cur, t2);
         }
         // out: GN, SiLU, conv k3 (:312)
-        if (x3) launch_gn_split_planes(cur, bs, Ta, lens2, T, B, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
-        else launch_gn_coeffs(cur, bs, Ta, lens2, T, B, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
-        ConvParams o = cp(cur, C, hf.out, OC, B, T, Ta, lens2);
+        if (x3) launch_gn_split_planes(cur, bs, Ta, hf.lens, T, nb, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
+        else launch_gn_coeffs(cur, bs, Ta, hf.lens, T, nb, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
+        ConvParams o = cp(cur, C, hf.out, OC, nb, T, Ta, hf.lens);
         o.pro_ab = ab;
         o.pro_act = ACT_SILU;
         o.pad = 1;
@@ -598,7 +616,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         }
         run_conv(out_conv_, o, st);
     }
-    if (two_streams) {
+    if (forked) {
         DTTS_CHECK_HIP(hipEventRecord(ev_join_, s2_));
         DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join_, 0));
     }

@@ -392,8 +392,8 @@ int Model::gpt_decode(int n_steps, hipStream_t s) {
     DTTS_REQUIRE(gs_.active, "dtts_gpt_decode: no session (call dtts_gpt_prefill first)");
     int n = std::min(n_steps, gs_.G - gs_.steps);
     if (n <= 0) return 0;
-    static const bool env_graph = []() { const char* v = getenv("DTTS_GPT_GRAPH"); return !(v && v[0] == '0'); }();
-    if (!(env_graph && opt_gpt_graph_)) {
+    static const int env_graph = []() { const char* v = getenv("DTTS_GPT_GRAPH"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
+    if (!(env_graph >= 0 ? env_graph != 0 : opt_gpt_graph_)) {
         for (int i = 0; i < n; ++i) gpt_step_launches(s);
         gs_.steps += n;
         return n;

@@ -101,9 +101,8 @@ class Runtime:
 
     def broadcast_weights(self, src=0):
         """One-time RCCL broadcast of the packed blob from rank `src` over xGMI."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(self.blob, src=src)
+        from .sharding import broadcast_blob
+        broadcast_blob(self.blob, src=src)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

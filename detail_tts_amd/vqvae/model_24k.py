@@ -149,10 +149,20 @@ class SynthesizerTrn:
 
         mark("start")
         # ---- stage A: codes + latents (:782-799)
+        session = forced_codes is None and B <= 8
         if forced_codes is None:
-            codes, ncodes, lat = self.rt.gpt_generate(refer, rl, texts, seed, sample_ids, max_generate_length=max_generate_length,
-                                                      top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
-                                                      repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
+            kw = dict(max_generate_length=max_generate_length, top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
+                      repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
+            if session:         # one decode session: prefill (+ first token), then 16-token chunks; finish flags polled per chunk
+                self.rt.gpt_prefill(refer, rl, texts, seed, sample_ids, **kw)
+                mark("gpt_prefill")
+                while self.rt.gpt_steps() < max_generate_length:
+                    if not suppress_eos and self.rt.gpt_all_finished():
+                        break
+                    self.rt.gpt_decode(16)
+                codes, ncodes, lat = self.rt.gpt_finish()
+            else:
+                codes, ncodes, lat = self.rt.gpt_generate(refer, rl, texts, seed, sample_ids, **kw)
             n = [int(c) - 1 for c in ncodes]                       # codes = codes[:, :-1]  (:795)
             if min(n) < 1:
                 raise ValueError("an utterance produced no mel codes (stop token first)")
@@ -160,7 +170,7 @@ class SynthesizerTrn:
         else:
             n = [len(c) for c in forced_codes]
             lat = self.rt.gpt_latents(refer, rl, texts, forced_codes)
-        mark("gpt")
+        mark("gpt_decode" if session else "gpt")
         # ---- stage B (:802-804)
         cond = self.rt.diff_conditioning(refer, rl)
         code_emb = self.rt.diff_timestep_independent(lat, cond, n)

@@ -36,12 +36,16 @@ def main():
     ap.add_argument("--vocab")
     ap.add_argument("--wav")
     ap.add_argument("--pinyin", default=" da4 jia1 hao3 ")
+    ap.add_argument("--ids", help="comma-separated text token ids (bypasses pypinyin + tokenizer: e.g. the demo.ipynb KAT ids)")
+    ap.add_argument("--seed", type=int)
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--out", default="gen.wav")
     ap.add_argument("--max-generate-length", type=int, default=600)
     a = ap.parse_args()
     device = "cuda:0"
-    if a.vocab:
+    if a.ids:
+        ids = [int(v) for v in a.ids.split(",")]
+    elif a.vocab:
         from detail_tts_amd.bpe_tokenizers.voice_tokenizer import VoiceBpeTokenizer
         ids = VoiceBpeTokenizer(a.vocab).encode(a.pinyin)                                   # api.py:23-24
     else:
@@ -61,7 +65,7 @@ def main():
     spec_lengths = torch.LongTensor([spec.shape[-1]])
     text_lengths = torch.LongTensor([text_tokens.shape[-1]])
     with torch.no_grad():
-        wav = vqvae.infer(text_tokens, text_lengths, spec, spec_lengths, max_generate_length=a.max_generate_length,
+        wav = vqvae.infer(text_tokens, text_lengths, spec, spec_lengths, max_generate_length=a.max_generate_length, seed=a.seed,
                           suppress_eos=a.synthetic or a.ckpt.startswith("synthetic"))       # api.py:49
     write_wav(a.out, wav.squeeze(0), 24000)                                                  # api.py:50
     print(f"{a.out}: {wav.shape[-1] / 24000:.2f} s of audio from {spec.shape[-1]} prompt frames and {len(ids)} text ids")

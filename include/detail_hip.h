@@ -218,7 +218,9 @@ int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int 
 
 /* Runtime options:
  *   "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams;
- *   "gpt_graph"   (default 1): dtts_gpt_decode replays captured hipGraphs; 0 = the same launches issued eagerly;
+ *   "gpt_graph"   (default 0): 1 = dtts_gpt_decode replays captured hipGraphs (16-step chunks); 0 = the same launches issued
+ *                 eagerly, 16 steps per call (measured faster on ROCm 7.2: a replayed kernel node costs ~0.8 us more than an eager
+ *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
  *   "conv_x3"     (default 1): diffusion-trunk convs and attention on the split-precision path (every fp32 operand as three
  *                 bf16 planes, six bf16 MFMA products per fp32 product, fp32 accumulate: fp32-class error at 1.7-2.3x the fp32
  *                 MFMA rate); 0 = the exact fp32-MFMA kernels. */

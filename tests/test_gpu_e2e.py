@@ -134,6 +134,58 @@ def test_wav_in_wav_out_example(tmp_path):
         assert f.getframerate() == 24000 and f.getnframes() == 5 * 1024           # 6 tokens incl. the last one dropped -> 5 codes
 
 
+def test_configs0_bundled_prompt_wav_in_wav_out_vs_oracle(model, weights):
+    """BASELINE configs[0] on the device: the reference's bundled 1.wav prompt + the demo.ipynb sentence (38 KAT ids) through the
+    api.py flow (device resampler + log-mel -> infer).  The waveform equals the oracle's for the same mel; the mel equals the oracle
+    front-end's."""
+    import json
+    import os
+    import wave
+    from detail_tts_amd.vqvae.utils.data_utils import Resample, mel_spectrogram_torch
+    from oracle import frontend as FE, pipeline
+    here = os.path.dirname(__file__)
+    with wave.open(os.path.join(here, "golden", "prompt_1.wav"), "rb") as f:
+        sr = f.getframerate()
+        pcm = np.frombuffer(f.readframes(f.getnframes()), np.int16).reshape(-1, f.getnchannels())
+    audio = torch.from_numpy(pcm[:, 0].astype(np.float32)[None] / 32768.0)
+    audio24 = Resample(sr, 24000, rt=model.rt)(audio)                                              # api.py:39
+    spec = mel_spectrogram_torch(audio24, 1024, 128, 24000, 256, 1024, 0.0, None, rt=model.rt)     # api.py:41-47
+    assert tuple(spec.shape) == (1, 128, 416)
+    ref_mel = FE.mel_spectrogram(FE.resample(audio.numpy(), sr, 24000))
+    assert float(np.abs(spec.cpu().numpy() - ref_mel).max()) < 5e-3
+    ids = json.load(open(os.path.join(here, "golden", "tokenizer_kat.json")))[0]["ids"]
+    text = torch.IntTensor(ids + [0])[None]
+    wav = model.infer(text, torch.tensor([text.shape[1]]), spec, torch.tensor([416]), seed=1234, sample_ids=[0], max_generate_length=7,
+                      suppress_eos=True).cpu().numpy()
+    ref = pipeline.infer_one(weights, text[0].numpy(), spec[0].cpu().numpy(), 1234, 0, max_generate_length=7, suppress_eos=True)
+    assert wav.shape == (1, 1, 6 * 1024)
+    assert rms(wav[0, 0], ref) < 1e-3
+
+
+def test_multi_rank_bench_path_on_one_gpu(tmp_path):
+    """The N > 1 code of bench.py itself, 2 ranks sharing ONE GPU over gloo: rank 1 starts from zero weights, receives
+    the packed blob by broadcast, re-binds (device-side timestep tables rebuilt), and its waveform for a shared (seed, sample id)
+    probe utterance equals rank 0's bit for bit; the bench line reports 2 ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTTS_BENCH_ONE_GPU="1", DTTS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    probe = str(tmp_path / "probe")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--batch", "2", "--codes", "12", "--no-cpu-baseline", "--probe-out", probe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "replica x2"
+    h = [json.load(open(f"{probe}.rank{k}.json")) for k in range(2)]
+    assert h[0]["blob_sha256"] == h[1]["blob_sha256"]
+    assert h[0]["wav_sha256"] == h[1]["wav_sha256"] and h[0]["wav_rms"] > 1e-4
+    assert h[0]["utterances"] != h[1]["utterances"]                     # disjoint shards of the global batch
+
+
 def test_long_form_batch4_streaming_vocoder(model):
     """BASELINE configs[4] at reduced length (15 s instead of 60 s to keep the suite short; tools/longform.py runs the full size):
     batch 4, forced codes, and the vocoder's generator streamed in 64-frame chunks == the one-shot waveform."""

@@ -140,6 +140,7 @@ def test_gpt_graph_replay_equals_eager_and_session_api(rt, I):
     way the steps are issued; steps past max_generate_length are no-ops."""
     B, Gn = 3, 41
     rs = np.random.RandomState(14)
+    rt.set_option("gpt_graph", 1)
     refer = dev((rs.randn(B, 128, 200) * 2 - 5).astype(np.float32))
     texts = [np.concatenate([rs.randint(3, 255, n), [0]]) for n in (12, 30, 7)]
     kw = dict(max_generate_length=Gn, suppress_eos=True)
@@ -162,10 +163,7 @@ def test_gpt_graph_replay_equals_eager_and_session_api(rt, I):
         assert np.array_equal(codes, ref_codes) and np.array_equal(n, ref_n), mode
         assert torch.equal(lat, ref_lat), mode
     rt.set_option("gpt_graph", 0)
-    try:
-        codes, n, lat = rt.gpt_generate(refer, [200, 150, 90], texts, 5, [1, 2, 3], **kw)
-    finally:
-        rt.set_option("gpt_graph", 1)
+    codes, n, lat = rt.gpt_generate(refer, [200, 150, 90], texts, 5, [1, 2, 3], **kw)
     assert np.array_equal(codes, ref_codes) and torch.equal(lat, ref_lat)
 
 

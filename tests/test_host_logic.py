@@ -240,3 +240,26 @@ def test_voice_bpe_tokenizer_known_answers():
         assert tok.encode(case["text"]) == case["ids"]
         assert tok.decode(np.array(case["ids"])) == case["decoded"]
     assert remove_extraneous_punctuation("{a}[b]`c—d") == "(a)(b)'c-d" and remove_extraneous_punctuation("@") == ""
+
+
+def test_configs0_cpu_plumbing_on_bundled_prompt(weights):
+    """BASELINE configs[0]: the api.py flow on the reference's bundled 1.wav (44.1 kHz mono int16, 195 979 samples) with the
+    demo.ipynb pinyin sentence (38 ids + trailing 0), random-init weights, on the CPU oracle: resample -> 416 mel frames -> 3 codes
+    -> 12 mel frames -> 3072 samples.  Plumbing check of the whole path at the prompt length api.py really uses."""
+    import json
+    import wave
+    from oracle import frontend as FE, pipeline
+    here = os.path.dirname(__file__)
+    with wave.open(os.path.join(here, "golden", "prompt_1.wav"), "rb") as f:
+        sr, n = f.getframerate(), f.getnframes()
+        pcm = np.frombuffer(f.readframes(n), np.int16).reshape(-1, f.getnchannels())
+    assert (sr, n) == (44100, 195979)
+    audio = FE.resample(pcm[:, 0].astype(np.float32)[None] / 32768.0, sr, 24000)
+    assert audio.shape[1] == 106656
+    mel = FE.mel_spectrogram(audio)[0]
+    assert mel.shape == (128, 416)
+    ids = json.load(open(os.path.join(here, "golden", "tokenizer_kat.json")))[0]["ids"]
+    text = np.array(ids + [0], np.int64)                       # F.pad(text_tokens, (0, 1)), api.py:25
+    assert len(ids) == 38
+    wav = pipeline.infer_one(weights, text, mel, 1234, 0, max_generate_length=4, suppress_eos=True, diffusion_steps=2)
+    assert wav.shape == (3 * 1024,) and np.isfinite(wav).all() and float(np.abs(wav).max()) > 1e-4
