@@ -1,16 +1,19 @@
-// Split-precision (3 x bf16) flash attention for the diffusion trunk (head dim 48, T5 relative-position bias) on gfx950.
+// Split-precision (2 x fp16 planes, 3 products) flash attention for the diffusion trunk (head dim 48, T5 relative-position bias).
 //
 // Same algorithm and register mapping as flash_attn_kernel (attention.hip): the score tile is computed transposed,
 // S^T[key, query] = K^T Q, so each query's scores sit in registers of 4 lanes and P^T is already the B operand of
-// O[c, query] += V[c, key] P^T[key, query].  The matrix products run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into
-// three bf16 planes (a = a0 + a1 + a2, 24 bits) and the six cross products a_i b_j (i + j <= 2) accumulated in fp32 - the result
-// matches the fp32-MFMA kernel to fp32 rounding at 2.3x less matrix-pipe time (336 vs 768 SIMD-cycles per 16 x 16 score tile).
+// O[c, query] += V[c, key] P^T[key, query].  The matrix products run on v_mfma_f32_16x16x32_f16 with every fp32 operand (scaled by a
+// power of two) split into two fp16 planes (a = h0 + h1, 22 bits) and the three cross products h0 h0', h0 h1', h1 h0' accumulated
+// in fp32 (conv_x3.h) - fp32-GEMM-class error at 42 instead of 192 matrix instructions per 16 x 64 score tile.
 //
+//   scales: Q carries scale * log2(e) * 16, K carries 16 -> the score accumulator is 256 S (undone by the fma that adds the bias);
+//           P = exp2(s - m + 10) (the 1024 is free in the exponent), V carries 16 -> the output accumulator is 16384 O, and the
+//           denominator is accumulated from the same scaled P: O = acc / (16 l').
 //   QK^T : K = 48 channels = one full 32-channel MFMA + one half-used (channels 48..63 of Q are zero, the K lanes of that half
 //          re-read valid chunks).  K tile in LDS: chunks (8 channels x 16 B) [plane][c8 0..5][key 0..63]   -> linear ds_read_b128
 //   P V  : one MFMA consumes 32 keys = two 16-key score tiles; k-slot 8g + r <-> key 4g + r (first tile), 8g + 4 + r <-> key
 //          16 + 4g + r (second).  V tile in LDS: chunks (8 keys in that slot order) [plane][ct][u][g][channel 0..15]
-// K, V and Q are split on the fly while staging (hardware v_cvt_pk_bf16_f32); P is split in registers after the softmax.
+// K, V and Q are split on the fly while staging (hardware v_cvt_pk_f16_f32); P is split in registers after the softmax.
 #include "attention.h"
 #include "conv_x3.h"
 #include "split3.h"
@@ -23,19 +26,18 @@ namespace {
 constexpr int D = 48, KT = 64, NW = 8, QPW = 16, QPB = NW * QPW, BIAS_CLIP = 64;
 constexpr int KCH = 6 * KT;                    // K chunks per plane
 constexpr int VCH = 3 * 2 * 4 * 16;            // V chunks per plane
-constexpr int BUF_BYTES = 3 * (KCH + VCH) * 16;   // 36 KiB per stage
+constexpr int NPL = XS_PLANES;
+constexpr int BUF_BYTES = NPL * (KCH + VCH) * 16;   // 24 KiB per stage
+constexpr float QK_SCALE = 16.f, P_SHIFT = 10.f, V_SCALE = 16.f;
 constexpr int NBUF = 2;                            // LDS stages (1: single buffer, two barriers per tile, half the LDS)
 
-__device__ __forceinline__ bf16x8 as_bf(const uint4& q) { return __builtin_bit_cast(bf16x8, q); }
+__device__ __forceinline__ hf8 as_hf(const uint4& q) { return __builtin_bit_cast(hf8, q); }
 
-// the six significant cross products, smallest first
-#define DTTS_X3_MFMA(acc, A, Bq)                                                          \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], Bq[0], acc, 0, 0, 0);             \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], Bq[1], acc, 0, 0, 0);             \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Bq[2], acc, 0, 0, 0);             \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], Bq[0], acc, 0, 0, 0);             \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Bq[1], acc, 0, 0, 0);             \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Bq[0], acc, 0, 0, 0);
+// the three significant cross products, smallest first
+#define DTTS_X3_MFMA(acc, A, Bq)                                                         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], Bq[0], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], Bq[1], acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], Bq[0], acc, 0, 0, 0);
 
 // 512 threads = 8 waves x 16 queries: <= 128 VGPRs -> 2 workgroups (16 waves) per CU share each staged K/V tile 8 ways
 __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams p) {
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
 
     // ---- Q fragments: B operand, lane (query j, g) holds channels kb*32 + 8g .. +7 of each plane, pre-scaled by scale*log2(e)
     const int tq0 = q0 + wave * QPW;
-    const float qs = p.scale * LOG2E;
-    bf16x8 qf[2][3];
+    const float qs = p.scale * LOG2E * QK_SCALE;
+    hf8 qf[2][NPL];
     {
         const int t = tq0 + j;
         const int tc = t < len ? t : len - 1;
@@ -72,11 +74,10 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
             const int c0 = kb * 32 + 8 * g;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (c0 < D) ? qp[(long long)(c0 + e < D ? c0 + e : 0) * p.cs + tc] * qs : 0.f;
-            uint4 w0, w1, w2;
-            split8(v, w0, w1, w2);
-            qf[kb][0] = as_bf(w0);
-            qf[kb][1] = as_bf(w1);
-            qf[kb][2] = as_bf(w2);
+            uint4 w0, w1;
+            split8(v, w0, w1);
+            qf[kb][0] = as_hf(w0);
+            qf[kb][1] = as_hf(w1);
         }
     }
 
@@ -122,16 +123,20 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
         }
     };
     auto store_tile = [&](int buf) {
-        uint4* kd = reinterpret_cast<uint4*>(smem + buf * BUF_BYTES);     // [3][6][64]
-        uint4* vd = kd + 3 * KCH;                                         // [3][ct][u][g][16]
-        uint4 w0, w1, w2;
+        uint4* kd = reinterpret_cast<uint4*>(smem + buf * BUF_BYTES);     // [2][6][64]
+        uint4* vd = kd + NPL * KCH;                                       // [2][ct][u][g][16]
+        uint4 w0, w1;
         if (hasK) {
-            split8(kr, w0, w1, w2);
-            kd[0 * KCH + kc8 * KT + kkey] = w0; kd[1 * KCH + kc8 * KT + kkey] = w1; kd[2 * KCH + kc8 * KT + kkey] = w2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kr[e] *= QK_SCALE;
+            split8(kr, w0, w1);
+            kd[0 * KCH + kc8 * KT + kkey] = w0; kd[1 * KCH + kc8 * KT + kkey] = w1;
         }
         if (hasV) {
-            split8(vr, w0, w1, w2);
-            vd[0 * VCH + vidx] = w0; vd[1 * VCH + vidx] = w1; vd[2 * VCH + vidx] = w2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vr[e] *= V_SCALE;
+            split8(vr, w0, w1);
+            vd[0 * VCH + vidx] = w0; vd[1 * VCH + vidx] = w1;
         }
     };
     load_tile(0);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
         if (has_next) load_tile(kt + 1);
         if (wave_active) {
             const uint4* Kb = reinterpret_cast<const uint4*>(smem + buf * BUF_BYTES);
-            const uint4* Vb = Kb + 3 * KCH;
+            const uint4* Vb = Kb + NPL * KCH;
             // The tile is processed in two independent 32-key halves (one PV MFMA step each): the second half's QK^T MFMAs carry
             // no dependence on the first half's softmax / split VALU work, so the two pipes overlap inside one wave.
             const bool full_tile = (s0 + KT <= len);
@@ -157,16 +162,17 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
             const bool far_hi = s0 - (tq0 + QPW - 1) >= BIAS_CLIP, far_lo = (s0 + KT - 1) - tq0 <= -BIAS_CLIP;
             const bool far = (far_hi || far_lo) && full_tile;
             const float bfar = bias_s[far_hi ? 2 * BIAS_CLIP : 0];
+            constexpr float SU = 1.f / (QK_SCALE * QK_SCALE);            // the score accumulator holds 256 S
             floatx4 sacc[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 sacc[ks] = floatx4{0.f, 0.f, 0.f, 0.f};
-                bf16x8 a[3];
+                hf8 a[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Kb[pl * KCH + kcol0 + ks * 16]);
+                for (int pl = 0; pl < NPL; ++pl) a[pl] = as_hf(Kb[pl * KCH + kcol0 + ks * 16]);
                 DTTS_X3_MFMA(sacc[ks], a, qf[0])
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Kb[pl * KCH + kcol1 + ks * 16]);
+                for (int pl = 0; pl < NPL; ++pl) a[pl] = as_hf(Kb[pl * KCH + kcol1 + ks * 16]);
                 DTTS_X3_MFMA(sacc[ks], a, qf[1])
             }
 #pragma unroll
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            sacc[2 * u + q][r] += bfar;
+                            sacc[2 * u + q][r] = fmaf(sacc[2 * u + q][r], SU, bfar);
                             mx = fmaxf(mx, sacc[2 * u + q][r]);
                         }
                 } else {
@@ -186,10 +192,9 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int s = s0 + (2 * u + q) * 16 + 4 * g + r;
-                            float v = sacc[2 * u + q][r];
                             int off = s - t;
                             off = off < -BIAS_CLIP ? -BIAS_CLIP : (off > BIAS_CLIP ? BIAS_CLIP : off);
-                            v += bias_s[off + BIAS_CLIP];
+                            float v = fmaf(sacc[2 * u + q][r], SU, bias_s[off + BIAS_CLIP]);
                             if (!full_tile) v = (s >= len) ? -INFINITY : v;
                             sacc[2 * u + q][r] = v;
                             mx = fmaxf(mx, v);
@@ -200,13 +205,14 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                 const float m_new = fmaxf(m_run, mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                const float m_sub = m_use - P_SHIFT;
                 float sum = 0.f;
                 float pv[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(sacc[2 * u + q][r] - m_use);
+                        const float e = __builtin_amdgcn_exp2f(sacc[2 * u + q][r] - m_sub);      // 1024 P: the scale is free in the exponent
                         pv[q * 4 + r] = e;
                         sum += e;
                     }
@@ -216,19 +222,18 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                 m_run = m_new;
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) oacc[ct] *= alpha;
-                bf16x8 pf[3];
+                hf8 pf[NPL];
                 {
-                    uint4 w0, w1, w2;
-                    split8(pv, w0, w1, w2);
-                    pf[0] = as_bf(w0);
-                    pf[1] = as_bf(w1);
-                    pf[2] = as_bf(w2);
+                    uint4 w0, w1;
+                    split8(pv, w0, w1);
+                    pf[0] = as_hf(w0);
+                    pf[1] = as_hf(w1);
                 }
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
-                    bf16x8 a[3];
+                    hf8 a[NPL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[pl] = as_bf(Vb[pl * VCH + ((ct * 2 + u) * 4 + g) * 16 + j]);
+                    for (int pl = 0; pl < NPL; ++pl) a[pl] = as_hf(Vb[pl * VCH + ((ct * 2 + u) * 4 + g) * 16 + j]);
                     DTTS_X3_MFMA(oacc[ct], a, pf)
                 }
             }
@@ -241,20 +246,20 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     if (!wave_active) return;
     const int t = tq0 + j;
     if (t >= len) return;
-    const float inv = 1.f / l_run;
+    const float inv = 1.f / (l_run * V_SCALE);          // acc = (1024 P)(16 V), l_run = sum of 1024 P
     if (p.out_x3) {
         // lane (j, g) holds channels ct*16 + 4g + r of query t: half (g & 1) of the 8-channel chunk c8 = h*6 + ct*2 + (g >> 1)
-        unsigned char* ob = static_cast<unsigned char*>(p.out_x3) + ((long long)b * (p.H * D / 8) * 3) * p.x3_tp * 16;
+        unsigned char* ob = static_cast<unsigned char*>(p.out_x3) + ((long long)b * (p.H * D / 8) * NPL) * p.x3_tp * 16;
+        const float sx = inv * XS_SCALE_X;              // the conv's activation planes carry XS_SCALE_X
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
-            unsigned w0[2], w1[2], w2[2];
-            split_pair(oacc[ct][0] * inv, oacc[ct][1] * inv, w0[0], w1[0], w2[0]);
-            split_pair(oacc[ct][2] * inv, oacc[ct][3] * inv, w0[1], w1[1], w2[1]);
+            unsigned w0[2], w1[2];
+            split_pair(oacc[ct][0] * sx, oacc[ct][1] * sx, w0[0], w1[0]);
+            split_pair(oacc[ct][2] * sx, oacc[ct][3] * sx, w0[1], w1[1]);
             const long long c8 = h * (D / 8) + ct * 2 + (g >> 1);
-            unsigned char* o = ob + ((c8 * 3) * p.x3_tp + (t + X3_HALO)) * 16 + (g & 1) * 8;
+            unsigned char* o = ob + ((c8 * NPL) * p.x3_tp + (t + X3_HALO)) * 16 + (g & 1) * 8;
             *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
             *reinterpret_cast<uint2*>(o + (long long)p.x3_tp * 16) = make_uint2(w1[0], w1[1]);
-            *reinterpret_cast<uint2*>(o + 2LL * p.x3_tp * 16) = make_uint2(w2[0], w2[1]);
         }
         return;
     }

@@ -1,24 +1,28 @@
-// fp32-accurate Conv1d on the bf16 matrix pipe: every fp32 operand is split into three bf16 planes (a = a0 + a1 + a2, exact to
-// 24 bits) and the six significant cross products a_i * b_j (i + j <= 2) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
-// Measured error vs an fp64 reference is the same as the fp32 MFMA path's (rel. 7e-7, tools/ubench/gemm_x3.hip) at 1.7x its
-// throughput (6 bf16 MFMAs per 16 channels cost 192 SIMD-cycles against 512 for 8 v_mfma_f32_32x32x2_f32).
+// fp32-accurate Conv1d on the 16-bit matrix pipe ("split precision"): every fp32 operand, scaled by a power of two, is split into
+// TWO fp16 planes (a s = h0 + h1, 22 significant bits; both differences exact in fp32) and the three significant cross products
+// h0 h0', h0 h1', h1 h0' are accumulated in fp32 by v_mfma_f32_32x32x16_f16 (the dropped h1 h1' term is < 2^-22 relative).
+// Measured against an fp64 reference the result carries the error of an fp32 GEMM - rel. 4.5e-7 at K = 768, below a 3 x bf16 / 6
+// product split (6.8e-7: twice the accumulations) and below numpy's sgemm (7.0e-7) - tools/ubench/gemm_x3v.hip - at 3 matrix
+// instructions per 16 channels instead of 8 v_mfma_f32_32x32x2_f32 (96 SIMD-cycles against 512).
 //
-// Operand layout in HBM — 16-byte chunks = 8 consecutive channels of one plane:
-//   w3 [tap][Cin/8][3][CoutP][8 bf16]    split once at bind time from the fp32 packed weights  (launch_split_weights)
-//   x3 [b][Cin/8][3][Tp][8 bf16]         written by the producer side (launch_split_planes: GroupNorm affine + SiLU + zero
-//                                        padding + per-sample length folded in), Tp = round_up(T,128) + 2 halo columns
-// A K-step (16 channels) of a 128-row tile is 6 contiguous 2 KiB runs in HBM and in LDS, so both tiles are moved by LDS-DMA and
-// every ds_read_b128 of an MFMA fragment is bank-conflict-free with no padding or swizzle.
+// Operand layout in HBM - 16-byte chunks = 8 consecutive channels of one plane:
+//   w3 [tap][Cin/8][2][CoutP][8 fp16]    split once at bind time from the fp32 packed weights  (launch_split_weights), x XS_SCALE_W
+//   x3 [b][Cin/8][2][Tp][8 fp16]         written by the producer side (launch_split_planes / launch_gn_split_planes: GroupNorm affine
+//                                        + SiLU + zero padding + per-sample length folded in), x XS_SCALE_X; Tp = round_up(T, 192) + 2
+//                                        halo columns
+// A K-step (16 channels) of a tile is 4 contiguous runs (plane, k-half) in HBM and in LDS, so both tiles are moved by LDS-DMA and every
+// ds_read_b128 of an MFMA fragment is bank-conflict-free with no padding or swizzle.
 #pragma once
 #include "conv_gemm.h"
 
 namespace dtts {
 
 constexpr int X3_HALO = 1;   // zero columns on each side of the time axis (covers k = 3, dilation 1)
-static inline int x3_tp(int T) { return round_up(T, 128) + 2 * X3_HALO; }
-static inline size_t x3_bytes(int B, int C, int T) { return (size_t)B * (C / 8) * 3 * x3_tp(T) * 16; }
+constexpr int X3_BN = 192;   // N tile of the conv kernel: 936 mel frames = 4.875 tiles (2.5 % padding; 128 would pad 8.6 %)
+static inline int x3_tp(int T) { return round_up(T, X3_BN) + 2 * X3_HALO; }
+static inline size_t x3_bytes(int B, int C, int T) { return (size_t)B * (C / 8) * 2 * x3_tp(T) * 16; }
 
-// wp: fp32 packed weights [KW][CinP][CoutP] -> out [KW][CinP/8][3][CoutP][8 bf16]
+// wp: fp32 packed weights [KW][CinP][CoutP] -> out [KW][CinP/8][2][CoutP][8 fp16]
 void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* out, hipStream_t s);
 // x [B][C][T] fp32 (strides) -> x3; v = act(a*x + d) with (a, d) = ab[b][c][0..1] (ab may be null); zero outside [0, len[b])
 void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* ab, int act, const int* lens, int T, int B, int C,

@@ -1,8 +1,10 @@
-// Split-precision (3 x bf16) conv GEMM for gfx950 — see conv_x3.h.
+// Split-precision (2 x fp16 planes, 3 products) conv GEMM for gfx950 - see conv_x3.h.
 //
-// 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA 32x32x16 tiles x 6 products = 24 MFMAs per
-// K-step.  LDS: 2 stages x (W tile 12 KiB + X tile 12 KiB) = 48 KiB -> 3 workgroups per CU.  Per K-step a wave issues 6 LDS-DMA
-// loads (1 KiB each; waves 0,1 fetch W, waves 2,3 fetch X), 12 ds_read_b128 and 24 MFMAs behind ONE barrier.
+// 256 threads = 4 waves (2 x 2), block tile 128 x 192, wave tile 64 x 96 = 2 x 3 MFMA 32x32x16 tiles x 3 products = 18 MFMAs per
+// K-step.  LDS: 2 W stages x 8 KiB + 2 X buffers x 12.1 KiB = 41 KiB -> 3 workgroups per CU.  Per K-step a wave issues 5 LDS-DMA
+// loads (1 KiB each: 2 of the W tile, 3 of the X tile), 10 ds_read_b128 and 18 MFMAs behind ONE barrier.  Tile shape from
+// tools/ubench/gemm_x3v.hip (M = 768 / 2304, B = 16, T = 936): 128 x 192 beats 128 x 128 by 8-10 % (2.5 instead of 8.6 % padded
+// columns, 17 % fewer LDS-DMA bytes per MFMA); deeper pipelines and 256-row tiles measured within +-3 % of it.
 #include "conv_x3.h"
 #include <cstdlib>
 #include "prof.h"
@@ -13,20 +15,23 @@ namespace dtts {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
-constexpr int BM = 128, BN = 128, TILE = 6 * 128 * 16, NSTAGE = 2;
+constexpr int NPL = XS_PLANES, NK = 2 * NPL;        // planes; "kinds" (plane, k-half) of a 16-channel K-step
+constexpr int BM = 128, BN = X3_BN, NSTAGE = 2;
+constexpr int WTILE = NK * BM * 16;                  // 8 KiB: [kind][128 rows][16 B]
+constexpr int XMAIN = NK * BN * 16;                  // 12 KiB: [kind][192 columns][16 B]
+constexpr int XBUF = XMAIN + NK * 2 * 16;            // + 2 halo columns per kind
 
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ wp, int C8, int CoutP, uint4* __restrict__ out) {
     const int m = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, tap = blockIdx.z;
     if (m >= CoutP) return;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = wp[((long long)tap * C8 * 8 + c8 * 8 + e) * CoutP + m];
-    uint4 q0, q1, q2;
-    split8(v, q0, q1, q2);
-    uint4* o = out + ((long long)(tap * C8 + c8) * 3) * CoutP + m;
+    for (int e = 0; e < 8; ++e) v[e] = wp[((long long)tap * C8 * 8 + c8 * 8 + e) * CoutP + m] * XS_SCALE_W;
+    uint4 q0, q1;
+    split8(v, q0, q1);
+    uint4* o = out + ((long long)(tap * C8 + c8) * NPL) * CoutP + m;
     o[0] = q0;
     o[CoutP] = q1;
-    o[2 * (long long)CoutP] = q2;
 }
 
 template <int ACT, bool AB>
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const int tp = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, b = blockIdx.z;
     if (tp >= Tp) return;
     const int t = tp - X3_HALO, len = lens ? lens[b] : T;
-    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     if (t >= 0 && t < len) {
         const float* xr = x + (long long)b * x_bs + (long long)(c8 * 8) * x_cs + t;
         float v[8];
@@ -51,12 +56,13 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * __frcp_rn(1.f + __expf(-v[e]));
         }
-        split8(v, q0, q1, q2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= XS_SCALE_X;
+        split8(v, q0, q1);
     }
-    uint4* o = out + ((long long)(b * C8 + c8) * 3) * Tp + tp;
+    uint4* o = out + ((long long)(b * C8 + c8) * NPL) * Tp + tp;
     o[0] = q0;
     o[Tp] = q1;
-    o[2 * (long long)Tp] = q2;
 }
 
 // GroupNorm statistics + affine (+ AdaGN scale/shift) + activation + split in ONE kernel: a workgroup owns one (sample, group),
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
     // every workgroup of a (sample, group) computes the statistics (the slab is L2-resident); the split work is divided among them
     for (int item = blockIdx.z * nthr + tid; item < c8n * Tp; item += nthr * gridDim.z) {
         const int c8l = item / Tp, tp = item - c8l * Tp, t = tp - X3_HALO;
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
         if (t >= 0 && t < len) {
             const float* xr = xg + (long long)(c8l * 8) * x_cs + t;
             float v[8];
@@ -151,25 +157,23 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
             for (int e = 0; e < 8; ++e) {
                 v[e] = sa[c8l * 8 + e] * v[e] + sd[c8l * 8 + e];
                 if (ACT == ACT_SILU) v[e] = v[e] * __frcp_rn(1.f + __expf(-v[e]));
+                v[e] *= XS_SCALE_X;
             }
-            split8(v, q0, q1, q2);
+            split8(v, q0, q1);
         }
-        uint4* o = out + ((long long)(b * C8 + g * c8n + c8l) * 3) * Tp + tp;
+        uint4* o = out + ((long long)(b * C8 + g * c8n + c8l) * NPL) * Tp + tp;
         o[0] = q0;
         o[Tp] = q1;
-        o[2 * (long long)Tp] = q2;
     }
 }
 
 // EPI 0: bias (+ residual); 1: + activation / out_scale.   KW3: three taps (else one).
-// K loop order is (16-channel block, tap): the X tile of a channel block carries its halo (128 + KW - 1 columns) and is fetched
-// ONCE, every tap reads it through a shifted (16-byte aligned) ds_read_b128; only the W tile changes per tap.  A k = 3 conv moves
-// 48.5 KiB per channel block through the L2 -> LDS path instead of 72.
+// K loop order is (16-channel block, tap): the X tile of a channel block carries its halo (192 + KW - 1 columns) and is fetched
+// ONCE, every tap reads it through a shifted (16-byte aligned) ds_read_b128; only the W tile changes per tap.
 template <int EPI, bool KW3>
 __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
     constexpr int KW = KW3 ? 3 : 1;
-    constexpr int XBUF = TILE + 6 * 2 * 16;            // 128-column main part + 2 halo columns per kind
-    constexpr int XOFF = 2 * TILE;                     // LDS: W stage 0 | W stage 1 | X buffer 0 | X buffer 1
+    constexpr int XOFF = NSTAGE * WTILE;               // LDS: W stage 0 | W stage 1 | X buffer 0 | X buffer 1 | bias
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
@@ -183,43 +187,42 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
     const int C8 = p.Cin >> 3, c16n = p.Cin >> 4, nks = KW * c16n, Tp = p.x3_tp;
     const int bin = p.x_bidx ? p.x_bidx[b] : b;
     const uint4* wbase = static_cast<const uint4*>(p.w3) + m0 + lane;
-    const uint4* xbase = static_cast<const uint4*>(p.x3) + (long long)bin * C8 * 3 * Tp + n0 + (X3_HALO - p.pad) + lane;
-    const long long wtap = (long long)C8 * 3 * p.CoutP;
+    const uint4* xbase = static_cast<const uint4*>(p.x3) + (long long)bin * C8 * NPL * Tp + n0 + (X3_HALO - p.pad) + lane;
+    const long long wtap = (long long)C8 * NPL * p.CoutP;
 
-    // LDS-DMA pieces (1 KiB = 64 rows of one (plane, k-half) "kind"): 12 per W tile, 12 (+ the 12 halo chunks) per X tile.
+    // LDS-DMA pieces (1 KiB = 64 rows / columns of one (plane, k-half) "kind"): 8 per W tile, 12 (+ the 8 halo chunks) per X tile.
     auto dma = [&](const uint4* g, int lds_off) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
     auto w_piece = [&](int j, int tap, int c16, int stage) {          // j = kind*2 + row half
         const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
-        dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * 3 + pl) * p.CoutP + rh * 64, stage * TILE + kind * 2048 + rh * 1024);
+        dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * NPL + pl) * p.CoutP + rh * 64, stage * WTILE + kind * (BM * 16) + rh * 1024);
     };
-    auto x_piece = [&](int j, int c16, int buf) {
-        const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
-        dma(xbase + ((long long)(2 * c16 + h) * 3 + pl) * Tp + rh * 64, XOFF + buf * XBUF + kind * 2048 + rh * 1024);
+    auto x_piece = [&](int j, int c16, int buf) {                       // j = kind*3 + column block
+        const int kind = j / 3, cb = j - kind * 3, pl = kind >> 1, h = kind & 1;
+        dma(xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + cb * 64, XOFF + buf * XBUF + kind * (BN * 16) + cb * 1024);
     };
-    auto x_halo = [&](int c16, int buf) {                              // lanes 0..11: (kind, column 128 + r)
-        if (lane < 12) {
+    auto x_halo = [&](int c16, int buf) {                              // lanes 0..7: (kind, column 192 + r)
+        if (lane < 2 * NK) {
             const int kind = lane >> 1, pl = kind >> 1, h = kind & 1, r = lane & 1;
-            dma(xbase - lane + ((long long)(2 * c16 + h) * 3 + pl) * Tp + 128 + r, XOFF + buf * XBUF + TILE);
+            dma(xbase - lane + ((long long)(2 * c16 + h) * NPL + pl) * Tp + BN + r, XOFF + buf * XBUF + XMAIN);
         }
     };
 
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
+    f32x16 acc[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        w_piece(wave * 3 + i, 0, 0, 0);
-        x_piece(wave * 3 + i, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i) w_piece(wave * 2 + i, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x_piece(wave * 3 + i, 0, 0);
     // the tile's 128 bias values -> LDS (read back in the epilogue; the first K-step barrier orders the write)
     float* bias_s = reinterpret_cast<float*>(smem + XOFF + 2 * XBUF);
     if (tid < BM) bias_s[tid] = (p.bias && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.f;
@@ -237,38 +240,42 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
         const int c16x = c16 + 1 < c16n ? c16 + 1 : c16;
         const int wst = (ks + 1) & 1, xbuf = (c16 + 1) & 1;
 
-        const unsigned char* As = smem + (ks & 1) * TILE + lhi * 2048;
+        const unsigned char* As = smem + (ks & 1) * WTILE + lhi * (BM * 16);
         const unsigned char* Xb = smem + XOFF + (c16 & 1) * XBUF;
-        bf16x8 a[2][3], bb[2][3];
+        hf8 a[2][NPL], bb[3][NPL];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int nn = wn0 + i * 32 + l31 + tap;                    // column of the haloed tile
-            const unsigned char* xq = nn < 128 ? Xb + lhi * 2048 + nn * 16 : Xb + TILE + lhi * 32 + (nn - 128) * 16;
-            const int xps = nn < 128 ? 4096 : 64;                       // plane stride: main part / halo part
+        for (int j = 0; j < 3; ++j) {
+            const int nn = wn0 + j * 32 + l31 + tap;                    // column of the haloed tile
+            const unsigned char* xq = nn < BN ? Xb + lhi * (BN * 16) + nn * 16 : Xb + XMAIN + lhi * 32 + (nn - BN) * 16;
+            const int xps = nn < BN ? 2 * BN * 16 : 64;                 // plane stride: main part / halo part
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * 4096 + (wm0 + i * 32 + l31) * 16);
-                bb[i][pl] = *reinterpret_cast<const bf16x8*>(xq + pl * xps);
+            for (int pl = 0; pl < NPL; ++pl) bb[j][pl] = *reinterpret_cast<const hf8*>(xq + pl * xps);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) a[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
+        // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first; ONE LDS-DMA piece after every
+        // three or four MFMAs (as a burst the pieces of a CU's 12 waves queue on the texture-address path while every MFMA pipe
+        // idles and the co-resident workgroups fall into lock-step)
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+        int slot = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
+                if (slot < 5) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot < 2) w_piece(wave * 2 + slot, tapn, c16w, wst);
+                    else if (!KW3) x_piece(wave * 3 + (slot - 2), c16x, xbuf);
+                    else if (slot == 2) x_piece(tap * 4 + wave, c16x, xbuf);
+                    else if (slot == 3 && tap == 2 && wave == 0) x_halo(c16x, xbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ++slot;
             }
-        }
-        // term-major: one cross product over the wave's 4 accumulators per group, smallest terms first; ONE LDS-DMA piece after
-        // each group (as a burst the 72 pieces of a CU's 12 waves queue on the texture-address path while every MFMA pipe idles
-        // and the co-resident workgroups fall into lock-step: 161 -> 190 TFLOP/s fp32-equivalent)
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t < 3) w_piece(wave * 3 + t, tapn, c16w, wst);
-            else if (!KW3) x_piece(wave * 3 + (t - 3), c16x, xbuf);
-            else if (t == 3) x_piece(tap * 4 + wave, c16x, xbuf);
-            else if (t == 4 && tap == 2 && wave == 0) x_halo(c16x, xbuf);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (++tap == KW) { tap = 0; ++c16; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 3; ++j) {
             const int n = n0 + wn0 + j * 32 + l31;
             if (n >= nvalid) continue;
             float rv[16];
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row >= p.Cout) continue;
-                float v = acc[i][j][r] + bv[i][r];
+                float v = acc[i][j][r] * XS_ACC_SCALE + bv[i][r];          // undo the operands' power-of-two scales (exact)
                 if (EPI == 1) v = act_apply(v, p.epi_act, p.epi_slope) * p.out_scale;
                 v += p.res_scale * rv[r];
                 yb[(long long)row * p.y_cs + n] = v;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
 }  // namespace
 
 void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* out, hipStream_t s) {
-    DTTS_REQUIRE(CinP % 16 == 0 && CoutP % 128 == 0, "split_weights: padding");
+    DTTS_REQUIRE(CinP % 16 == 0 && CoutP % BM == 0, "split_weights: padding");
     hipLaunchKernelGGL(split_weights_kernel, dim3(cdiv(CoutP, 256), CinP / 8, KW), dim3(256), 0, s, wp, CinP / 8, CoutP,
                        static_cast<uint4*>(out));
     DTTS_CHECK_HIP(hipGetLastError());
@@ -326,7 +333,7 @@ void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* 
     const dim3 grid(cdiv(Tp, 256), C / 8, B);
     uint4* o = static_cast<uint4*>(out);
     const double n = (double)B * C * T;
-    ProfScope ps("split_planes_kernel", 0.0, n * 10.0, s);
+    ProfScope ps("split_planes_kernel", 0.0, n * 8.0, s);
     if (ab) {
         if (act == ACT_SILU) hipLaunchKernelGGL((split_planes_kernel<ACT_SILU, true>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
         else hipLaunchKernelGGL((split_planes_kernel<ACT_NONE, true>), grid, dim3(256), 0, s, x, x_bs, x_cs, ab, lens, T, C / 8, Tp, o);
@@ -344,7 +351,7 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
     DTTS_REQUIRE(act == ACT_NONE || act == ACT_SILU, "gn_split_planes: activation");
     const int Tp = x3_tp(T);
     uint4* o = static_cast<uint4*>(out);
-    ProfScope ps("gn_split_planes_kernel", 0.0, (double)B * C * T * 14.0, s);
+    ProfScope ps("gn_split_planes_kernel", 0.0, (double)B * C * T * 12.0, s);
     static const int ns = []() { const char* v = getenv("DTTS_GN_SPLIT_NS"); return v ? atoi(v) : 1; }();
     static const int nt = []() { const char* v = getenv("DTTS_GN_SPLIT_NT"); return v ? atoi(v) : 1024; }();
     if (act == ACT_SILU)
@@ -364,7 +371,7 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
     static bool attr = false;
-    constexpr size_t lds = (size_t)2 * TILE + 2 * (TILE + 6 * 2 * 16) + BM * sizeof(float);
+    constexpr size_t lds = (size_t)NSTAGE * WTILE + 2 * XBUF + BM * sizeof(float);
     if (!attr) {
         DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -374,11 +381,11 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     }
     const dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);
     const double cols = (double)p.B * p.Nout;
-    const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 6x this in bf16
-    const double bytes = 6.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 6.0 * (double)p.Cout * p.Cin * p.KW;
+    const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 3x this in fp16
+    const double bytes = 4.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 4.0 * (double)p.Cout * p.Cin * p.KW;
     {
         static const bool by_shape = []() { const char* v = getenv("DTTS_PROF_SHAPES"); return v && v[0] == '1'; }();
-        const char* tag = "conv_x3_kernel<128,128>";
+        const char* tag = "conv_x3_kernel<128,192>";
         if (by_shape) tag = p.KW == 3 ? "conv_x3 k3" : (p.Cout > 1024 ? "conv_x3 k1 M=2304" : (p.res ? "conv_x3 k1 +res" : "conv_x3 k1"));
         ProfScope ps(tag, flops, bytes, s);
         const bool epi = p.epi_act != ACT_NONE || p.out_scale != 1.f;

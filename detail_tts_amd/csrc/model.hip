@@ -308,11 +308,11 @@ void Model::build_diffusion(hipStream_t s) {
     size_t total = 0;
     for (PackedConv* pc : hot) {
         DTTS_REQUIRE(pc->Cin == pc->CinP && pc->CoutP % 128 == 0, "trunk conv not eligible for the split-precision path");
-        total += (size_t)pc->KW * pc->CinP * pc->CoutP * 6 + 256;
+        total += (size_t)pc->KW * pc->CinP * pc->CoutP * 4 + 256;
     }
     w3_.ensure(total + 4096);
     for (PackedConv* pc : hot) {
-        void* dst = w3_.raw((size_t)pc->KW * pc->CinP * pc->CoutP * 6);
+        void* dst = w3_.raw((size_t)pc->KW * pc->CinP * pc->CoutP * 4);
         launch_split_weights(pc->w, pc->KW, pc->CinP, pc->CoutP, dst, s);
         pc->w3 = dst;
     }

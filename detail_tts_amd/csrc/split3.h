@@ -1,30 +1,36 @@
-// fp32 -> three bf16 planes (v = p0 + p1 + p2 to 24 bits): device helpers shared by the split-precision conv and attention.
+// fp32 -> two fp16 planes (v s = h0 + h1 to 22 bits, s a power of two): device helpers shared by the split-precision conv and
+// attention.  See conv_x3.h for the arithmetic.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace dtts {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two elements at a time on the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even): 3 converts, 4 unpacks, 2 packed subs
-__device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
-    const f32x2 v = {x, y};
-    const bf16x2 p0 = __builtin_convertvector(v, bf16x2);
+
+constexpr int XS_PLANES = 2;
+// Power-of-two operand scales (exact; undone by one multiply of the fp32 accumulator): they keep the LOW plane of typical weights
+// (|w| ~ 0.03) and activations (|x| ~ 1) in fp16's normal range.  Elements so small that their low plane is subnormal keep an
+// ABSOLUTE error <= 2^-25 / scale; elements beyond +-65504 / scale saturate (never inf).
+constexpr float XS_SCALE_W = 64.f, XS_SCALE_X = 16.f;
+constexpr float XS_ACC_SCALE = 1.f / (XS_SCALE_W * XS_SCALE_X);
+
+// two elements at a time: clamp, round to fp16 (v_cvt_pk_f16_f32, nearest-even), residual (exact in fp32), round again
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsigned& w1) {
+    const f32x2 v = {__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f)};
+    const hf2 p0 = __builtin_convertvector(v, hf2);
     const f32x2 r1 = v - __builtin_convertvector(p0, f32x2);
-    const bf16x2 p1 = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(p1, f32x2);
-    const bf16x2 p2 = __builtin_convertvector(r2, bf16x2);
+    const hf2 p1 = __builtin_convertvector(r1, hf2);
     w0 = __builtin_bit_cast(unsigned, p0);
     w1 = __builtin_bit_cast(unsigned, p1);
-    w2 = __builtin_bit_cast(unsigned, p2);
 }
-__device__ __forceinline__ void split8(const float* v, uint4& q0, uint4& q1, uint4& q2) {
-    split_pair(v[0], v[1], q0.x, q1.x, q2.x);
-    split_pair(v[2], v[3], q0.y, q1.y, q2.y);
-    split_pair(v[4], v[5], q0.z, q1.z, q2.z);
-    split_pair(v[6], v[7], q0.w, q1.w, q2.w);
+// v[0..7] (already scaled) -> one 16-byte chunk per plane
+__device__ __forceinline__ void split8(const float* v, uint4& q0, uint4& q1) {
+    split_pair(v[0], v[1], q0.x, q1.x);
+    split_pair(v[2], v[3], q0.y, q1.y);
+    split_pair(v[4], v[5], q0.z, q1.z);
+    split_pair(v[6], v[7], q0.w, q1.w);
 }
-
 
 }  // namespace dtts
