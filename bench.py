@@ -25,7 +25,8 @@ N_CODES = 234            # forced utterance length: 234 codes -> 936 mel frames 
 T_REF = 936              # 10 s prompt
 L_TEXT = 60
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (no sparsity)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 matrix peak (no sparsity)
+XS_PRODUCTS = 3.0               # fp16 MFMA products per fp32 product on the split-precision path (csrc/conv_x3.h)
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E 8 TB/s (6.3 TB/s achievable)
 PMC_TRAFFIC = "r02_pmc_layer_traffic.json"      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the trunk kernels (this round)
 
@@ -243,15 +244,15 @@ def main():
     roof = None
     if dom:
         # chip-level rate = flops / (union of the launch intervals): equals the per-launch mean when the cond | uncond halves run
-        # merged (one 2B-sample launch per layer, the default); with DTTS_MERGE_CFG=0 two launches are co-resident on two streams
+        # merged (DTTS_CFG_STREAMS=1); by default (2 chunks) two launches are usually co-resident on two streams
         ach = dom["flops"] / (dom["union_ms"] * 1e-3) / 1e12
         x3 = dom["name"].startswith("conv_x3")
-        # conv_x3 computes every fp32 product as 6 bf16 MFMA products (3 x bf16 split operands, detail_tts_amd/csrc/conv_x3.h):
-        # the matrix pipe executes 6x the fp32-equivalent flops the profiler counts, and its roofline is the dense bf16 peak.
+        # conv_x3 computes every fp32 product as 3 fp16 MFMA products (2 x fp16 split operands, detail_tts_amd/csrc/conv_x3.h):
+        # the matrix pipe executes 3x the fp32-equivalent flops the profiler counts, and its roofline is the dense fp16 peak.
         peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
         fp32_equiv = ach
         if x3:
-            ach *= 6.0
+            ach *= XS_PRODUCTS
         # HBM-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
         # same kernel at the bench's per-launch shapes; bench.py cannot attach rocprof to itself).  FETCH_SIZE under-reports 16 B/lane
         # streams 2x on gfx950 (MI355X_MICROARCH.md, HBM section): corrected here.  Launch mix of one diffusion layer.
@@ -267,7 +268,7 @@ def main():
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_over_algorithmic": ratio,
                 "traffic_source": f"profiles/{PMC_TRAFFIC}: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction), mean over the layer's launch mix",
-                "arithmetic": "bf16 MFMA x 6 products per fp32 product (fp32-exact split), fp32 accumulate" if x3 else "fp32 MFMA",
+                "arithmetic": "fp16 MFMA x 3 products per fp32 product (operands as two fp16 planes, 22 bits; fp32-GEMM-class error), fp32 accumulate" if x3 else "fp32 MFMA",
                 "fp32_equivalent_tflops": round(fp32_equiv, 2),
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
                 "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
@@ -279,8 +280,8 @@ def main():
     roof_att = None
     if att:
         a = att["flops"] / (att["union_ms"] * 1e-3) / 1e12
-        roof_att = {"bound": "mfma", "kernel": att["name"], "achieved": round(6 * a, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(6 * a / BF16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_tflops": round(a, 2),
+        roof_att = {"bound": "mfma", "kernel": att["name"], "achieved": round(XS_PRODUCTS * a, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(XS_PRODUCTS * a / BF16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_tflops": round(a, 2),
                     "avg_launch_us": round(att["total_ms"] * 1e3 / att["launches"], 2)}
     roof_dec = None
     if "gpt_decode" in stage_ms:

@@ -16,7 +16,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int NPL = XS_PLANES, NK = 2 * NPL;        // planes; "kinds" (plane, k-half) of a 16-channel K-step
-constexpr int BM = 128, BN = X3_BN, NSTAGE = 2;
+constexpr int BM = 128, BN = X3_BN;
 constexpr int WTILE = NK * BM * 16;                  // 8 KiB: [kind][128 rows][16 B]
 constexpr int XMAIN = NK * BN * 16;                  // 12 KiB: [kind][192 columns][16 B]
 constexpr int XBUF = XMAIN + NK * 2 * 16;            // + 2 halo columns per kind
@@ -167,13 +167,16 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
     }
 }
 
-// EPI 0: bias (+ residual); 1: + activation / out_scale.   KW3: three taps (else one).
+// EPI 0: bias (+ residual); 1: + activation / out_scale.   KW3: three taps (else one).  NSTG: LDS stages (2: every K-step waits for
+// the loads issued during the previous one; 3: loads run two steps ahead and the wait is a counted vmcnt).
 // K loop order is (16-channel block, tap): the X tile of a channel block carries its halo (192 + KW - 1 columns) and is fetched
 // ONCE, every tap reads it through a shifted (16-byte aligned) ds_read_b128; only the W tile changes per tap.
-template <int EPI, bool KW3>
-__global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
-    constexpr int KW = KW3 ? 3 : 1;
-    constexpr int XOFF = NSTAGE * WTILE;               // LDS: W stage 0 | W stage 1 | X buffer 0 | X buffer 1 | bias
+// Every wave issues the SAME number of LDS-DMA instructions per step (5 for k = 1; 3, + 1 halo at the last tap, for k = 3), so the
+// counted wait is one immediate for all waves; VMEM loads complete in order.
+template <int EPI, bool KW3, int NSTG>
+__global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvParams p) {
+    constexpr int KW = KW3 ? 3 : 1, D = NSTG - 1;       // D: prefetch distance in steps (W, X of k = 1) / channel blocks (X of k = 3)
+    constexpr int XOFF = NSTG * WTILE;                  // LDS: W stages | X buffers | bias
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
@@ -195,18 +198,21 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
-    auto w_piece = [&](int j, int tap, int c16, int stage) {          // j = kind*2 + row half
+    auto w_piece = [&](int j, int q) {                                  // j = kind*2 + row half; q = step (clamped to the last one)
+        const int qq = q < nks ? q : nks - 1, c16 = KW3 ? qq / 3 : qq, tap = KW3 ? qq - 3 * c16 : 0;
         const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
-        dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * NPL + pl) * p.CoutP + rh * 64, stage * WTILE + kind * (BM * 16) + rh * 1024);
+        dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * NPL + pl) * p.CoutP + rh * 64, (q % NSTG) * WTILE + kind * (BM * 16) + rh * 1024);
     };
-    auto x_piece = [&](int j, int c16, int buf) {                       // j = kind*3 + column block
+    auto x_piece = [&](int j, int c) {                                   // j = kind*3 + column block; c = channel block (clamped)
+        const int c16 = c < c16n ? c : c16n - 1;
         const int kind = j / 3, cb = j - kind * 3, pl = kind >> 1, h = kind & 1;
-        dma(xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + cb * 64, XOFF + buf * XBUF + kind * (BN * 16) + cb * 1024);
+        dma(xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + cb * 64, XOFF + (c % NSTG) * XBUF + kind * (BN * 16) + cb * 1024);
     };
-    auto x_halo = [&](int c16, int buf) {                              // lanes 0..7: (kind, column 192 + r)
+    auto x_halo = [&](int c) {                                           // lanes 0..7: (kind, column 192 + r); every wave issues it
+        const int c16 = c < c16n ? c : c16n - 1;                         // (identical bytes) so that the instruction count is uniform
         if (lane < 2 * NK) {
             const int kind = lane >> 1, pl = kind >> 1, h = kind & 1, r = lane & 1;
-            dma(xbase - lane + ((long long)(2 * c16 + h) * NPL + pl) * Tp + BN + r, XOFF + buf * XBUF + XMAIN);
+            dma(xbase - lane + ((long long)(2 * c16 + h) * NPL + pl) * Tp + BN + r, XOFF + (c % NSTG) * XBUF + XMAIN);
         }
     };
 
@@ -219,29 +225,28 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // prologue, oldest data first: W of steps 0 .. D-1; X of steps 0 .. D-1 (k = 1) / of channel blocks 0 .. D-1 (k = 3)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w_piece(wave * 2 + i, 0, 0, 0);
+    for (int q = 0; q < D; ++q) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) x_piece(wave * 3 + i, 0, 0);
+        for (int i = 0; i < 2; ++i) w_piece(wave * 2 + i, q);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) x_piece(wave * 3 + i, q);
+        if (KW3) x_halo(q);
+    }
     // the tile's 128 bias values -> LDS (read back in the epilogue; the first K-step barrier orders the write)
-    float* bias_s = reinterpret_cast<float*>(smem + XOFF + 2 * XBUF);
+    float* bias_s = reinterpret_cast<float*>(smem + XOFF + NSTG * XBUF);
     if (tid < BM) bias_s[tid] = (p.bias && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.f;
-    if (KW3 && wave == 0) x_halo(0, 0);
 
     int c16 = 0, tap = 0;                               // the step being computed
     for (int ks = 0; ks < nks; ++ks) {
-        // the barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
+        // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
+        if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KW3 ? 3 : 5) : "memory");
         __builtin_amdgcn_s_barrier();
-        // what to fetch during this step: the W tile of the next step; (a share of) the X tile of the next channel block.  The
-        // last step / block refetch themselves into the idle stage: branch-free tail.
-        int tapn = tap + 1, c16w = c16;
-        if (tapn == KW) { tapn = 0; c16w = c16 + 1 < c16n ? c16 + 1 : c16; if (c16 + 1 >= c16n) tapn = tap; }
-        const int c16x = c16 + 1 < c16n ? c16 + 1 : c16;
-        const int wst = (ks + 1) & 1, xbuf = (c16 + 1) & 1;
-
-        const unsigned char* As = smem + (ks & 1) * WTILE + lhi * (BM * 16);
-        const unsigned char* Xb = smem + XOFF + (c16 & 1) * XBUF;
+        const unsigned char* As = smem + (ks % NSTG) * WTILE + lhi * (BM * 16);
+        const unsigned char* Xb = smem + XOFF + (c16 % NSTG) * XBUF;
         hf8 a[2][NPL], bb[3][NPL];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) a[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
         // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first; ONE LDS-DMA piece after every
-        // three or four MFMAs (as a burst the pieces of a CU's 12 waves queue on the texture-address path while every MFMA pipe
-        // idles and the co-resident workgroups fall into lock-step)
+        // three MFMAs (as a burst the pieces of a CU's waves queue on the texture-address path while every MFMA pipe idles and the
+        // co-resident workgroups fall into lock-step)
         constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
         int slot = 0;
 #pragma unroll
@@ -268,17 +273,17 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(ConvParams p) {
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
                 if (slot < 5) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (slot < 2) w_piece(wave * 2 + slot, tapn, c16w, wst);
-                    else if (!KW3) x_piece(wave * 3 + (slot - 2), c16x, xbuf);
-                    else if (slot == 2) x_piece(tap * 4 + wave, c16x, xbuf);
-                    else if (slot == 3 && tap == 2 && wave == 0) x_halo(c16x, xbuf);
+                    if (slot < 2) w_piece(wave * 2 + slot, ks + D);
+                    else if (!KW3) x_piece(wave * 3 + (slot - 2), ks + D);
+                    else if (slot == 2) x_piece(tap * 4 + wave, c16 + D);
+                    else if (slot == 3 && tap == 2) x_halo(c16 + D);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ++slot;
             }
         if (++tap == KW) { tap = 0; ++c16; }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last refetch must land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail refetches must land before the LDS is released
 
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // bias of this lane's 32 output rows from the LDS copy made at kernel start: no global latency here, no registers held
@@ -370,13 +375,16 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
     DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
+    static const int nstg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 2; return n == 3 ? 3 : 2; }();
+    const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float);
     static bool attr = false;
-    constexpr size_t lds = (size_t)NSTAGE * WTILE + 2 * XBUF + BM * sizeof(float);
     if (!attr) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int l3 = 3 * (WTILE + XBUF) + BM * (int)sizeof(float);
+        const void* fns[8] = {reinterpret_cast<const void*>(conv_x3_kernel<0, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 2>),
+                              reinterpret_cast<const void*>(conv_x3_kernel<0, true, 2>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 2>),
+                              reinterpret_cast<const void*>(conv_x3_kernel<0, false, 3>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 3>),
+                              reinterpret_cast<const void*>(conv_x3_kernel<0, true, 3>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 3>)};
+        for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
         attr = true;
     }
     const dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);
@@ -389,13 +397,19 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
         if (by_shape) tag = p.KW == 3 ? "conv_x3 k3" : (p.Cout > 1024 ? "conv_x3 k1 M=2304" : (p.res ? "conv_x3 k1 +res" : "conv_x3 k1"));
         ProfScope ps(tag, flops, bytes, s);
         const bool epi = p.epi_act != ACT_NONE || p.out_scale != 1.f;
+#define DTTS_LAUNCH_X3(E, K3)                                                                                          \
+    do {                                                                                                               \
+        if (nstg == 3) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p);                      \
+        else hipLaunchKernelGGL((conv_x3_kernel<E, K3, 2>), grid, dim3(256), lds, s, p);                                \
+    } while (0)
         if (p.KW == 3) {
-            if (epi) hipLaunchKernelGGL((conv_x3_kernel<1, true>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((conv_x3_kernel<0, true>), grid, dim3(256), lds, s, p);
+            if (epi) DTTS_LAUNCH_X3(1, true);
+            else DTTS_LAUNCH_X3(0, true);
         } else {
-            if (epi) hipLaunchKernelGGL((conv_x3_kernel<1, false>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((conv_x3_kernel<0, false>), grid, dim3(256), lds, s, p);
+            if (epi) DTTS_LAUNCH_X3(1, false);
+            else DTTS_LAUNCH_X3(0, false);
         }
+#undef DTTS_LAUNCH_X3
     }
     DTTS_CHECK_HIP(hipGetLastError());
 }

@@ -172,7 +172,7 @@ public:
         if (key == "two_streams") opt_two_streams_ = value != 0;
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
-        else if (key == "merge_cfg") opt_merge_cfg_ = value != 0;
+        else if (key == "cfg_streams") opt_cfg_streams_ = value < 1 ? 1 : value;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -260,11 +260,12 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
-    bool opt_merge_cfg_ = true;           // cond | uncond halves of a diffusion forward as ONE 2B-sample launch per layer
+    int opt_cfg_streams_ = 2;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies
-    hipStream_t s2_ = nullptr;            // second stream of the two-stream diffusion forward
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    static constexpr int MAX_CFG_STREAMS = 4;
+    hipStream_t sx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};   // extra streams of the diffusion forward
+    hipEvent_t ev_fork_ = nullptr, ev_joinx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};
     const int* umap_local_ = nullptr;     // [B] uncond sample -> index of its length group
 
     // prompt front-end

@@ -41,9 +41,9 @@ Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) {
 Model::~Model() {
     gpt_drop_graphs();
     if (lens_dev_) (void)hipFree(lens_dev_);
-    for (hipStream_t st : {s2_, sg_})
+    for (hipStream_t st : {sx_[0], sx_[1], sx_[2], sg_})
         if (st) (void)hipStreamDestroy(st);
-    for (hipEvent_t e : {ev_fork_, ev_join_, ev_g0_, ev_g1_})
+    for (hipEvent_t e : {ev_fork_, ev_joinx_[0], ev_joinx_[1], ev_joinx_[2], ev_g0_, ev_g1_})
         if (e) (void)hipEventDestroy(e);
 }
 
@@ -489,11 +489,6 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     const long long bs = (long long)C * Ta;
     static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
     const bool two_streams = env_two && opt_two_streams_;
-    if (two_streams && !s2_) {
-        DTTS_CHECK_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
-        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    }
     int groups = 32;
     while (C % groups) groups /= 2;
     const bool x3 = use_x3();
@@ -522,73 +517,73 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
             run_conv(integ1_, q, s);
         }
     }
-    // Both CFG halves are the same B-sample stack on the same weights.  Merged (default): ONE 2B-sample launch per layer - at B = 8
-    // a 768-channel conv is 768 workgroups = exactly one resident wave of the chip (3 per CU) instead of two half-empty launches that
-    // need a second stream to fill it.  Split (DTTS_MERGE_CFG=0): the halves as two B-sample launch sequences on two streams.
-    struct Half {
-        hipStream_t st;
-        int nb;               // samples of the main stack
-        int nb_integ;         // samples of the conditioning_timestep_integrator / its precomputed output
-        const float* cin;
-        const float* integ;   // precomputed integrator output for these samples (or null)
-        const int* lens;      // [nb]
-        const int* lens_integ;
-        const int* xmap;      // integrator-output sample of main-stack sample b (null: identity)
-        float* out;
-    };
-    static const bool env_merge = []() { const char* v = getenv("DTTS_MERGE_CFG"); return !(v && v[0] == '0'); }();
-    const bool merged = env_merge && opt_merge_cfg_;
-    hipStream_t sb = (two_streams && !merged) ? s2_ : s;
-    const size_t hoff = (size_t)B * C * Ta;
-    Half halves[2];
-    int nh;
-    if (merged) {
-        nh = 1;
-        halves[0] = {s, 2 * B, B + Nu, cbuf0, integ, lens2, lens_i, umap, out2};
-    } else {
-        nh = 2;
-        halves[0] = {s, B, B, cbuf0, integ, lens2, lens_i, nullptr, out2};
-        halves[1] = {sb, B, Nu, cbuf0 + hoff, integ ? integ + hoff : nullptr, lens2 + B, lens_i + B, umap_local_, out2 + (size_t)B * OC * T};
+    // Both CFG halves are the same B-sample stack on the same weights: the 2B samples form ONE stack that is cut into NS equal
+    // chunks, each a launch sequence on its own HIP stream (fork after the shared x-path, join before returning).  NS = 1: one
+    // 2B-sample launch per layer (best per-kernel efficiency: a 768-channel conv is one full wave of workgroups); NS = 2 (default):
+    // cond | uncond on two streams - the HBM-bound GroupNorm/split passes and the VALU-bound attention of one chunk run under the
+    // matrix work of the other (measured 3.3 % faster end to end than NS = 1 with the fp16-plane kernels); option "cfg_streams".
+    static const int env_ns = []() { const char* v = getenv("DTTS_CFG_STREAMS"); return v ? atoi(v) : 0; }();
+    int NS = env_ns > 0 ? env_ns : opt_cfg_streams_;
+    if (!two_streams) NS = 1;
+    if (NS > MAX_CFG_STREAMS) NS = MAX_CFG_STREAMS;
+    while (NS > 1 && ((2 * B) % NS != 0 || (B % ((2 * B) / NS) != 0 && ((2 * B) / NS) % B != 0))) --NS;
+    const int n = 2 * B / NS, Bi = B + Nu;
+    for (int k = 1; k < NS; ++k)
+        if (!sx_[k - 1]) DTTS_CHECK_HIP(hipStreamCreateWithFlags(&sx_[k - 1], hipStreamNonBlocking));
+    if (NS > 1 && !ev_fork_) {
+        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        for (auto& e : ev_joinx_) DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const bool forked = two_streams && !merged;
-    if (forked) {
+    // conditioning_timestep_integrator (vqvae/diff_model.py:295) on B code embeddings | Nu unconditional inputs: precomputed for all
+    // steps before the loop (precompute_integrator), or evaluated here as one (B + Nu)-sample batch
+    const float* code_path = integ;
+    if (!integ) {
+        float* bufI = ws_.f32((size_t)Bi * C * Ta);
+        const size_t mark = ws_.mark();
+        const size_t act = (size_t)Bi * C * Ta;
+        float* tA = ws_.f32(act);
+        float* tB = ws_.f32(act);
+        float* qkv = ws_.f32(3 * act);
+        float* ab = ws_.f32((size_t)Bi * C * 2);
+        void* xs = x3 ? ws_.raw(x3_bytes(Bi, C, T)) : nullptr;
+        const float* in = cbuf0;
+        for (int l = 0; l < 3; ++l) {
+            res_block_fwd(integ_[l].rb, in, tA, tB, ab, lens_i, Bi, T, Ta, step, s, xs);
+            attention_block(integ_[l].at, tB, bufI, qkv, tA, ab, lens_i, Bi, T, Ta, s, xs);
+            in = bufI;
+        }
+        ws_.rewind(mark);
+        code_path = bufI;
+    }
+    void* xs_code = nullptr;
+    if (x3) {
+        xs_code = ws_.raw(x3_bytes(Bi, C, T));
+        launch_split_planes(code_path, bs, Ta, nullptr, ACT_NONE, lens_i, T, Bi, C, xs_code, s);
+    }
+    if (NS > 1) {
         DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
-        DTTS_CHECK_HIP(hipStreamWaitEvent(s2_, ev_fork_, 0));
+        for (int k = 1; k < NS; ++k) DTTS_CHECK_HIP(hipStreamWaitEvent(sx_[k - 1], ev_fork_, 0));
     }
-    for (int hi = 0; hi < nh; ++hi) {
-        const Half& hf = halves[hi];
-        hipStream_t st = hf.st;
-        const int nb = hf.nb, nbi = hf.nb_integ, nbw = std::max(nb, nbi);
-        const size_t act = (size_t)nbw * C * Ta;
+    for (int k = 0; k < NS; ++k) {
+        hipStream_t st = k ? sx_[k - 1] : s;
+        const int b0 = k * n;                          // first sample of the chunk in the 2B stack
+        const int* lens = lens2 + b0;
+        const size_t act = (size_t)n * C * Ta;
         float* bufA = ws_.f32(act);
         float* bufB = ws_.f32(act);
         float* bufC = ws_.f32(act);
         float* qkv = ws_.f32(3 * act);
-        float* ab = ws_.f32((size_t)nbw * C * 2);
-        void* xs = x3 ? ws_.raw(x3_bytes(nbw, C, T)) : nullptr;
-        auto dlayer_n = [&](const DiffLayerW& l, const float* in, float* tmp, float* mid, float* outp, const int* lens, int n) {
-            res_block_fwd(l.rb, in, tmp, mid, ab, lens, n, T, Ta, step, st, xs);
-            attention_block(l.at, mid, outp, qkv, tmp, ab, lens, n, T, Ta, st, xs);
-        };
-        // conditioning_timestep_integrator (vqvae/diff_model.py:295): B code embeddings | Nu unconditional inputs
-        const float* code_path = bufA;
-        if (hf.integ) {
-            code_path = hf.integ;                                              // evaluated before the loop (precompute_integrator)
-        } else {
-            dlayer_n(integ_[0], hf.cin, bufB, bufC, bufA, hf.lens_integ, nbi);
-            dlayer_n(integ_[1], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
-            dlayer_n(integ_[2], bufA, bufB, bufC, bufA, hf.lens_integ, nbi);
-        }
-        // integrating_conv, code half, accumulated onto the shared x-path term
-        ConvParams r = cp(code_path, C, bufB, C, nb, T, Ta, hf.lens);
-        r.res = xpath;
+        float* ab = ws_.f32((size_t)n * C * 2);
+        void* xs = x3 ? ws_.raw(x3_bytes(n, C, T)) : nullptr;
+        // integrating_conv, code half, accumulated onto the shared x-path term (the residual of stack sample b is xpath[b % B])
+        ConvParams r = cp(code_path, C, bufB, C, n, T, Ta, lens);
+        r.res = xpath + (size_t)(b0 % B) * C * Ta;
         r.res_bs = bs;
         r.res_cs = Ta;
-        r.res_bmod = B;
-        r.x_bidx = hf.xmap;
+        r.res_bmod = n > B ? B : 0;
+        r.x_bidx = umap + b0;                          // code-path sample of stack sample b (uncond samples share one per length)
         if (x3) {
-            launch_split_planes(code_path, bs, Ta, nullptr, ACT_NONE, hf.lens_integ, T, nbi, C, xs, st);
-            r.x3 = xs;
+            r.x3 = xs_code;
             r.x3_tp = x3_tp(T);
         }
         run_conv(integ2_, r, st);
@@ -596,15 +591,18 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* cur = bufB;
         float* t1 = bufA;
         float* t2 = bufC;
-        for (auto& l : layers_) dlayer_n(l, cur, t1, t2, cur, hf.lens, nb);   // output back into `cur` (x is dead after the residual add)
+        for (auto& l : layers_) {                       // output back into `cur` (x is dead after the residual add)
+            res_block_fwd(l.rb, cur, t1, t2, ab, lens, n, T, Ta, step, st, xs);
+            attention_block(l.at, t2, cur, qkv, t1, ab, lens, n, T, Ta, st, xs);
+        }
         for (auto& rb : tail_) {
-            res_block_fwd(rb, cur, t1, t2, ab, hf.lens, nb, T, Ta, step, st, xs);
+            res_block_fwd(rb, cur, t1, t2, ab, lens, n, T, Ta, step, st, xs);
             std::swap(cur, t2);
         }
         // out: GN, SiLU, conv k3 (:312)
-        if (x3) launch_gn_split_planes(cur, bs, Ta, hf.lens, T, nb, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
-        else launch_gn_coeffs(cur, bs, Ta, hf.lens, T, nb, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
-        ConvParams o = cp(cur, C, hf.out, OC, nb, T, Ta, hf.lens);
+        if (x3) launch_gn_split_planes(cur, bs, Ta, lens, T, n, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
+        else launch_gn_coeffs(cur, bs, Ta, lens, T, n, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
+        ConvParams o = cp(cur, C, out2 + (size_t)b0 * OC * T, OC, n, T, Ta, lens);
         o.pro_ab = ab;
         o.pro_act = ACT_SILU;
         o.pad = 1;
@@ -616,9 +614,9 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         }
         run_conv(out_conv_, o, st);
     }
-    if (forked) {
-        DTTS_CHECK_HIP(hipEventRecord(ev_join_, s2_));
-        DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+    for (int k = 1; k < NS; ++k) {
+        DTTS_CHECK_HIP(hipEventRecord(ev_joinx_[k - 1], sx_[k - 1]));
+        DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_joinx_[k - 1], 0));
     }
 }
 
@@ -639,10 +637,10 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     const bool x3 = use_x3();
     static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
     const bool two = env_two && opt_two_streams_;
-    if (two && !s2_) {
-        DTTS_CHECK_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+    if (two && !sx_[0]) DTTS_CHECK_HIP(hipStreamCreateWithFlags(&sx_[0], hipStreamNonBlocking));
+    if (two && !ev_fork_) {
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        for (auto& e : ev_joinx_) DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     float* vin = ws_.f32((size_t)Bv * ct);
     for (int j = 0; j < J; ++j)
@@ -651,7 +649,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     struct Lane { hipStream_t st; float *bufA, *bufB, *bufC, *qkv, *ab; void* xs; };
     Lane lanes[2];
     for (int q = 0; q < (two ? 2 : 1); ++q) {
-        lanes[q].st = q ? s2_ : s;
+        lanes[q].st = q ? sx_[0] : s;
         lanes[q].bufB = ws_.f32((size_t)Bv * ct);
         lanes[q].bufC = ws_.f32((size_t)Bv * ct);
         lanes[q].bufA = ws_.f32((size_t)Bv * ct);
@@ -661,7 +659,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     }
     if (two) {
         DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
-        DTTS_CHECK_HIP(hipStreamWaitEvent(s2_, ev_fork_, 0));
+        DTTS_CHECK_HIP(hipStreamWaitEvent(sx_[0], ev_fork_, 0));
     }
     std::vector<int> lv(Bv), sv(Bv);
     int ci = 0;
@@ -685,15 +683,17 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         dlayer(integ_[2], L.bufA, outp);
     }
     if (two) {
-        DTTS_CHECK_HIP(hipEventRecord(ev_join_, s2_));
-        DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+        DTTS_CHECK_HIP(hipEventRecord(ev_joinx_[0], sx_[0]));
+        DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_joinx_[0], 0));
     }
     ws_.rewind(mark);
 }
 
 static size_t pair_ws_bytes(int B, int C, int T) {
     const size_t act = (size_t)B * C * T;
-    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C)) + 3 * x3_bytes(B, C, T) + 20 * 256;
+    // x path (2 act) + the chunks' scratch over the 2B stack (2 x 6 act) + the integrator evaluated in place (2 act out + 2 x 6 act
+    // scratch, only without the precomputed integrator) ; split planes: x path (B) + chunks (2B) + code path (2B) + integrator (2B)
+    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C) + 2 * act + 2 * (5 * act + (size_t)2 * B * C)) + 7 * x3_bytes(B, C, T) + 64 * 256;
 }
 
 // ------------------------------------------------------------------------------ stage entry points

@@ -14,7 +14,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
 
-template <int NPL, int WGM, int WGN, int MI, int NJ, int MINW, int NSTG = 2, int KB = 1>
+template <int NPL, int WGM, int WGN, int MI, int NJ, int MINW, int NSTG = 2, int KB = 1, int ABL = 0, int BUF = 0>
 __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y,
                                                                 int M, int C8, int Tp, int T, int ntn, float oscale) {
     constexpr int NW = WGM * WGN, BM = WGM * MI * 32, BN = WGN * NJ * 32;
@@ -38,20 +38,35 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
     const uint4* wbase = Wp + m0 + lane;
     const uint4* xbase = Xp + (size_t)b * C8 * NPL * Tp + n0 + 1 + lane;
     // piece p (0 .. PIECES-1): p < APIECES -> W piece (kind = p / (BM/64), rh = p % (BM/64)); else X piece
+    // BUF: buffer_load ... lds through two resource descriptors (W, X of this sample): per-lane offset lane*16 is loop-invariant, the
+    // piece's offset is a scalar -> no vector address arithmetic per piece
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + m0), (short)0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Xp + (size_t)b * C8 * NPL * Tp + n0 + 1), (short)0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
     auto issue = [&](int pp, int kstep, int stage) {            // kstep: index of the KB-block
         if (pp >= PIECES) return;
         const int sub = pp / SPIECES, p = pp - sub * SPIECES, c16 = kstep * KB + sub;
         unsigned char* sbase = smem + stage * STAGE + sub * SUB;
         if (p < APIECES) {
             const int kind = p / (BM / 64), rh = p % (BM / 64), pl = kind >> 1, h = kind & 1;
-            const uint4* g = wbase + ((long long)(2 * c16 + h) * NPL + pl) * M + rh * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(sbase + kind * (BM * 16) + rh * 1024), 16, 0, 0);
+            if (BUF) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(sbase + kind * (BM * 16) + rh * 1024), 16, voff,
+                                                         (((2 * c16 + h) * NPL + pl) * M + rh * 64) * 16, 0, 0);
+            } else {
+                const uint4* g = wbase + ((long long)(2 * c16 + h) * NPL + pl) * M + rh * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(sbase + kind * (BM * 16) + rh * 1024), 16, 0, 0);
+            }
         } else {
             const int q = p - APIECES, kind = q / (BN / 64), rh = q % (BN / 64), pl = kind >> 1, h = kind & 1;
-            const uint4* g = xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + rh * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(sbase + ATILE + kind * (BN * 16) + rh * 1024), 16, 0, 0);
+            if (BUF) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(sbase + ATILE + kind * (BN * 16) + rh * 1024), 16, voff,
+                                                         (((2 * c16 + h) * NPL + pl) * Tp + rh * 64) * 16, 0, 0);
+            } else {
+                const uint4* g = xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + rh * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(sbase + ATILE + kind * (BN * 16) + rh * 1024), 16, 0, 0);
+            }
         }
     };
     const int wm0 = (wave / WGN) * (MI * 32), wn0 = (wave % WGN) * (NJ * 32);
@@ -70,12 +85,15 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
     for (int st = 0; st < NSTG - 1; ++st)
 #pragma unroll
         for (int i = 0; i < PPW; ++i) issue_w(i, st < nkb ? st : nkb - 1, st);
+    bf8 keep_a[MI][NPL], keep_b[NJ][NPL];
     for (int ks = 0; ks < nkb; ++ks) {
         // data of K-block ks was issued NSTG-1 blocks ago: at most (NSTG-2) newer blocks may stay in flight
-        if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (NSTG == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 2)) {
+            if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (NSTG == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const int cur = ks % NSTG, nst = (ks + NSTG - 1) % NSTG, kx = ks + NSTG - 1 < nkb ? ks + NSTG - 1 : nkb - 1;
         int mf = 0, piece = 0;
 #pragma unroll
@@ -83,12 +101,31 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
             const unsigned char* As = smem + cur * STAGE + sub * SUB + lhi * (BM * 16);
             const unsigned char* Bs = smem + cur * STAGE + sub * SUB + ATILE + lhi * (BN * 16);
             bf8 a[MI][NPL], bb[NJ][NPL];
+            if ((ABL & 4) && ks > 0) {          // ablation: no LDS fragment reads after the first step (operands stay in registers)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[i][p] = keep_a[i][p];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bb[j][p] = keep_b[j][p];
+                }
+            } else {
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a[i][p] = *reinterpret_cast<const bf8*>(As + p * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) bb[j][p] = *reinterpret_cast<const bf8*>(Bs + p * (2 * BN * 16) + (wn0 + j * 32 + l31) * 16);
+            }
+            if (ABL & 4) {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) keep_a[i][p] = a[i][p];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) keep_b[j][p] = bb[j][p];
+                }
+            }
             }
             constexpr int TA[6] = {NPL == 3 ? 2 : 1, NPL == 3 ? 1 : 0, 0, 1, 0, 0}, TB[6] = {0, 1, NPL == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
@@ -102,7 +139,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
                         ++mf;
                         if (piece < PPW && mf * PPW >= (piece + 1) * NMF) {       // this wave's PPW pieces spread evenly over the NMF MFMAs
                             __builtin_amdgcn_sched_barrier(0);
-                            issue_w(piece, kx, nst);
+                            if (!(ABL & 1)) issue_w(piece, kx, nst);
                             __builtin_amdgcn_sched_barrier(0);
                             ++piece;
                         }
@@ -133,7 +170,7 @@ static void split3(float v, unsigned short* p) {
     p[2] = h_bf16(r2);
 }
 
-template <int NPL, int WGM, int WGN, int MI, int NJ, int MINW, int NSTG = 2, int KB = 1>
+template <int NPL, int WGM, int WGN, int MI, int NJ, int MINW, int NSTG = 2, int KB = 1, int ABL = 0, int BUF = 0>
 void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int T, int Tp, int B, const std::vector<float>& hw, const std::vector<float>& hx,
          const char* name, float oscale) {
     constexpr int BM = WGM * MI * 32, BN = WGN * NJ * 32;
@@ -142,7 +179,7 @@ void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int T, int Tp
     if (ntn * BN + 2 > Tp) { printf("%-34s Tp too small\n", name); return; }
     const dim3 grid((M / BM) * ntn * B);
     const size_t lds = (size_t)NSTG * KB * 2 * NPL * 16 * (BM + BN);
-    auto k = gemm_x3v<NPL, WGM, WGN, MI, NJ, MINW, NSTG, KB>;
+    auto k = gemm_x3v<NPL, WGM, WGN, MI, NJ, MINW, NSTG, KB, ABL, BUF>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int occ = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, WGM * WGN * 64, lds);
@@ -199,24 +236,14 @@ void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, con
     const float os = 1.f / (sw * sx);
     printf("---- %s, M = %d\n", NPL == 3 ? "3 x bf16 planes, 6 products" : "2 x fp16 planes, 3 products", M);
     for (int rep = 0; rep < 2; ++rep) {
-        run<NPL, 2, 2, 2, 2, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x128 2x2", os);
-        run<NPL, 2, 2, 2, 2, 3, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x128 2x2", os);
-        run<NPL, 2, 2, 2, 2, 3, 4, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x128 2x2", os);
-        run<NPL, 2, 2, 2, 2, 2, 2, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x128 2x2", os);
-        run<NPL, 2, 2, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x128 2x2", os);
-        run<NPL, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 2x2", os);
-        run<NPL, 2, 2, 2, 3, 2, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 2x2", os);
-        run<NPL, 2, 2, 2, 3, 2, 2, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 2x2", os);
-        run<NPL, 2, 2, 2, 3, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 2x2", os);
-        run<NPL, 4, 2, 2, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4x2", os);
-        run<NPL, 4, 2, 2, 3, 1, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4x2", os);
-        run<NPL, 4, 2, 2, 3, 1, 2, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4x2", os);
-        run<NPL, 4, 2, 2, 3, 1, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4x2", os);
-        run<NPL, 4, 2, 3, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "384x192 4x2", os);
-        run<NPL, 4, 2, 3, 3, 1, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "384x192 4x2", os);
-        run<NPL, 4, 2, 3, 3, 1, 2, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "384x192 4x2", os);
-        run<NPL, 2, 4, 3, 2, 1, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "192x256 2x4", os);
-        run<NPL, 2, 4, 3, 2, 1, 2, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "192x256 2x4", os);
+        run<NPL, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 global_load_lds", os);
+        run<NPL, 2, 2, 2, 3, 2, 2, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 buffer_load lds", os);
+        run<NPL, 2, 2, 2, 3, 2, 3, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 buffer st3", os);
+        run<NPL, 2, 2, 2, 3, 2, 2, 1, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 no DMA", os);
+        run<NPL, 4, 2, 2, 3, 1, 3, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 st3 global", os);
+        run<NPL, 4, 2, 2, 3, 1, 3, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 st3 buffer", os);
+        run<NPL, 4, 2, 2, 3, 1, 2, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 st2 buffer", os);
+        run<NPL, 4, 2, 3, 3, 1, 3, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "384x192 st3 buffer", os);
     }
     (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
 }
