@@ -26,6 +26,23 @@ struct AttnParams {
     // of fp32 `out`; only columns t < len are written (halo / tail columns keep what the previous writer left: zeros)
     void* out_x3 = nullptr;
     int x3_tp = 0;
+    // x3 only: q / k / v come as AttnPlanes images (qkv is ignored) written by the qkv conv
+    const void* planes = nullptr;
+};
+
+// Operand images of the split-precision attention (head dim 48), written by the qkv conv's epilogue (conv_x3.hip) and consumed by
+// LDS-DMA / direct fragment loads - no staging arithmetic in the attention kernel.  16-byte chunks of 8 fp16; two planes (split3.h);
+// Q carries scale * log2(e) * 16, K and V carry 16.  Per (sample, head):
+//   Q  [plane 2][c8 6][Tq]            chunk = 8 channels of one query
+//   KV [tile][ K: plane 2 x (c8 6 x key 64) | V: plane 2 x (ct 3 x u 2 x g 4 x c16 16) ]   = the kernel's 24 KiB LDS stage image;
+//      V chunk (ct, u, g, c16) = keys {4g..4g+3, 16+4g..16+4g+3} + 32u of channel 16 ct + c16; keys >= len hold zeros
+struct AttnPlanes {
+    static constexpr int D = 48, KT = 64, TILE_BYTES = 2 * (6 * 64 + 3 * 2 * 4 * 16) * 16;      // 24576
+    __host__ __device__ static inline int tq(int T) { return (T + KT - 1) / KT * KT; }
+    __host__ __device__ static inline int nt64(int T) { return (T + KT - 1) / KT; }
+    __host__ __device__ static inline size_t q_bytes(int T) { return (size_t)2 * 6 * tq(T) * 16; }
+    __host__ __device__ static inline size_t head_bytes(int T) { return q_bytes(T) + (size_t)nt64(T) * TILE_BYTES; }
+    __host__ __device__ static inline size_t bytes(int B, int H, int T) { return (size_t)B * H * head_bytes(T); }
 };
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream);

@@ -52,6 +52,11 @@ struct ConvParams {
     const void* w3 = nullptr;
     const void* x3 = nullptr;
     int x3_tp = 0;
+    // conv_x3 only, the trunk's qkv conv: write the output as the split-precision attention's operand images (attention.h:
+    // AttnPlanes) instead of fp32 rows - Q / K chunks straight from the accumulator layout, V through a 4 x 4 lane transpose
+    void* qkv_planes = nullptr;
+    int qkv_heads = 0, qkv_nt64 = 0, qkv_tq = 0;
+    float qkv_qscale = 1.f;        // softmax scale * log2(e), folded into the Q planes
     int ablate = 0;                // experiments only (DTTS_CONV_ABLATE): 1 skip global loads, 2 skip LDS stores, 4 skip barriers
 };
 

@@ -293,6 +293,81 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[i][r] = bias_s[wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+    if (EPI == 2) {
+        // qkv conv of an AttentionBlock (QKVAttentionLegacy row order: head h = rows 144 h + [q 48 | k 48 | v 48]): the 4 consecutive
+        // rows a lane holds per register group never straddle a section or an 8-channel chunk.  Q and K: half a chunk (4 channels
+        // of one position) per lane.  V wants 4 consecutive KEYS of one channel: 4 x 4 transpose over the lane quad (DPP).
+        constexpr int D = 48, KT = 64;
+        const int H = p.qkv_heads, Tq = p.qkv_tq;
+        const size_t qb = (size_t)2 * 6 * Tq * 16, hb = qb + (size_t)p.qkv_nt64 * (2 * (6 * KT + 384) * 16);
+        unsigned char* pb = static_cast<unsigned char*>(p.qkv_planes) + (size_t)b * H * hb;
+        const int q4 = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int n = n0 + wn0 + j * 32 + l31;
+                if (((n0 + wn0 + j * 32) & ~63) >= nvalid) continue;               // its whole 64-key tile lies beyond the length (wave-uniform)
+                const bool ok = n < nvalid;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int row0 = m0 + wm0 + i * 32 + 8 * rg + 4 * lhi;         // first of this lane's 4 rows
+                    if (row0 >= p.Cout) continue;
+                    const int h = row0 / (3 * D), rem = row0 - h * 3 * D, sec = rem / D, c = rem - sec * D;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] * XS_ACC_SCALE + bv[i][4 * rg + e];
+                    unsigned char* hp = pb + (size_t)h * hb;
+                    if (sec == 0) {
+                        const float qs = p.qkv_qscale * 16.f;
+                        unsigned w0[2], w1[2];
+                        split_pair(v[0] * qs, v[1] * qs, w0[0], w1[0]);
+                        split_pair(v[2] * qs, v[3] * qs, w0[1], w1[1]);
+                        if (ok) {
+                            unsigned char* o = hp + ((size_t)(c >> 3) * Tq + n) * 16 + ((c >> 2) & 1) * 8;
+                            *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
+                            *reinterpret_cast<uint2*>(o + (size_t)6 * Tq * 16) = make_uint2(w1[0], w1[1]);
+                        }
+                    } else if (sec == 1) {
+                        unsigned w0[2], w1[2];
+                        split_pair(ok ? v[0] * 16.f : 0.f, ok ? v[1] * 16.f : 0.f, w0[0], w1[0]);
+                        split_pair(ok ? v[2] * 16.f : 0.f, ok ? v[3] * 16.f : 0.f, w0[1], w1[1]);
+                        unsigned char* o = hp + qb + (size_t)(n >> 6) * (2 * (6 * KT + 384) * 16) + ((size_t)(c >> 3) * KT + (n & 63)) * 16 + ((c >> 2) & 1) * 8;
+                        *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
+                        *reinterpret_cast<uint2*>(o + 6 * KT * 16) = make_uint2(w1[0], w1[1]);
+                    } else {
+                        // lane quad (keys n - q4 .. n - q4 + 3) x registers (channels c .. c + 3) -> transposed
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = ok ? v[e] * 16.f : 0.f;                 // zeros beyond the length: P = 0 there
+                        {
+                            const bool odd = q4 & 1;
+                            const float a = odd ? t[0] : t[1], bq = odd ? t[2] : t[3];
+                            const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+                            const float rb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bq), 0xB1, 0xF, 0xF, true));
+                            if (odd) { t[0] = ra; t[2] = rb; } else { t[1] = ra; t[3] = rb; }
+                        }
+                        {
+                            const bool hi2 = q4 & 2;
+                            const float a = hi2 ? t[0] : t[2], bq = hi2 ? t[1] : t[3];
+                            const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));
+                            const float rb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bq), 0x4E, 0xF, 0xF, true));
+                            if (hi2) { t[0] = ra; t[1] = rb; } else { t[2] = ra; t[3] = rb; }
+                        }
+                        // now: channel c + q4, keys kb .. kb + 3 with kb = n - q4 (a multiple of 4)
+                        unsigned w0[2], w1[2];
+                        split_pair(t[0], t[1], w0[0], w1[0]);
+                        split_pair(t[2], t[3], w0[1], w1[1]);
+                        const int ch = c + q4, kb = n - q4, k64 = kb & 63, u = k64 >> 5, k32 = k64 & 31;
+                        const int chunk = (((ch >> 4) * 2 + u) * 4 + ((k32 & 15) >> 2)) * 16 + (ch & 15);
+                        unsigned char* o = hp + qb + (size_t)(kb >> 6) * (2 * (6 * KT + 384) * 16) + (size_t)2 * 6 * KT * 16 + (size_t)chunk * 16 + (k32 >> 4) * 8;
+                        *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
+                        *reinterpret_cast<uint2*>(o + 384 * 16) = make_uint2(w1[0], w1[1]);
+                    }
+                }
+            }
+        return;
+    }
     float* yb = p.y + (long long)b * p.y_bs;
     const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
     // The residual usually IS the output buffer (in-place x += f(x)): the compiler must keep every residual load behind the
@@ -369,7 +444,7 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
 }
 
 void launch_conv_x3(const ConvParams& p, hipStream_t s) {
-    DTTS_REQUIRE(p.w3 && p.x3 && p.y && p.x3_tp > 0, "conv_x3: operands");
+    DTTS_REQUIRE(p.w3 && p.x3 && (p.y || p.qkv_planes) && p.x3_tp > 0, "conv_x3: operands");
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
     DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3: channel padding");
     DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
@@ -380,6 +455,8 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         const int l3 = 3 * (WTILE + XBUF) + BM * (int)sizeof(float);
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, l3));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<2, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, l3));
         const void* fns[8] = {reinterpret_cast<const void*>(conv_x3_kernel<0, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 2>),
                               reinterpret_cast<const void*>(conv_x3_kernel<0, true, 2>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 2>),
                               reinterpret_cast<const void*>(conv_x3_kernel<0, false, 3>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 3>),
@@ -402,7 +479,10 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
         if (nstg == 3) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p);                      \
         else hipLaunchKernelGGL((conv_x3_kernel<E, K3, 2>), grid, dim3(256), lds, s, p);                                \
     } while (0)
-        if (p.KW == 3) {
+        if (p.qkv_planes) {
+            DTTS_REQUIRE(p.KW == 1 && !epi && !p.res && p.Cout % 144 == 0 && p.qkv_heads * 144 == p.Cout, "qkv planes epilogue: 48-channel heads, 1x1 conv");
+            DTTS_LAUNCH_X3(2, false);
+        } else if (p.KW == 3) {
             if (epi) DTTS_LAUNCH_X3(1, true);
             else DTTS_LAUNCH_X3(0, true);
         } else {

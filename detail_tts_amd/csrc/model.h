@@ -266,7 +266,6 @@ private:
     static constexpr int MAX_CFG_STREAMS = 4;
     hipStream_t sx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};   // extra streams of the diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_joinx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};
-    const int* umap_local_ = nullptr;     // [B] uncond sample -> index of its length group
 
     // prompt front-end
     bool has_frontend_ = false;

@@ -318,6 +318,13 @@ void Model::build_diffusion(hipStream_t s) {
     }
 }
 
+// floats of the qkv scratch of an AttentionBlock: fp32 rows [B, 3C, T] or, on the split-precision path, the attention's operand
+// images (attention.h: AttnPlanes; key tiles padded to 64)
+static size_t qkv_floats(int B, int C, int T) {
+    const size_t rows = (size_t)3 * B * C * T, planes = (AttnPlanes::bytes(B, C / AttnPlanes::D, T) + 3) / 4;
+    return std::max(rows, planes) + 64;
+}
+
 static bool attn_x3_enabled() {
     static const bool on = []() { const char* v = getenv("DTTS_ATTN_X3"); return !(v && v[0] == '0'); }();
     return on;
@@ -352,9 +359,18 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     p.y = qkv;
     p.y_bs = 3 * bs;
     p.y_cs = Ta;
+    static const bool env_planes = []() { const char* v = getenv("DTTS_ATTN_PLANES"); return !(v && v[0] == '0'); }();
+    const bool planes = x3 && attn_x3_enabled() && env_planes && D == AttnPlanes::D;
     if (x3) {
         p.x3 = xs;
         p.x3_tp = x3_tp(T);
+    }
+    if (planes) {            // the qkv conv writes the attention's operand images instead of fp32 rows
+        p.qkv_planes = qkv;
+        p.qkv_heads = w.H;
+        p.qkv_nt64 = AttnPlanes::nt64(T);
+        p.qkv_tq = AttnPlanes::tq(T);
+        p.qkv_qscale = (1.f / std::sqrt((float)D)) * 1.4426950408889634f;
     }
     run_conv(w.qkv, p, s);
     AttnParams a;
@@ -376,6 +392,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     a.scale = 1.f / std::sqrt((float)D);
     a.bias_tab = w.bias_tab;
     a.x3 = x3 && attn_x3_enabled();
+    if (planes) a.planes = qkv;
     // the proj conv's input planes come straight from the attention epilogue; xs still holds the zero halo / tail columns that
     // gn_split_planes wrote for the qkv conv (same B, T, lens), and the qkv conv has consumed the rest
     const bool att_planes = a.x3 && T + 1 < x3_tp(T);
@@ -468,9 +485,6 @@ Model::PairPlan Model::plan_pair(const int* lens_host, int B, int T, hipStream_t
         um[B + b] = B + gidx;
     }
     for (int v : ul) li.push_back(v);
-    std::vector<int> um2(B);
-    for (int b = 0; b < B; ++b) um2[b] = um[B + b] - B;
-    umap_local_ = upload_ints(um2.data(), B, s);
     PairPlan pl;
     pl.Nu = (int)ul.size();
     pl.ulen = ul;
@@ -543,7 +557,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         const size_t act = (size_t)Bi * C * Ta;
         float* tA = ws_.f32(act);
         float* tB = ws_.f32(act);
-        float* qkv = ws_.f32(3 * act);
+        float* qkv = ws_.f32(qkv_floats(Bi, C, T));
         float* ab = ws_.f32((size_t)Bi * C * 2);
         void* xs = x3 ? ws_.raw(x3_bytes(Bi, C, T)) : nullptr;
         const float* in = cbuf0;
@@ -572,7 +586,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* bufA = ws_.f32(act);
         float* bufB = ws_.f32(act);
         float* bufC = ws_.f32(act);
-        float* qkv = ws_.f32(3 * act);
+        float* qkv = ws_.f32(qkv_floats(n, C, T));
         float* ab = ws_.f32((size_t)n * C * 2);
         void* xs = x3 ? ws_.raw(x3_bytes(n, C, T)) : nullptr;
         // integrating_conv, code half, accumulated onto the shared x-path term (the residual of stack sample b is xpath[b % B])
@@ -622,7 +636,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
 
 static size_t integ_ws_bytes(int Bv, int C, int T) {
     const size_t act = (size_t)Bv * C * T;
-    return sizeof(float) * (act + 2 * (6 * act + (size_t)2 * Bv * C)) + 2 * x3_bytes(Bv, C, T) + 32 * 256;
+    return sizeof(float) * (act + 2 * (3 * act + qkv_floats(Bv, C, T) + (size_t)2 * Bv * C)) + 2 * x3_bytes(Bv, C, T) + 32 * 256;
 }
 static int integ_chunk(int Bi) {     // steps per batched evaluation (~36 samples per launch; DTTS_INTEG_SAMPLES overrides)
     static const int target = []() { const char* v = getenv("DTTS_INTEG_SAMPLES"); return v ? atoi(v) : 36; }();
@@ -653,7 +667,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         lanes[q].bufB = ws_.f32((size_t)Bv * ct);
         lanes[q].bufC = ws_.f32((size_t)Bv * ct);
         lanes[q].bufA = ws_.f32((size_t)Bv * ct);
-        lanes[q].qkv = ws_.f32((size_t)3 * Bv * ct);
+        lanes[q].qkv = ws_.f32(qkv_floats(Bv, C, T));
         lanes[q].ab = ws_.f32((size_t)2 * Bv * C);
         lanes[q].xs = x3 ? ws_.raw(x3_bytes(Bv, C, T)) : nullptr;
     }
@@ -693,7 +707,8 @@ static size_t pair_ws_bytes(int B, int C, int T) {
     const size_t act = (size_t)B * C * T;
     // x path (2 act) + the chunks' scratch over the 2B stack (2 x 6 act) + the integrator evaluated in place (2 act out + 2 x 6 act
     // scratch, only without the precomputed integrator) ; split planes: x path (B) + chunks (2B) + code path (2B) + integrator (2B)
-    return sizeof(float) * (2 * act + 2 * (6 * act + (size_t)2 * B * C) + 2 * act + 2 * (5 * act + (size_t)2 * B * C)) + 7 * x3_bytes(B, C, T) + 64 * 256;
+    return sizeof(float) * (2 * act + 2 * (3 * act + qkv_floats(B, C, T) + (size_t)2 * B * C) + 2 * act + 2 * (2 * act + qkv_floats(B, C, T) + (size_t)2 * B * C)) +
+           7 * x3_bytes(B, C, T) + 64 * 256;
 }
 
 // ------------------------------------------------------------------------------ stage entry points
@@ -906,11 +921,11 @@ void Model::op_attention_block(const char* prefix, const float* x, const int* le
     DTTS_REQUIRE(bound_, "weights not bound");
     AttnBlockW w = attn_block(prefix, C, cfg.diff_heads);
     const size_t act = (size_t)B * C * T;
-    ws_.ensure(sizeof(float) * (4 * act + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
+    ws_.ensure(sizeof(float) * (act + qkv_floats(B, C, T) + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
-    float* qkv = ws_.f32(3 * act);
+    float* qkv = ws_.f32(qkv_floats(B, C, T));
     float* att = ws_.f32(act);
     float* ab = ws_.f32((size_t)2 * B * C);
     // the trunk's blocks take the split-precision path exactly as inside diff_forward

@@ -42,7 +42,7 @@ for n in names:
     if "FETCH_SIZE" not in res[n]:
         continue
     out[n] = {"fetch_MB": round(res[n]["FETCH_SIZE"] * 1024 / 1e6, 1), "write_MB": round(res[n].get("WRITE_SIZE", 0) * 1024 / 1e6, 1),
-              "alg_in_MB": round(B * cin * T * 6 / 1e6, 1), "alg_w_MB": round(cin * cout * k * 6 / 1e6, 1),
+              "alg_in_MB": round(B * cin * T * 4 / 1e6, 1), "alg_w_MB": round(cin * cout * k * 4 / 1e6, 1),
               "alg_out_MB": round(B * cout * T * 4 * 2 / 1e6 if "2304" not in n and k == 3 or "proj" in n else B * cout * T * 4 / 1e6, 1)}
 for k, v in other.items():
     out[k] = {"fetch_MB": round(v.get("FETCH_SIZE", 0) * 1024 / 1e6, 1), "write_MB": round(v.get("WRITE_SIZE", 0) * 1024 / 1e6, 1)}
@@ -52,8 +52,8 @@ if out:
         fh.write(f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/bench_layer.py  (one diffusion layer, B=8, T=936:\n"
                  "the per-launch shape of the two-stream bench).  Units: KiB per dispatch (rocprofv3) -> MB = KiB*1024/1e6.  gfx950 caveat\n"
                  "(MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x; both conv_x3 operand\n"
-                 "streams are 16 B/lane LDS-DMA loads, so the raw fetch value is a LOWER bound.  alg_* = algorithmic bytes (6 B per split-\n"
-                 "precision input element, 4 B per fp32 output element, residual read included where the conv adds one).\n\n")
+                 "streams are 16 B/lane LDS-DMA loads, so the raw fetch value is a LOWER bound (bench.py doubles it).  alg_* = algorithmic bytes\n"
+                 "(4 B per split-precision input element = two fp16 planes, 4 B per fp32 output element, residual read included where the conv adds one).\n\n")
         for k, v in out.items():
             fh.write(f"{k:24s} " + "  ".join(f"{a}={b}" for a, b in v.items()) + "\n")
     print(json.dumps(out, indent=1))
