@@ -121,7 +121,7 @@ class SynthesizerTrn:
         """vqvae/model_24k.py:774-810.  Returns wav [B,1,1024*n_max] (B=1 unless batch=True).
 
         stream_vocoder: stage C runs on a second HIP stream, its generator window by window (`vocoder_chunk` mel frames + halo,
-        dtts_vocoder_stream).  With wait=False the call returns while stage C is still running - `self.vocoder_done` is the event
+        dtts_vocoder_stream; 0 = one shot).  With wait=False the call returns while stage C is still running - `self.vocoder_done` is the event
         to wait on before reading the waveform - so the NEXT call's GPT decode and diffusion (first stream) overlap this call's
         vocoder (BASELINE configs[4]: long-form batches, overlapped diffusion / vocoder streams)."""
         text = torch.as_tensor(text)
@@ -187,7 +187,7 @@ class SynthesizerTrn:
             ready.record(cur)
             with torch.cuda.stream(self._voc_stream):
                 self._voc_stream.wait_event(ready)
-                wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk))
+                wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
                 mel.record_stream(self._voc_stream)
                 self.vocoder_done = torch.cuda.Event()
                 self.vocoder_done.record(self._voc_stream)
