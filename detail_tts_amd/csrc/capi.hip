@@ -12,6 +12,7 @@ struct dtts_handle {
 };
 
 static std::string g_create_error;
+static std::mutex g_create_mu;
 
 #define DTTS_API_BEGIN try {
 #define DTTS_API_END(h)                                   \
@@ -111,6 +112,7 @@ int dtts_create(dtts_handle** out, const dtts_config* cfg, int device) {
         h->m.reset(new Model(*cfg, device));
         *out = h;
     } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> lk(g_create_mu);
         g_create_error = e.what();
         return -2;
     }

@@ -33,9 +33,10 @@ void* Arena::raw(size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------ Model
+static constexpr size_t INT_RING_BYTES = 1u << 20;
 Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) {
     DTTS_CHECK_HIP(hipSetDevice(dev));
-    DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&lens_dev_), 1 << 16));
+    DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&lens_dev_), INT_RING_BYTES));
 }
 
 Model::~Model() {
@@ -48,9 +49,11 @@ Model::~Model() {
 }
 
 const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
-    // small ring buffer; entries stay valid for at least the next ~16K ints of uploads
-    const size_t cap = (1 << 16) / sizeof(int);
-    DTTS_REQUIRE((size_t)n <= cap / 4, "too many ints");
+    // ring buffer of small host -> device int tables (lengths, ids, maps): 1 MiB, so an entry stays valid for the next >= 192 K ints
+    // of uploads - far beyond what one entry point uploads while its kernels are in flight (the largest: B * max_text ids of a GPT
+    // prefill = 6.4 K, 2 J (B + Nu) ints per integrator chunk)
+    const size_t cap = INT_RING_BYTES / sizeof(int);
+    DTTS_REQUIRE((size_t)n <= cap / 4, "int table too large for the upload ring");
     if (lens_off_ + n > cap) lens_off_ = 0;
     int* dst = lens_dev_ + lens_off_;
     lens_off_ += (size_t)((n + 15) & ~15);

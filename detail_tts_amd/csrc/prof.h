@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -36,7 +37,11 @@ public:
             pool_.push_back(e);
         }
     }
+    // begin / end / collect take the lock: two handles driven from two host threads may record concurrently (each ProfScope's
+    // begin..end pair still has to stay on one thread)
     void begin(const char* tag, double flops, double bytes, hipStream_t s) {
+        if (!on) { active_ = false; return; }
+        std::lock_guard<std::mutex> lk(mu_);
         active_ = on && (all || flops > 0.0);
         if (!active_) return;
         if (!base_) {
@@ -49,10 +54,12 @@ public:
     }
     void end(hipStream_t s) {
         if (!active_) return;
+        std::lock_guard<std::mutex> lk(mu_);
         (void)hipEventRecord(recs_.back().stop, s);
     }
     // synchronises, folds the pending records into the per-tag totals and recycles the events
     void collect() {
+        std::lock_guard<std::mutex> lk(mu_);
         for (auto& r : recs_) {
             (void)hipEventSynchronize(r.stop);
             float ms = 0.f, t0 = 0.f;
@@ -100,6 +107,7 @@ public:
     }
 
 private:
+    std::mutex mu_;
     struct Rec {
         const char* tag;
         double flops, bytes;

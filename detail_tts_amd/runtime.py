@@ -56,6 +56,24 @@ class Runtime:
         c.gpt_dim, c.gpt_layers, c.gpt_heads, c.gpt_mel_codes = g["model_dim"], g["layers"], g["heads"], g["number_mel_codes"]
         c.gpt_text_tokens = g["number_text_tokens"] + 1
         c.gpt_max_mel_pos, c.gpt_max_text_pos = g["max_mel_tokens"] + 3, g["max_text_tokens"] + 2
+        # every vaegan field the C side reads (the packer lays the blob out from the same cfg: a mismatch would otherwise surface
+        # as a confusing bind-time size error, or - equal sizes, different geometry - not at all)
+        c.inter_channels, c.hidden_channels, c.filter_channels = v["inter_channels"], v["hidden_channels"], v["filter_channels"]
+        c.enc_heads, c.enc_layers, c.gin_channels = v["n_heads"], v["n_layers"], v["gin_channels"]
+        c.upsample_initial_channel, c.n_upsamples = v["upsample_initial_channel"], len(v["upsample_rates"])
+        if c.n_upsamples > 8 or len(v["resblock_kernel_sizes"]) > 4 or str(v.get("resblock", "1")) != "1":
+            raise DttsError("vaegan config outside what libdetail_hip supports (<= 8 upsampling stages, <= 4 ResBlock1 kernels)")
+        if any(list(d) != list(v["resblock_dilation_sizes"][0]) for d in v["resblock_dilation_sizes"]) or len(v["resblock_dilation_sizes"][0]) != 3:
+            raise DttsError("vaegan config: the ResBlock1 branches must share one set of 3 dilations")
+        for i, (r, k) in enumerate(zip(v["upsample_rates"], v["upsample_kernel_sizes"])):
+            c.upsample_rates[i], c.upsample_kernels[i] = int(r), int(k)
+        c.n_resblock_kernels = len(v["resblock_kernel_sizes"])
+        for i, k in enumerate(v["resblock_kernel_sizes"]):
+            c.resblock_kernels[i] = int(k)
+        for i, dd in enumerate(v["resblock_dilation_sizes"][0]):
+            c.resblock_dilations[i] = int(dd)
+        from .config import COND_FREE_K, INFER_DIFFUSION_STEPS, TRAINED_DIFFUSION_STEPS
+        c.diff_steps, c.diff_trained_steps, c.cond_free_k = INFER_DIFFUSION_STEPS, TRAINED_DIFFUSION_STEPS, float(COND_FREE_K)
         from .vqvae.utils.diffusion import space_timesteps
         self.timestep_map = sorted(space_timesteps(4000, [50]))
         self.h = C.c_void_p()

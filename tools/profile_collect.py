@@ -7,15 +7,16 @@ import rocprof_summary
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pf = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
-dbs = glob.glob(os.path.join(go, f"{tag}_stats", "**", "*.db"), recursive=True)
-if dbs:
-    rocprof_summary.main(dbs[0], os.path.join(pf, f"{tag}_bench_kernel_stats.txt"),
-                         f"{tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline (3 passes: warmup, "
-                         "stage-timing, timed; batch 8). The cond/uncond halves of each diffusion forward run on two HIP streams, so launch "
-                         "durations include time shared with the other stream's kernels.")
-    line = [l for l in open(os.path.join(go, f"{tag}_bench.json")) if l.startswith("{")]
-    if line:
-        open(os.path.join(pf, f"{tag}_bench.json"), "w").write(line[-1])
+for name in (f"{tag}_bench_kernel_stats.txt", f"{tag}_default_bench.json"):          # summarised on the box by tools/profile_round.sh
+    src = os.path.join(go, name)
+    if os.path.exists(src):
+        txt = open(src).read()
+        if name.endswith(".json"):
+            txt = [l for l in txt.splitlines() if l.startswith("{")][-1] + "\n"
+        open(os.path.join(pf, name), "w").write(txt)
+line = [l for l in open(os.path.join(go, f"{tag}_bench.json")) if l.startswith("{")] if os.path.exists(os.path.join(go, f"{tag}_bench.json")) else []
+if line:
+    open(os.path.join(pf, f"{tag}_bench.json"), "w").write(line[-1])
 # HBM-side traffic of the conv_x3 launches of one layer: dispatch order inside a layer is c1 (1x1), c2 (k3), qkv (1x1, M=2304), proj (1x1)
 names = ["768->768 k1", "768->768 k3", "768->2304 k1", "768->768 k1 (proj)"]
 res = collections.OrderedDict((n, {}) for n in names)
@@ -29,7 +30,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for i, n in enumerate(names):
         v = [float(r["Counter_Value"]) for r in conv[i::4]]
         res[n][c] = sum(v) / max(len(v), 1)
-    for k in ("gn_split_planes", "split_planes_kernel", "flash_attn"):
+    for k in ("gn_split_planes", "split_planes_kernel", "flash_attn"):   # the other trunk kernels
         v = [float(r["Counter_Value"]) for r in rows if k in r["Kernel_Name"] and r["Counter_Name"] == c and ("gn_" in r["Kernel_Name"]) == k.startswith("gn_")]
         if v:
             other[k][c] = sum(v) / len(v)
