@@ -159,6 +159,117 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
             }
 }
 
+// ---- ping-pong variant: 256 x 192 tile, 8 waves = two groups of four (waves w and w + 4 share a SIMD).  The groups run half a K-step
+// out of phase: while one group issues its 18 MFMAs of step s (M phase) the other reads its fragments of the next step from LDS and
+// issues its share of the LDS-DMA two steps ahead (R phase); ONE barrier per phase.  3 LDS stages; every wave issues 4 DMA instructions
+// per step and waits vmcnt(4) at the end of its R phase, so every piece issued at least one R phase earlier has landed at each barrier.
+template <int NSTG>     // LDS stages: loads run NSTG - 1 steps ahead
+__global__ __launch_bounds__(512, 2) void gemm_pp(const uint4* __restrict__ Wp, const uint4* __restrict__ Xp, float* __restrict__ Y, int M, int C8, int Tp,
+                                                  int T, int ntn, float oscale) {
+    constexpr int NPL = 2, NK = 4, BM = 256, BN = 192, MI = 2, NJ = 3, DIST = NSTG - 1;
+    constexpr int ATILE = NK * BM * 16, BTILE = NK * BN * 16, STAGE = ATILE + BTILE;          // 16 + 12 KiB
+    constexpr int APIECES = NK * BM / 64, BPIECES = NK * BN / 64, PIECES = APIECES + BPIECES;  // 16 + 12 = 28
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+    const int grp = wave >> 2, wq = wave & 3;        // group (phase parity), index inside the group
+    const int mtiles = M / BM;
+    int L;
+    {
+        const int nwg = gridDim.x, lin = blockIdx.x, xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    }
+    const int mt = L % mtiles, nb = L / mtiles, b = nb / ntn, n0 = (nb - b * ntn) * BN, m0 = mt * BM;
+    const int nks = C8 / 2;
+    const uint4* wbase = Wp + m0 + lane;
+    const uint4* xbase = Xp + (size_t)b * C8 * NPL * Tp + n0 + 1 + lane;
+    auto issue = [&](int i, int ks) {               // this wave's i-th piece (0..3) of step ks (clamped)
+        const int c16 = ks < nks ? ks : nks - 1, stage = ks % NSTG;
+        int p = wave + 8 * i;
+        if (p >= PIECES) p = wave;                  // duplicates keep the instruction count uniform
+        if (p < APIECES) {
+            const int kind = p >> 2, rh = p & 3, pl = kind >> 1, h = kind & 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + ((long long)(2 * c16 + h) * NPL + pl) * M + rh * 64),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + kind * (BM * 16) + rh * 1024), 16, 0, 0);
+        } else {
+            const int q = p - APIECES, kind = q / 3, rh = q - kind * 3, pl = kind >> 1, h = kind & 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + rh * 64),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + ATILE + kind * (BN * 16) + rh * 1024), 16, 0, 0);
+        }
+    };
+    // wave grid 4 (M) x 2 (N): the two waves of a SIMD (w, w + 4) take different row blocks
+    const int wr = (wq & 1) * 2 + grp, wc = wq >> 1;
+    const int wm0 = wr * 64, wn0 = wc * 96;
+    f16v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < DIST; ++st)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue(i, st);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf8 a[MI][NPL], bb[NJ][NPL];
+    auto rphase = [&](int ks) {                     // fragments of step ks, then this wave's DMA share two steps ahead
+        const unsigned char* As = smem + (ks % NSTG) * STAGE + lhi * (BM * 16);
+        const unsigned char* Bs = smem + (ks % NSTG) * STAGE + ATILE + lhi * (BN * 16);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i][p] = *reinterpret_cast<const bf8*>(As + p * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bb[j][p] = *reinterpret_cast<const bf8*>(Bs + p * (2 * BN * 16) + (wn0 + j * 32 + l31) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue(i, ks + DIST);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST - 1)) : "memory");       // all but the newest DIST - 1 steps' pieces have landed
+    };
+    auto mphase = [&]() {
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[i][TA[t]]), __builtin_bit_cast(hf8, bb[j][TB[t]]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // group 0: R(0) | M R(1) | ... ; group 1 runs the same sequence one phase later.  Two straight-line loops (a shared loop with a
+    // per-phase branch makes the compiler copy all 96 accumulator registers around every M phase).
+    auto step = [&](int ks) {
+        rphase(ks);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mphase();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    if (grp == 0) {
+        for (int ks = 0; ks < nks; ++ks) step(ks);
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __builtin_amdgcn_s_barrier();
+        for (int ks = 0; ks < nks; ++ks) step(ks);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* yb = Y + (long long)b * M * T;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, n = n0 + wn0 + j * 32 + l31;
+                if (n < T) yb[(long long)row * T + n] = acc[i][j][r] * oscale;
+            }
+}
+
 static unsigned short h_bf16(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
 static float h_f(unsigned short h) { unsigned u = ((unsigned)h) << 16; float f; memcpy(&f, &u, 4); return f; }
 static unsigned short h_f16(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
@@ -213,6 +324,45 @@ void run(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int T, int Tp
            fl / (best * 1e-3) / 1e12, (NPL == 3 ? 6 : 3) * fl / (best * 1e-3) / 1e12 / 2500.0);
 }
 
+template <int NSTG>
+void run_pp(const uint4* Wp, const uint4* Xp, float* Y, int M, int C, int T, int Tp, int B, const std::vector<float>& hw, const std::vector<float>& hx,
+            const char* name, float oscale) {
+    constexpr int BM = 256, BN = 192;
+    if (M % BM) { printf("%-26s M %d not a multiple of %d\n", name, M, BM); return; }
+    const int ntn = (T + BN - 1) / BN;
+    const dim3 grid((M / BM) * ntn * B);
+    const size_t lds = (size_t)NSTG * 4 * 16 * (BM + BN);
+    auto k = gemm_pp<NSTG>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, Wp, Xp, Y, M, C / 8, Tp, T, ntn, oscale);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("%-26s launch failed\n", name); return; }
+    std::vector<float> hy((size_t)M * T);
+    (void)hipMemcpy(hy.data(), Y + (size_t)(B - 1) * M * T, hy.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0, scale = 0;
+    const float* xb = hx.data() + (size_t)(B - 1) * C * T;
+    for (int m = 0; m < M; m += 37)
+        for (int n = 0; n < T; n += 53) {
+            double ref = 0;
+            for (int c = 0; c < C; ++c) ref += (double)hw[(size_t)m * C + c] * (double)xb[(size_t)c * T + n];
+            maxerr = fmax(maxerr, fabs(ref - hy[(size_t)m * T + n]));
+            scale = fmax(scale, fabs(ref));
+        }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f, tot = 0.f;
+    const int reps = 5, rounds = 4;
+    for (int r = 0; r < rounds; ++r) {
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, Wp, Xp, Y, M, C / 8, Tp, T, ntn, oscale);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = fminf(best, ms / reps);
+        tot += ms / reps;
+    }
+    const double fl = 2.0 * M * C * (double)T * B;
+    printf("%-26s ping-pong st%d M %4d  tile 256x192  %4d WGs  rel err %.1e  %7.1f us (best %7.1f)  %6.1f TF-eq (best %6.1f)  frac %.3f\n", name, NSTG, M, grid.x,
+           maxerr / scale, tot / rounds * 1e3, best * 1e3, fl / (tot / rounds * 1e-3) / 1e12, fl / (best * 1e-3) / 1e12, 3 * fl / (best * 1e-3) / 1e12 / 2500.0);
+}
+
 template <int NPL>
 void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, const std::vector<float>& hx) {
     const float sw = NPL == 2 ? 64.f : 1.f, sx = NPL == 2 ? 16.f : 1.f;
@@ -236,6 +386,7 @@ void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, con
     const float os = 1.f / (sw * sx);
     printf("---- %s, M = %d\n", NPL == 3 ? "3 x bf16 planes, 6 products" : "2 x fp16 planes, 3 products", M);
     for (int rep = 0; rep < 2; ++rep) {
+        if (NPL == 2) { run_pp<3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); run_pp<4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); run_pp<5>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); }
         run<NPL, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 global_load_lds", os);
         run<NPL, 2, 2, 2, 3, 2, 2, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 buffer_load lds", os);
         run<NPL, 2, 2, 2, 3, 2, 3, 1, 0, 1>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 buffer st3", os);
