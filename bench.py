@@ -178,16 +178,24 @@ def main():
                    "wav_sha256": hashlib.sha256(pw.tobytes()).hexdigest(), "wav_rms": float(np.sqrt(np.mean(pw.astype(np.float64) ** 2)))},
                   open(f"{args.probe_out}.rank{rank}.json", "w"))
 
-    # Stage C of batch i runs on a second HIP stream while the first stream already decodes batch i + 1 (the GPT decode is a chain of
-    # short latency-bound kernels that leaves the chip mostly idle): every waveform is complete and checked before the clock stops.
+    # Software pipeline over batches (SynthesizerTrn.infer_stream): stage A of batch i + 1 (the GPT decode: a chain of short
+    # latency-bound kernels) runs on a high-priority HIP stream under stage B of batch i, stage C of batch i on a third stream under
+    # stage B of batch i + 1.  The timed region starts with nothing in flight and ends when every waveform is complete and checked.
+    # DTTS_BENCH_PIPELINE=0: one infer() call per step, stage C of batch i under the GPT decode of batch i + 1 only (round-2 first form).
+    pipeline = os.environ.get("DTTS_BENCH_PIPELINE", "1") != "0"
     overlap = os.environ.get("DTTS_BENCH_OVERLAP_VOCODER", "1") != "0"
 
     def step(i, pipelined=True):
         return model.infer(text, tl, refer, rl, batch=True, seed=1234 + i, sample_ids=sample_ids, max_generate_length=n_codes + 1,
                            suppress_eos=True, return_lengths=True, stream_vocoder=overlap and pipelined, vocoder_chunk=0, wait=False)
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, count):
+        if not pipeline:
+            return [step(first + i) for i in range(count)]
+        reqs = (dict(text=text, text_length=tl, refer=refer, refer_lengths=rl, seed=1234 + first + i, sample_ids=sample_ids) for i in range(count))
+        return list(model.infer_stream(reqs, max_generate_length=n_codes + 1, suppress_eos=True))
+
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -195,21 +203,24 @@ def main():
     step(99, pipelined=False)                # one untimed, un-pipelined pass with per-stage hipEvents (adds a sync, so not part of the timed region)
     stage_ms = {k: round(v, 2) for k, v in model.stage_ms.items()}
     model.stage_ms = None
-    model.rt.profile_enable(os.environ.get("DTTS_BENCH_NO_PROF") != "1")            # per-launch hipEvents on the launch streams, live over the timed region
+    # per-launch hipEvents on the launch streams, live over the timed region: every launch of every PROF_EVERY-th sampling step of each
+    # batch (all streams, so the union of the intervals keeps its meaning) - bracketing all 50 steps costs 2 % of the step
+    PROF_EVERY = int(os.environ.get("DTTS_BENCH_PROF_EVERY", "5"))
+    model.rt.profile_sampling(PROF_EVERY)
+    model.rt.profile_enable(os.environ.get("DTTS_BENCH_NO_PROF") != "1")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    wavs = []
-    for i in range(args.steps):
-        wav, lens = step(100 + i)
-        wavs.append(wav)
+    outs = run_steps(100, args.steps)
+    wavs, lens = [o[0] for o in outs], outs[-1][1]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = model.rt.profile_report()
     model.rt.profile_enable(False)
+    model.rt.profile_sampling(1)
     assert all(l == n_codes * 1024 for l in lens) and all(bool(torch.isfinite(w).all()) for w in wavs)
     del wavs
     # stage C alone under the all-kernel profiler (untimed): TFLOP/s and algorithmic GB/s of the vocoder stage
@@ -279,9 +290,10 @@ def main():
                 "fp32_equivalent_tflops": round(fp32_equiv, 2),
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
                 "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
-                "busy_share_of_timed_region": round(dom["union_ms"] * 1e-3 / dt, 3),
+                "busy_share_of_timed_region": round(dom["union_ms"] * PROF_EVERY * 1e-3 / dt, 3),
                 "overlap": round(dom["total_ms"] / max(dom["union_ms"], 1e-9), 3),
-                "measured": "hipEvents on the launch streams around every launch of the timed region; achieved = flops / union of launch intervals"}
+                "measured": f"hipEvents on the launch streams around every launch of every {PROF_EVERY}-th sampling step of the timed region's batches "
+                            "(`launches` counts the bracketed ones); achieved = flops / union of launch intervals"}
     # the other stages' rooflines
     att = next((p for p in prof if p["name"].startswith("flash_attn_x3")), None)
     roof_att = None
@@ -308,7 +320,9 @@ def main():
         "config": {"workload": "configs[2]: 1xMI355X batch-8, 10 s prompts (T_ref=936), 234 codes -> 9.984 s audio per utterance; "
                                "GPT KV-cache decode + 50-step CFG diffusion + flow-VAE/HiFiGAN vocoder, seed-0 random-init weights",
                    "batch_per_gpu": B, "codes": n_codes, "diffusion_steps": 50, "parallelism": f"replica x{world}",
-                   "pipelining": "stage C of batch i on a second HIP stream under the GPT decode of batch i + 1" if overlap else "none"},
+                   "pipelining": ("stage A of batch i + 1 on a high-priority HIP stream under stage B of batch i, stage C of batch i under stage B of "
+                                  "batch i + 1 (SynthesizerTrn.infer_stream)") if pipeline else
+                                 ("stage C of batch i on a second HIP stream under the GPT decode of batch i + 1" if overlap else "none")},
         "stage_ms": stage_ms,
         "roofline": roof,
         "roofline_attention": roof_att,

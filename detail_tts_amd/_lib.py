@@ -51,6 +51,7 @@ SIGNATURES = {
     "dtts_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dtts_profile_enable": (C.c_int, [C.c_int]),
+    "dtts_profile_sampling": (C.c_int, [C.c_int]),
     "dtts_profile_report": (C.c_int, [C.POINTER(DttsKernelStat), C.c_int]),
     "dtts_gpt_generate": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int,
                                     C.POINTER(DttsGptOptions), c_int_p, c_int_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -8,8 +8,10 @@ using dtts::Model;
 
 struct dtts_handle {
     std::unique_ptr<Model> m;
-    std::string err;
 };
+
+// last error of the CALLING thread (a handle may be driven by two threads: stage A of the next request beside stages B / C of this one)
+static thread_local std::string t_err;
 
 static std::string g_create_error;
 static std::mutex g_create_mu;
@@ -18,11 +20,11 @@ static std::mutex g_create_mu;
 #define DTTS_API_END(h)                                   \
     }                                                     \
     catch (const dtts::Error& e) {                        \
-        if (h) (h)->err = e.what();                       \
+        t_err = e.what();                                 \
         return e.code;                                    \
     }                                                     \
     catch (const std::exception& e) {                     \
-        if (h) (h)->err = e.what();                       \
+        t_err = e.what();                                 \
         return -100;                                      \
     }                                                     \
     return 0;
@@ -87,6 +89,11 @@ int dtts_profile_enable(int on) {
     return 0;
 }
 
+int dtts_profile_sampling(int every) {
+    dtts::Profiler::get().step_every = every < 1 ? 1 : every;
+    return 0;
+}
+
 int dtts_profile_report(dtts_kernel_stat* out, int max_entries) {
     auto v = dtts::Profiler::get().report();
     int n = 0;
@@ -124,7 +131,7 @@ int dtts_destroy(dtts_handle* h) {
     return 0;
 }
 
-const char* dtts_last_error(dtts_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* dtts_last_error(dtts_handle* h) { return h ? t_err.c_str() : g_create_error.c_str(); }
 
 int dtts_bind_weights(dtts_handle* h, const void* blob, size_t nbytes, const char* const* names, const unsigned long long* offsets,
                       const unsigned long long* numels, int n, void* stream) {

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -105,6 +106,21 @@ private:
     char* base_ = nullptr;
     size_t cap_ = 0, off_ = 0;
 };
+
+// A stage-local arena stands in for the handle's main workspace for the duration of one entry point ON THE CALLING THREAD, so stages
+// that run concurrently on different streams - and are issued from different host threads (stage A of the next request under stage B of
+// this one, SynthesizerTrn.infer_stream) - never share scratch.
+class ArenaUse {
+public:
+    explicit ArenaUse(Arena& a);
+    ~ArenaUse();
+    ArenaUse(const ArenaUse&) = delete;
+    ArenaUse& operator=(const ArenaUse&) = delete;
+
+private:
+    Arena* prev_;
+};
+Arena* arena_override();     // the calling thread's stand-in (nullptr: none)
 
 class Model {
 public:
@@ -281,11 +297,14 @@ private:
     PackedConv vqe_c1_, vqe_c2_, vqe_c3_, vq_proj_in_;
     const float *vqe_ln_g_ = nullptr, *vqe_ln_b_ = nullptr, *vq_embed_ = nullptr, *vq_embed_sq_ = nullptr;
 
-    Arena ws_;        // per-call activations
-    Arena ws_voc_;    // stage C's own scratch (swapped in for the duration of a vocoder call)
+    Arena ws_main_;   // per-call activations (stages B and everything else); see ws()
+    Arena& ws() { Arena* o = arena_override(); return o ? *o : ws_main_; }
+    Arena ws_voc_;    // stage C's own scratch (stands in for the duration of a vocoder call)
+    Arena ws_gpt_;    // stage A's session prefill scratch: the next batch's decode session may run under this batch's diffusion
     Arena persist_;   // tables built at bind time
     int* lens_dev_ = nullptr;   // small ring of device int buffers
     size_t lens_off_ = 0;
+    std::mutex ints_mu_;        // upload_ints is called from both issuing threads
 };
 
 }  // namespace dtts

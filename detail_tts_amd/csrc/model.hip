@@ -1,6 +1,7 @@
 // Model runtime: weight lookup, workspace, diffusion-stage orchestration (see model.h).
 #include "model.h"
 #include "conv_x3.h"
+#include "prof.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -8,6 +9,11 @@
 namespace dtts {
 
 // ------------------------------------------------------------------------------------------ Arena
+static thread_local Arena* t_arena_override = nullptr;
+Arena* arena_override() { return t_arena_override; }
+ArenaUse::ArenaUse(Arena& a) : prev_(t_arena_override) { t_arena_override = &a; }
+ArenaUse::~ArenaUse() { t_arena_override = prev_; }
+
 Arena::~Arena() {
     if (base_) (void)hipFree(base_);
 }
@@ -54,6 +60,7 @@ const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
     // prefill = 6.4 K, 2 J (B + Nu) ints per integrator chunk)
     const size_t cap = INT_RING_BYTES / sizeof(int);
     DTTS_REQUIRE((size_t)n <= cap / 4, "int table too large for the upload ring");
+    std::lock_guard<std::mutex> lk(ints_mu_);
     if (lens_off_ + n > cap) lens_off_ = 0;
     int* dst = lens_dev_ + lens_off_;
     lens_off_ += (size_t)((n + 15) & ~15);
@@ -511,8 +518,8 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     const bool x3 = use_x3();
 
     // shared x path: inp_block + the x-half of integrating_conv (+ bias) on the B samples (vqvae/diff_model.py:296-298)
-    float* xin = ws_.f32((size_t)B * C * Ta);
-    float* xpath = ws_.f32((size_t)B * C * Ta);
+    float* xin = ws().f32((size_t)B * C * Ta);
+    float* xpath = ws().f32((size_t)B * C * Ta);
     {
         ConvParams p = cp(x, cfg.mel_channels, xin, C, B, T, Ta, lens2);
         p.x_bs = (long long)cfg.mel_channels * T;
@@ -520,7 +527,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         p.pad = 1;
         ConvParams q = cp(xin, C, xpath, C, B, T, Ta, lens2);
         if (x3) {
-            void* xs0 = ws_.raw(x3_bytes(B, C, T));
+            void* xs0 = ws().raw(x3_bytes(B, C, T));
             launch_split_planes(x, p.x_bs, T, nullptr, ACT_NONE, lens2, T, B, cfg.mel_channels, xs0, s);
             p.x3 = xs0;
             p.x3_tp = x3_tp(T);
@@ -555,26 +562,26 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     // steps before the loop (precompute_integrator), or evaluated here as one (B + Nu)-sample batch
     const float* code_path = integ;
     if (!integ) {
-        float* bufI = ws_.f32((size_t)Bi * C * Ta);
-        const size_t mark = ws_.mark();
+        float* bufI = ws().f32((size_t)Bi * C * Ta);
+        const size_t mark = ws().mark();
         const size_t act = (size_t)Bi * C * Ta;
-        float* tA = ws_.f32(act);
-        float* tB = ws_.f32(act);
-        float* qkv = ws_.f32(qkv_floats(Bi, C, T));
-        float* ab = ws_.f32((size_t)Bi * C * 2);
-        void* xs = x3 ? ws_.raw(x3_bytes(Bi, C, T)) : nullptr;
+        float* tA = ws().f32(act);
+        float* tB = ws().f32(act);
+        float* qkv = ws().f32(qkv_floats(Bi, C, T));
+        float* ab = ws().f32((size_t)Bi * C * 2);
+        void* xs = x3 ? ws().raw(x3_bytes(Bi, C, T)) : nullptr;
         const float* in = cbuf0;
         for (int l = 0; l < 3; ++l) {
             res_block_fwd(integ_[l].rb, in, tA, tB, ab, lens_i, Bi, T, Ta, step, s, xs);
             attention_block(integ_[l].at, tB, bufI, qkv, tA, ab, lens_i, Bi, T, Ta, s, xs);
             in = bufI;
         }
-        ws_.rewind(mark);
+        ws().rewind(mark);
         code_path = bufI;
     }
     void* xs_code = nullptr;
     if (x3) {
-        xs_code = ws_.raw(x3_bytes(Bi, C, T));
+        xs_code = ws().raw(x3_bytes(Bi, C, T));
         launch_split_planes(code_path, bs, Ta, nullptr, ACT_NONE, lens_i, T, Bi, C, xs_code, s);
     }
     if (NS > 1) {
@@ -586,12 +593,12 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         const int b0 = k * n;                          // first sample of the chunk in the 2B stack
         const int* lens = lens2 + b0;
         const size_t act = (size_t)n * C * Ta;
-        float* bufA = ws_.f32(act);
-        float* bufB = ws_.f32(act);
-        float* bufC = ws_.f32(act);
-        float* qkv = ws_.f32(qkv_floats(n, C, T));
-        float* ab = ws_.f32((size_t)n * C * 2);
-        void* xs = x3 ? ws_.raw(x3_bytes(n, C, T)) : nullptr;
+        float* bufA = ws().f32(act);
+        float* bufB = ws().f32(act);
+        float* bufC = ws().f32(act);
+        float* qkv = ws().f32(qkv_floats(n, C, T));
+        float* ab = ws().f32((size_t)n * C * 2);
+        void* xs = x3 ? ws().raw(x3_bytes(n, C, T)) : nullptr;
         // integrating_conv, code half, accumulated onto the shared x-path term (the residual of stack sample b is xpath[b % B])
         ConvParams r = cp(code_path, C, bufB, C, n, T, Ta, lens);
         r.res = xpath + (size_t)(b0 % B) * C * Ta;
@@ -649,7 +656,7 @@ static int integ_chunk(int Bi) {     // steps per batched evaluation (~36 sample
 void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, int B, int Nu, int T, const std::vector<int>& steps,
                                   float* integ_all, hipStream_t s) {
     const int C = cfg.diff_channels, Bi = B + Nu, J = integ_chunk(Bi), NS = (int)steps.size();
-    const size_t ct = (size_t)C * T, mark = ws_.mark();
+    const size_t ct = (size_t)C * T, mark = ws().mark();
     const int Bv = J * Bi;
     const bool x3 = use_x3();
     static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
@@ -659,7 +666,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         for (auto& e : ev_joinx_) DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    float* vin = ws_.f32((size_t)Bv * ct);
+    float* vin = ws().f32((size_t)Bv * ct);
     for (int j = 0; j < J; ++j)
         DTTS_CHECK_HIP(hipMemcpyAsync(vin + (size_t)j * Bi * ct, cbuf0, sizeof(float) * (size_t)Bi * ct, hipMemcpyDeviceToDevice, s));
     // chunks of J steps alternate between the two streams (independent of each other), each with its own scratch
@@ -667,12 +674,12 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     Lane lanes[2];
     for (int q = 0; q < (two ? 2 : 1); ++q) {
         lanes[q].st = q ? sx_[0] : s;
-        lanes[q].bufB = ws_.f32((size_t)Bv * ct);
-        lanes[q].bufC = ws_.f32((size_t)Bv * ct);
-        lanes[q].bufA = ws_.f32((size_t)Bv * ct);
-        lanes[q].qkv = ws_.f32(qkv_floats(Bv, C, T));
-        lanes[q].ab = ws_.f32((size_t)2 * Bv * C);
-        lanes[q].xs = x3 ? ws_.raw(x3_bytes(Bv, C, T)) : nullptr;
+        lanes[q].bufB = ws().f32((size_t)Bv * ct);
+        lanes[q].bufC = ws().f32((size_t)Bv * ct);
+        lanes[q].bufA = ws().f32((size_t)Bv * ct);
+        lanes[q].qkv = ws().f32(qkv_floats(Bv, C, T));
+        lanes[q].ab = ws().f32((size_t)2 * Bv * C);
+        lanes[q].xs = x3 ? ws().raw(x3_bytes(Bv, C, T)) : nullptr;
     }
     if (two) {
         DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
@@ -682,6 +689,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     int ci = 0;
     for (int k0 = 0; k0 < NS; k0 += J, ++ci) {
         const Lane& L = lanes[two ? (ci & 1) : 0];
+        Profiler::get().gate = ((ci / 2) % Profiler::get().step_every) == 0;      // both lanes of a chunk pair, or neither
         const int jn = std::min(J, NS - k0), nb = jn * Bi;
         for (int j = 0; j < jn; ++j)
             for (int b = 0; b < Bi; ++b) {
@@ -703,7 +711,8 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         DTTS_CHECK_HIP(hipEventRecord(ev_joinx_[0], sx_[0]));
         DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_joinx_[0], 0));
     }
-    ws_.rewind(mark);
+    Profiler::get().gate = true;
+    ws().rewind(mark);
 }
 
 static size_t pair_ws_bytes(int B, int C, int T) {
@@ -720,10 +729,10 @@ void Model::diff_forward(const float* x, const float* code_emb, const int* lens_
     DTTS_REQUIRE(bound_, "weights not bound");
     DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
     const int C = cfg.diff_channels, OC = cfg.diff_out_channels;
-    ws_.ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 4096);
+    ws().ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 4096);
     const PairPlan pl = plan_pair(lens_host, B, T, s);
-    float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
-    float* out2 = ws_.f32((size_t)2 * B * OC * T);
+    float* cbuf0 = ws().f32((size_t)2 * B * C * T);
+    float* out2 = ws().f32((size_t)2 * B * OC * T);
     const size_t half = (size_t)B * C * T;
     if (code_emb)
         DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
@@ -745,12 +754,12 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     // the integrator outputs of all steps are evaluated up front (opt-out: DTTS_INTEG_PRECOMPUTE=0); Nu <= B distinct lengths
     static const bool env_pre = []() { const char* v = getenv("DTTS_INTEG_PRECOMPUTE"); return !(v && v[0] == '0'); }();
     const size_t integ_bytes = env_pre ? sizeof(float) * (size_t)n_steps * 2 * B * C * T + integ_ws_bytes(integ_chunk(B + 1) * 2 * B, C, T) : 0;
-    ws_.ensure(per_call + integ_bytes + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
+    ws().ensure(per_call + integ_bytes + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
     const PairPlan pl = plan_pair(lens_host, B, T, s);
     const int* lens2 = pl.lens2;
     const int* sids = upload_ints(sample_ids_host, B, s);
-    float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
-    float* out2 = ws_.f32((size_t)2 * B * OC * T);
+    float* cbuf0 = ws().f32((size_t)2 * B * C * T);
+    float* out2 = ws().f32((size_t)2 * B * OC * T);
     const size_t half = (size_t)B * C * T;
     DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
     launch_broadcast_channels(uncond_, pl.Nu, C, T, cbuf0 + half, (long long)C * T, T, s);
@@ -782,19 +791,21 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
         for (int k = 0; k < n_steps; ++k) steps[k] = n_steps_ - 1 - k;
         for (int b = 0; b < B; ++b) li[b] = lens_host ? lens_host[b] : T;
         for (int u = 0; u < pl.Nu; ++u) li[B + u] = pl.ulen[u];
-        integ_all = ws_.f32((size_t)n_steps * Bi * C * T);
+        integ_all = ws().f32((size_t)n_steps * Bi * C * T);
         precompute_integrator(cbuf0, li.data(), B, pl.Nu, T, steps, integ_all, s);
     }
-    const size_t mark = ws_.mark();
+    const size_t mark = ws().mark();
     for (int k = 0; k < n_steps; ++k) {
         const int i = n_steps_ - 1 - k;
-        ws_.rewind(mark);                              // the forward's scratch is re-carved every step
+        Profiler::get().gate = (k % Profiler::get().step_every) == 0;
+        ws().rewind(mark);                              // the forward's scratch is re-carved every step
         diff_forward_pair(x, cbuf0, lens2, pl.lens_i, pl.umap, B, pl.Nu, T, i, out2, s,
                           integ_all ? integ_all + (size_t)k * Bi * C * T : nullptr);
         const bool last = (k == n_steps - 1);
         launch_diff_update(x, xbs, T, out2, (long long)OC * T, T, lens2, T, B, MC, step_coefs_[i], seed, sids, i,
                            step_noise ? step_noise + (size_t)k * B * MC * T : nullptr, (denorm && last) ? 1 : 0, s);
     }
+    Profiler::get().gate = true;
 }
 
 // GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at one sampling step, x in place
@@ -804,11 +815,11 @@ void Model::diff_p_sample(float* x, const float* code_emb, const int* lens_host,
     DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
     DTTS_REQUIRE(sample_ids_host, "sample_ids");
     const int C = cfg.diff_channels, OC = cfg.diff_out_channels, MC = cfg.mel_channels;
-    ws_.ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
+    ws().ensure(pair_ws_bytes(B, C, T) + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
     const PairPlan pl = plan_pair(lens_host, B, T, s);
     const int* sids = upload_ints(sample_ids_host, B, s);
-    float* cbuf0 = ws_.f32((size_t)2 * B * C * T);
-    float* out2 = ws_.f32((size_t)2 * B * OC * T);
+    float* cbuf0 = ws().f32((size_t)2 * B * C * T);
+    float* out2 = ws().f32((size_t)2 * B * OC * T);
     const size_t half = (size_t)B * C * T;
     DTTS_CHECK_HIP(hipMemcpyAsync(cbuf0, code_emb, sizeof(float) * half, hipMemcpyDeviceToDevice, s));
     launch_broadcast_channels(uncond_, pl.Nu, C, T, cbuf0 + half, (long long)C * T, T, s);
@@ -828,16 +839,16 @@ void Model::diff_conditioning(const float* refer, const int* lens_host, int B, i
         l2[b] = (l1[b] - 1) / 2 + 1;
     }
     const size_t act = (size_t)B * C2 * T2;
-    ws_.ensure(sizeof(float) * ((size_t)B * C * T1 + 3 * act + 3 * act + (size_t)2 * B * C2) + 8192);
+    ws().ensure(sizeof(float) * ((size_t)B * C * T1 + 3 * act + 3 * act + (size_t)2 * B * C2) + 8192);
     const int* d0 = upload_ints(l0.data(), B, s);
     const int* d1 = upload_ints(l1.data(), B, s);
     const int* d2 = upload_ints(l2.data(), B, s);
-    float* h1 = ws_.f32((size_t)B * C * T1);
-    float* a = ws_.f32(act);
-    float* bb = ws_.f32(act);
-    float* att = ws_.f32(act);
-    float* qkv = ws_.f32(3 * act);
-    float* ab = ws_.f32((size_t)2 * B * C2);
+    float* h1 = ws().f32((size_t)B * C * T1);
+    float* a = ws().f32(act);
+    float* bb = ws().f32(act);
+    float* att = ws().f32(act);
+    float* qkv = ws().f32(3 * act);
+    float* ab = ws().f32((size_t)2 * B * C2);
     ConvParams p;
     p.B = B;
     p.Tin = Tmax;
@@ -882,15 +893,15 @@ void Model::diff_timestep_independent(const float* latent_cm, const int* lens_n_
     DTTS_REQUIRE(bound_, "weights not bound");
     const int C = cfg.diff_channels;
     const size_t act = (size_t)B * C * nmax;
-    ws_.ensure(sizeof(float) * (3 * act + 3 * act + (size_t)2 * B * C) + 8192);
+    ws().ensure(sizeof(float) * (3 * act + 3 * act + (size_t)2 * B * C) + 8192);
     std::vector<int> ln(B);
     for (int b = 0; b < B; ++b) ln[b] = lens_n_host ? lens_n_host[b] : nmax;
     const int* dl = upload_ints(ln.data(), B, s);
-    float* a = ws_.f32(act);
-    float* bb = ws_.f32(act);
-    float* att = ws_.f32(act);
-    float* qkv = ws_.f32(3 * act);
-    float* ab = ws_.f32((size_t)2 * B * C);
+    float* a = ws().f32(act);
+    float* bb = ws().f32(act);
+    float* att = ws().f32(act);
+    float* qkv = ws().f32(3 * act);
+    float* ab = ws().f32((size_t)2 * B * C);
     const long long bs = (long long)C * nmax;
     ConvParams p;
     p.B = B;
@@ -924,18 +935,18 @@ void Model::op_attention_block(const char* prefix, const float* x, const int* le
     DTTS_REQUIRE(bound_, "weights not bound");
     AttnBlockW w = attn_block(prefix, C, cfg.diff_heads);
     const size_t act = (size_t)B * C * T;
-    ws_.ensure(sizeof(float) * (act + qkv_floats(B, C, T) + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
+    ws().ensure(sizeof(float) * (act + qkv_floats(B, C, T) + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
-    float* qkv = ws_.f32(qkv_floats(B, C, T));
-    float* att = ws_.f32(act);
-    float* ab = ws_.f32((size_t)2 * B * C);
+    float* qkv = ws().f32(qkv_floats(B, C, T));
+    float* att = ws().f32(act);
+    float* ab = ws().f32((size_t)2 * B * C);
     // the trunk's blocks take the split-precision path exactly as inside diff_forward
     for (auto* grp : {&integ_, &layers_})
         for (auto& dl2 : *grp)
             if (dl2.at.qkv.w == w.qkv.w) w = dl2.at;
-    void* xs = (use_x3() && w.qkv.w3) ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
+    void* xs = (use_x3() && w.qkv.w3) ? ws().raw(x3_bytes(B, C, T)) : nullptr;
     attention_block(w, x, y, qkv, att, ab, dl, B, T, T, s, xs);
 }
 
@@ -954,13 +965,13 @@ void Model::op_resblock(const char* prefix, const float* x, const int* lens_host
     for (size_t i = 0; i < tail_.size(); ++i) check(tail_[i], "diffusion.layers." + std::to_string(layers_.size() + i));
     DTTS_REQUIRE(found, "unknown resblock prefix");
     const size_t act = (size_t)B * C * T;
-    ws_.ensure(sizeof(float) * (act + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
+    ws().ensure(sizeof(float) * (act + (size_t)2 * B * C) + x3_bytes(B, C, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
-    float* h1 = ws_.f32(act);
-    float* ab = ws_.f32((size_t)2 * B * C);
-    void* xs = use_x3() ? ws_.raw(x3_bytes(B, C, T)) : nullptr;
+    float* h1 = ws().f32(act);
+    float* ab = ws().f32((size_t)2 * B * C);
+    void* xs = use_x3() ? ws().raw(x3_bytes(B, C, T)) : nullptr;
     res_block_fwd(*found, x, h1, y, ab, dl, B, T, T, step, s, xs);
 }
 

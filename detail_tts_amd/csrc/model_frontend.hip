@@ -75,10 +75,10 @@ void Model::mel_spectrogram(const float* wav, const int* lens_host, int B, int L
         tl[b] = len[b] / hop;
         DTTS_REQUIRE(tl[b] >= 1, "wav shorter than one hop");
     }
-    ws_.ensure(sizeof(float) * ((size_t)B * n_fft * T + (size_t)B * 2 * nf * T + (size_t)B * nf * T) + 8192);
-    float* F = ws_.f32((size_t)B * n_fft * T);
-    float* S = ws_.f32((size_t)B * 2 * nf * T);
-    float* M = ws_.f32((size_t)B * nf * T);
+    ws().ensure(sizeof(float) * ((size_t)B * n_fft * T + (size_t)B * 2 * nf * T + (size_t)B * nf * T) + 8192);
+    float* F = ws().f32((size_t)B * n_fft * T);
+    float* S = ws().f32((size_t)B * 2 * nf * T);
+    float* M = ws().f32((size_t)B * nf * T);
     const int* dlen = upload_ints(len.data(), B, s);
     const int* dtl = upload_ints(tl.data(), B, s);
     hipLaunchKernelGGL(frame_reflect_kernel, dim3(cdiv(T, 256), n_fft, B), dim3(256), 0, s, wav, L, dlen, n_fft, hop, T, F);

@@ -67,11 +67,11 @@ void Model::gpt_prefill_layers(float* x, const int* lens, int B, int L, float* k
                                long long kv_bs, int kv_cs, hipStream_t s) {
     const int C = cfg.gpt_dim, H = cfg.gpt_heads, D = C / H;
     const size_t act = (size_t)B * C * L;
-    const size_t mark = ws_.mark();
-    float* h = ws_.f32(act);
-    float* qkv = ws_.f32(3 * act);
-    float* att = ws_.f32(act);
-    float* mlp = ws_.f32(4 * act);
+    const size_t mark = ws().mark();
+    float* h = ws().f32(act);
+    float* qkv = ws().f32(3 * act);
+    float* att = ws().f32(act);
+    float* mlp = ws().f32(4 * act);
     const long long bs = (long long)C * L;
     for (size_t l = 0; l < gpt_layers_.size(); ++l) {
         const GptLayerW& w = gpt_layers_[l];
@@ -113,7 +113,7 @@ void Model::gpt_prefill_layers(float* x, const int* lens, int B, int L, float* k
         p.res_cs = L;
         run_conv(w.fc2, p, s);
     }
-    ws_.rewind(mark);
+    ws().rewind(mark);
 }
 
 static size_t prefill_ws(int B, int C, int L) { return sizeof(float) * (size_t)9 * B * C * L + 16 * 256; }
@@ -155,6 +155,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     DTTS_REQUIRE(o.max_generate_length >= 1 && o.max_generate_length + 1 <= cfg.gpt_max_mel_pos, "max_generate_length");
     DTTS_REQUIRE(!latents_cm || lat_stride >= o.max_generate_length, "latent buffer too small");
     DTTS_REQUIRE(o.sample_ids, "sample_ids");
+    ArenaUse use_stage_a_arena(ws_gpt_);             // decode steps use only gpt_state_; the prefill's scratch is stage A's own
     const int C = cfg.gpt_dim, V = cfg.gpt_mel_codes, G = o.max_generate_length;
     const int NL = (int)gpt_layers_.size();
     std::vector<int> ids, tl;
@@ -202,17 +203,17 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     gs_.kv_layer = kv_layer;
     gs_.steps = 0;
     gs_.active = false;
-    ws_.ensure(std::max(prefill_ws(B, C, Lp) + sizeof(float) * (size_t)B * C * Lp,
+    ws().ensure(std::max(prefill_ws(B, C, Lp) + sizeof(float) * (size_t)B * C * Lp,
                         sizeof(float) * ((size_t)5 * B * (C / 2) * Tr + (size_t)B * C * Tr + (size_t)B * C)) + 65536);
-    float* emb = ws_.f32((size_t)B * C * Lp);
-    float* cond = ws_.f32((size_t)B * C);
+    float* emb = ws().f32((size_t)B * C * Lp);
+    float* cond = ws().f32((size_t)B * C);
     {
         std::vector<int> rl(B);
         for (int b = 0; b < B; ++b) rl[b] = refer_lens_host ? refer_lens_host[b] : Tr;
         const int* d_rl = upload_ints(rl.data(), B, s);
-        const size_t m = ws_.mark();
+        const size_t m = ws().mark();
         mel_style(gpt_cond_, refer, d_rl, rl.data(), B, Tr, cond, s);        // gpt/model.py:521-524
-        ws_.rewind(m);
+        ws().rewind(m);
     }
     const int* d_ids = upload_ints(ids.data(), B * tl_max, s);
     const int* d_tl = upload_ints(tl.data(), B, s);
@@ -477,11 +478,11 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
 void Model::op_sample_logits(const float* logits, int R, int V, const int* history_host, int hist_len, const float* uniforms, int top_k,
                              float top_p, float temperature, float repetition_penalty, int* tokens_host, hipStream_t s) {
     DTTS_REQUIRE(R >= 1 && R <= GEMV_MAXB && V >= 2 && V < 65535, "op_sample_logits: rows 1..8");
-    ws_.ensure((size_t)R * V + sizeof(int) * 4 * R + sizeof(GptCtl) + 16 * 256);
-    unsigned char* seen = static_cast<unsigned char*>(ws_.raw((size_t)R * V));
-    int* finished = ws_.i32(R);
-    int* codes = ws_.i32(R);
-    GptCtl* dctl = static_cast<GptCtl*>(ws_.raw(sizeof(GptCtl)));
+    ws().ensure((size_t)R * V + sizeof(int) * 4 * R + sizeof(GptCtl) + 16 * 256);
+    unsigned char* seen = static_cast<unsigned char*>(ws().raw((size_t)R * V));
+    int* finished = ws().i32(R);
+    int* codes = ws().i32(R);
+    GptCtl* dctl = static_cast<GptCtl*>(ws().raw(sizeof(GptCtl)));
     std::vector<unsigned char> hs((size_t)R * V, 0);
     for (int r = 0; r < R; ++r)
         for (int j = 0; j < hist_len; ++j) {
@@ -557,21 +558,21 @@ void Model::gpt_latents(const float* refer, const int* refer_lens_host, int Tr, 
         }
         r[nn[b] + 1] = 8193;
     }
-    ws_.ensure(sizeof(float) * ((size_t)2 * B * C * L + (size_t)B * C) + prefill_ws(B, C, L) + sizeof(int) * mids.size() +
+    ws().ensure(sizeof(float) * ((size_t)2 * B * C * L + (size_t)B * C) + prefill_ws(B, C, L) + sizeof(int) * mids.size() +
                (size_t)sizeof(float) * ((size_t)5 * B * (C / 2) * Tr + (size_t)B * C * Tr) + 65536);
-    float* emb = ws_.f32((size_t)B * C * L);
-    float* enc = ws_.f32((size_t)B * C * L);
-    float* cond = ws_.f32((size_t)B * C);
-    int* d_mids = ws_.i32(mids.size());
+    float* emb = ws().f32((size_t)B * C * L);
+    float* enc = ws().f32((size_t)B * C * L);
+    float* cond = ws().f32((size_t)B * C);
+    int* d_mids = ws().i32(mids.size());
     DTTS_CHECK_HIP(hipMemcpyAsync(d_mids, mids.data(), sizeof(int) * mids.size(), hipMemcpyHostToDevice, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
     std::vector<int> rl(B);
     for (int b = 0; b < B; ++b) rl[b] = refer_lens_host ? refer_lens_host[b] : Tr;
     const int* d_rl = upload_ints(rl.data(), B, s);
     {
-        const size_t m = ws_.mark();
+        const size_t m = ws().mark();
         mel_style(gpt_cond_, refer, d_rl, rl.data(), B, Tr, cond, s);
-        ws_.rewind(m);
+        ws().rewind(m);
     }
     const int* d_ids = upload_ints(ids.data(), B * tl_max, s);
     const int* d_tl = upload_ints(tl.data(), B, s);

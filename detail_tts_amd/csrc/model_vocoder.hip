@@ -93,10 +93,10 @@ void Model::mel_style(const MelStyleW& w, const float* mel, const int* lens, con
                       hipStream_t s) {
     const int H = w.hidden;
     const size_t act = (size_t)B * H * T;
-    float* a = ws_.f32(act);
-    float* b = ws_.f32(act);
-    float* qkv = ws_.f32(3 * act);
-    float* y = ws_.f32((size_t)B * w.out * T);
+    float* a = ws().f32(act);
+    float* b = ws().f32(act);
+    float* qkv = ws().f32(3 * act);
+    float* y = ws().f32((size_t)B * w.out * T);
     // spectral: Linear -> Mish -> Linear -> Mish  (modules.py:661-668)
     ConvParams p = cp(mel, w.n_mel, a, H, B, T, T, lens);
     p.epi_act = ACT_MISH;
@@ -160,7 +160,7 @@ void Model::op_mel_style(const char* which, const float* mel, const int* lens_ho
     if (n == "ref_enc" && has_vocoder_) w = &ref_enc_;
     if (n == "gpt.conditioning_encoder" && has_gpt_) w = &gpt_cond_;
     DTTS_REQUIRE(w, "unknown / unbound MelStyleEncoder");
-    ws_.ensure(mel_style_ws(B, w->hidden, w->out, T) + 4096);
+    ws().ensure(mel_style_ws(B, w->hidden, w->out, T) + 4096);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -184,12 +184,12 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
         }
     }
     const size_t buf = (size_t)B * biggest;
-    const size_t mark = ws_.mark();
-    float* X = ws_.f32(buf);
-    float* R[3] = {ws_.f32(buf), ws_.f32(buf), ws_.f32(buf)};
-    float* T1 = ws_.f32(buf);
-    float* T2 = ws_.f32(buf);
-    float* gc = ws_.f32((size_t)B * dec_cond_.CoutP);
+    const size_t mark = ws().mark();
+    float* X = ws().f32(buf);
+    float* R[3] = {ws().f32(buf), ws().f32(buf), ws().f32(buf)};
+    float* T1 = ws().f32(buf);
+    float* T2 = ws().f32(buf);
+    float* gc = ws().f32((size_t)B * dec_cond_.CoutP);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -273,7 +273,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     o.pad = 3;
     o.epi_act = ACT_TANH;
     run_conv(dec_post_, o, s);
-    ws_.rewind(mark);
+    ws().rewind(mark);
 }
 
 static size_t generator_ws(const dtts_config& cfg, int B, int T) {
@@ -288,7 +288,7 @@ static size_t generator_ws(const dtts_config& cfg, int B, int T) {
 
 void Model::op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s) {
     DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
-    ws_.ensure(generator_ws(cfg, B, T) + 8192);
+    ws().ensure(generator_ws(cfg, B, T) + 8192);
     DTTS_CHECK_HIP(hipMemsetAsync(wav, 0, sizeof(float) * (size_t)B * 256 * T, s));
     generator(z, g, lens_host, B, T, wav, s);
 }
@@ -303,38 +303,34 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
     DTTS_REQUIRE(T % 4 == 0, "mel length must be a multiple of 4 (assert y.shape[-1]%4==0, model_24k.py:851)");
     DTTS_REQUIRE(gen_chunk >= 0, "generator chunk");
-    struct ArenaSwap {
-        Arena &a, &b;
-        ArenaSwap(Arena& x, Arena& y) : a(x), b(y) { a.swap(b); }
-        ~ArenaSwap() { a.swap(b); }
-    } use_stage_c_arena(ws_, ws_voc_);
+    ArenaUse use_stage_c_arena(ws_voc_);
     const int HALO = 16, Tg = gen_chunk > 0 ? std::min(T, gen_chunk + 2 * HALO) : T;
     const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
     const int H = cfg.enc_heads, dk = hid / H;
     const size_t a192 = (size_t)B * hid * T;
     const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256;
-    ws_.ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, Tg) + sizeof(float) * (size_t)B * 256 * Tg) + 8192);
+    ws().ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, Tg) + sizeof(float) * (size_t)B * 256 * Tg) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
     const int* sids = upload_ints(sample_ids_host, B, s);
 
-    float* g = ws_.f32((size_t)B * gin);
-    float* x = ws_.f32(a192);
-    float* y = ws_.f32(a192);
-    float* qkv = ws_.f32(3 * a192);
-    float* att = ws_.f32(a192);
-    float* ffn = ws_.f32((size_t)B * filt * T);
-    float* relk = ws_.f32((size_t)B * H * T * 9);
-    float* ml = ws_.f32((size_t)B * H * T * 2);
-    float* stats = ws_.f32(2 * a192);
-    float* Gc = ws_.f32((size_t)B * 2048);
+    float* g = ws().f32((size_t)B * gin);
+    float* x = ws().f32(a192);
+    float* y = ws().f32(a192);
+    float* qkv = ws().f32(3 * a192);
+    float* att = ws().f32(a192);
+    float* ffn = ws().f32((size_t)B * filt * T);
+    float* relk = ws().f32((size_t)B * H * T * 9);
+    float* ml = ws().f32((size_t)B * H * T * 2);
+    float* stats = ws().f32(2 * a192);
+    float* Gc = ws().f32((size_t)B * 2048);
 
     // g = ref_enc(y * y_mask, y_mask)  (:855)
     {
-        const size_t m = ws_.mark();
+        const size_t m = ws().mark();
         mel_style(ref_enc_, mel, dl, l.data(), B, T, g, s);
-        ws_.rewind(m);
+        ws().rewind(m);
     }
     // x = in_proj(y) ; enc_p(x, y_lengths)  (:856-857)
     ConvParams p = cp(mel, cfg.mel_channels, x, inter, B, T, T, dl);
@@ -452,7 +448,7 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
         generator(zc, g, l.data(), B, T, wav, s);
         return;
     }
-    float* tmp = ws_.f32((size_t)B * 256 * Tg);
+    float* tmp = ws().f32((size_t)B * 256 * Tg);
     std::vector<int> lw(B);
     for (int t0 = 0; t0 < T; t0 += gen_chunk) {
         const int t1 = std::min(T, t0 + gen_chunk), a = std::max(0, t0 - HALO), e = std::min(T, t1 + HALO), W = e - a;
@@ -553,12 +549,12 @@ void Model::vq_encode(const float* mel, const int* lens_host, int B, int T, int*
         l1[b] = (l0[b] + 1) / 2;
         l2[b] = (l1[b] + 1) / 2;
     }
-    ws_.ensure(sizeof(float) * ((size_t)B * MC * T + (size_t)B * 2 * inter * T1 + (size_t)2 * B * C * T2 + (size_t)B * 32 * T2) + 65536);
-    float* ln = ws_.f32((size_t)B * MC * T);
-    float* h1 = ws_.f32((size_t)B * 2 * inter * T1);
-    float* h2 = ws_.f32((size_t)B * C * T2);
-    float* xv = xvq_out ? xvq_out : ws_.f32((size_t)B * C * T2);
-    float* x8 = ws_.f32((size_t)B * 32 * T2);
+    ws().ensure(sizeof(float) * ((size_t)B * MC * T + (size_t)B * 2 * inter * T1 + (size_t)2 * B * C * T2 + (size_t)B * 32 * T2) + 65536);
+    float* ln = ws().f32((size_t)B * MC * T);
+    float* h1 = ws().f32((size_t)B * 2 * inter * T1);
+    float* h2 = ws().f32((size_t)B * C * T2);
+    float* xv = xvq_out ? xvq_out : ws().f32((size_t)B * C * T2);
+    float* x8 = ws().f32((size_t)B * 32 * T2);
     const int* d0 = upload_ints(l0.data(), B, s);
     const int* d1 = upload_ints(l1.data(), B, s);
     const int* d2 = upload_ints(l2.data(), B, s);
@@ -606,14 +602,14 @@ void Model::vq_decode(const int* codes_host, const int* ncodes_host, int nmax, c
         n4[b] = 4 * n1[b];
         rl[b] = refer_lens_host ? refer_lens_host[b] : Tr;
     }
-    ws_.ensure(sizeof(float) * ((size_t)2 * B * C * nmax + (size_t)B * 2 * inter * 2 * nmax + (size_t)B * inter * 4 * nmax + (size_t)B * C) +
+    ws().ensure(sizeof(float) * ((size_t)2 * B * C * nmax + (size_t)B * 2 * inter * 2 * nmax + (size_t)B * inter * 4 * nmax + (size_t)B * C) +
                sizeof(int) * (size_t)B * nmax + sizeof(float) * ((size_t)5 * B * 128 * Tr + (size_t)B * C * Tr) + 65536);
-    float* g = ws_.f32((size_t)B * C);
-    float* lat = ws_.f32((size_t)B * C * nmax);
-    float* ln = ws_.f32((size_t)B * C * nmax);
-    float* u1 = ws_.f32((size_t)B * 2 * inter * 2 * nmax);
-    float* u2 = ws_.f32((size_t)B * inter * 4 * nmax);
-    int* dcodes = ws_.i32((size_t)B * nmax);
+    float* g = ws().f32((size_t)B * C);
+    float* lat = ws().f32((size_t)B * C * nmax);
+    float* ln = ws().f32((size_t)B * C * nmax);
+    float* u1 = ws().f32((size_t)B * 2 * inter * 2 * nmax);
+    float* u2 = ws().f32((size_t)B * inter * 4 * nmax);
+    int* dcodes = ws().i32((size_t)B * nmax);
     DTTS_CHECK_HIP(hipMemcpyAsync(dcodes, codes_host, sizeof(int) * (size_t)B * nmax, hipMemcpyHostToDevice, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
     const int* d1 = upload_ints(n1.data(), B, s);
@@ -621,9 +617,9 @@ void Model::vq_decode(const int* codes_host, const int* ncodes_host, int nmax, c
     const int* d4 = upload_ints(n4.data(), B, s);
     const int* drl = upload_ints(rl.data(), B, s);
     {
-        const size_t m = ws_.mark();
+        const size_t m = ws().mark();
         mel_style(vq_ref_enc_, refer, drl, rl.data(), B, Tr, g, s);
-        ws_.rewind(m);
+        ws().rewind(m);
     }
     hipLaunchKernelGGL(vq_gather_kernel, dim3(nmax, B), dim3(256), 0, s, vq_table_, dcodes, nmax, d1, g, C, nmax, lat);
     DTTS_CHECK_HIP(hipGetLastError());

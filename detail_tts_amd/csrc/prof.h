@@ -28,7 +28,8 @@ public:
     }
     bool on = false;
     bool all = false;        // also bracket the bandwidth-only helper kernels (flops == 0); off in bench.py: fewer events
-    bool active_ = false;    // the current ProfScope is being recorded
+    bool gate = true;        // false inside the sampling steps dtts_profile_sampling skips
+    int step_every = 1;
     // events are created here, outside any timed region
     void reserve(size_t n) {
         while (pool_.size() < n) {
@@ -37,13 +38,11 @@ public:
             pool_.push_back(e);
         }
     }
-    // begin / end / collect take the lock: two handles driven from two host threads may record concurrently (each ProfScope's
-    // begin..end pair still has to stay on one thread)
-    void begin(const char* tag, double flops, double bytes, hipStream_t s) {
-        if (!on) { active_ = false; return; }
+    // begin / collect take the lock: a handle may be driven from two host threads (include/detail_hip.h, "Threads"), and two handles
+    // from any.  begin returns the scope's stop event (nullptr: not recorded); each ProfScope lives on one thread.
+    hipEvent_t begin(const char* tag, double flops, double bytes, hipStream_t s) {
+        if (!on || !gate || !(all || flops > 0.0)) return nullptr;
         std::lock_guard<std::mutex> lk(mu_);
-        active_ = on && (all || flops > 0.0);
-        if (!active_) return;
         if (!base_) {
             (void)hipEventCreate(&base_);
             (void)hipEventRecord(base_, s);
@@ -51,11 +50,10 @@ public:
         hipEvent_t a = take(), b = take();
         recs_.push_back({tag, flops, bytes, a, b});
         (void)hipEventRecord(a, s);
+        return b;
     }
-    void end(hipStream_t s) {
-        if (!active_) return;
-        std::lock_guard<std::mutex> lk(mu_);
-        (void)hipEventRecord(recs_.back().stop, s);
+    void end(hipEvent_t stop, hipStream_t s) {
+        if (stop) (void)hipEventRecord(stop, s);
     }
     // synchronises, folds the pending records into the per-tag totals and recycles the events
     void collect() {
@@ -131,8 +129,9 @@ private:
 
 struct ProfScope {
     hipStream_t s;
-    ProfScope(const char* tag, double flops, double bytes, hipStream_t st) : s(st) { Profiler::get().begin(tag, flops, bytes, st); }
-    ~ProfScope() { Profiler::get().end(s); }
+    hipEvent_t stop;
+    ProfScope(const char* tag, double flops, double bytes, hipStream_t st) : s(st), stop(Profiler::get().begin(tag, flops, bytes, st)) {}
+    ~ProfScope() { Profiler::get().end(stop, s); }
 };
 
 }  // namespace dtts

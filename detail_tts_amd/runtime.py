@@ -107,6 +107,10 @@ class Runtime:
         """True / 1: MFMA kernels; 2: also the bandwidth-only helper kernels; False: off"""
         self.lib.dtts_profile_enable(int(on))
 
+    def profile_sampling(self, every=1):
+        """bracket only every n-th sampling step of diff_sample (all its launches); 1 = every step"""
+        self.lib.dtts_profile_sampling(int(every))
+
     def profile_report(self):
         arr = (_lib.DttsKernelStat * 64)()
         n = self.lib.dtts_profile_report(arr, 64)

@@ -6,6 +6,10 @@ would be alone), the noise seed / per-utterance stream ids, and forced codes (pa
 """
 from __future__ import annotations
 
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
@@ -104,6 +108,9 @@ class SynthesizerTrn:
         self.rt.timestep_map = list(self.infer_diffuser.timestep_map)
         self.stage_ms = None          # set to {} to collect per-stage hipEvent timings of the next infer() call
         self._voc_stream = None       # second stream of infer(stream_vocoder=True)
+        self._gpt_stream = None       # high-priority stage-A stream of infer_stream()
+        self._a_pool = None           # ... and its issuing thread
+        self.stream_trace = None      # set to [] to collect the per-request timeline of infer_stream()
         self.vocoder_done = None
 
     def eval(self):
@@ -204,6 +211,141 @@ class SynthesizerTrn:
         if return_lengths:
             return wav, [1024 * v for v in n]
         return wav
+
+    # ------------------------------------------------------------------------------------------------------------
+    def infer_stream(self, requests, noise_scale=NOISE_SCALE, *, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False,
+                     vocoder_chunk=0):
+        """Batch server: `infer(..., batch=True)` over a sequence of request batches, software-pipelined over three HIP streams.
+
+        requests: iterable of dicts with keys text [B,Lt], text_length [B], refer [B,128,Tr], refer_lengths [B] and optionally seed,
+        sample_ids (B <= 8 per request: one decode session).  Yields (wav [B,1,1024*n_max], lengths) per request, in order; every
+        result is bit-identical to `infer(**request, batch=True)` with the same seed and sample ids.
+
+        Stage A of request i+1 (GPT prefill + decode: a chain of short latency-bound kernels that leaves the chip mostly idle) runs
+        on a high-priority stream under stage B of request i (50 diffusion steps: throughput-bound); stage C of request i runs on a
+        third stream under stage B of request i+1.  Stage A is issued from a second host thread; the calling thread blocks only on a decode session's
+        results (the code lengths size the diffusion) and on the waveform it is about to hand out, which is the PREVIOUS request's
+        (one request of lag), so the diffusion stream never drains.  Device tensors handed over in a request must be complete (not pending on another stream):
+        stage A reads them on its own stream."""
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        if self._gpt_stream is None:
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            self._gpt_stream = torch.cuda.Stream(dev, priority=lo if os.environ.get("DTTS_STAGE_A_PRIORITY") == "low" else hi)
+        if self._voc_stream is None:
+            self._voc_stream = torch.cuda.Stream(dev)
+        sa, sc = self._gpt_stream, self._voc_stream
+        trace = self.stream_trace          # a list: per-request host times and stream events (tools/pipeline_trace.py)
+        kw = dict(max_generate_length=max_generate_length, top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
+                  repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
+
+        def launch_a(req):
+            text = torch.as_tensor(req["text"])
+            tl = torch.as_tensor(req["text_length"]).reshape(-1).tolist()
+            rl = [int(v) for v in torch.as_tensor(req["refer_lengths"]).reshape(-1).tolist()]
+            B = text.shape[0]
+            if B > 8:
+                raise ValueError("infer_stream: at most 8 utterances per request (one decode session); split the batch")
+            seed = req.get("seed")
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            sids = list(range(B)) if req.get("sample_ids") is None else list(req["sample_ids"])
+            texts = [text[b, : int(tl[b])].cpu().numpy().astype(np.int32) for b in range(B)]
+            tr = None
+            if trace is not None:
+                tr = dict(host_a0=time.perf_counter(), ev_a0=torch.cuda.Event(enable_timing=True), ev_a1=torch.cuda.Event(enable_timing=True),
+                          ev_b0=torch.cuda.Event(enable_timing=True), ev_b1=torch.cuda.Event(enable_timing=True),
+                          ev_c1=torch.cuda.Event(enable_timing=True))
+                trace.append(tr)
+            with torch.cuda.stream(sa):
+                if tr:
+                    tr["ev_a0"].record(sa)
+                refer = torch.as_tensor(req["refer"]).to(dev, torch.float32).contiguous()
+                self.rt.gpt_prefill(refer, rl, texts, seed, sids, **kw)
+                if suppress_eos:                               # fixed length: the whole decode is enqueued without a host round trip
+                    self.rt.gpt_decode(max_generate_length)
+            if tr:
+                tr["host_a1"] = time.perf_counter()
+            return dict(refer=refer, rl=rl, seed=seed, sids=sids, tr=tr)
+
+        def finish_a(st):
+            with torch.cuda.stream(sa):
+                while self.rt.gpt_steps() < max_generate_length:
+                    if not suppress_eos and self.rt.gpt_all_finished():
+                        break
+                    self.rt.gpt_decode(16)
+                codes, ncodes, lat = self.rt.gpt_finish()          # waits for stream A only
+                n = [int(c) - 1 for c in ncodes]
+                if min(n) < 1:
+                    raise ValueError("an utterance produced no mel codes (stop token first)")
+                st["lat"] = lat[:, :, : max(n)].contiguous()
+                st["n"] = n
+                done = torch.cuda.Event()
+                done.record(sa)
+                if st["tr"]:
+                    st["tr"]["ev_a1"].record(sa)
+                    st["tr"]["host_a2"] = time.perf_counter()
+            st["a_done"] = done
+            return st
+
+        def launch_bc(st):
+            cur.wait_event(st["a_done"])
+            refer, lat, n = st["refer"], st["lat"], st["n"]
+            refer.record_stream(cur)
+            lat.record_stream(cur)
+            tr = st["tr"]
+            if tr:
+                tr["host_b0"] = time.perf_counter()
+                tr["ev_b0"].record(cur)
+            cond = self.rt.diff_conditioning(refer, st["rl"])
+            code_emb = self.rt.diff_timestep_independent(lat, cond, n)
+            lens_t = [4 * v for v in n]
+            mel = self.rt.diff_sample(code_emb, st["seed"], st["sids"], lens=lens_t, denorm=True)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            if tr:
+                tr["ev_b1"].record(cur)
+            with torch.cuda.stream(sc):
+                sc.wait_event(ready)
+                wav = self.rt.vocoder(mel, st["seed"], st["sids"], lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
+                mel.record_stream(sc)
+                self.vocoder_done = torch.cuda.Event()
+                self.vocoder_done.record(sc)
+                if tr:
+                    tr["ev_c1"].record(sc)
+                    tr["host_b1"] = time.perf_counter()
+            wav.record_stream(cur)
+            return wav, [1024 * v for v in n], self.vocoder_done
+
+        # Stage A is issued from its own host thread: a kernel-launch call blocks once its stream's hardware queue is full, so one
+        # thread could not enqueue request i+1's decode (12 K launches) while it is still feeding request i's diffusion (10 K).  The
+        # library supports exactly this split (include/detail_hip.h, "Threads"); ctypes releases the GIL inside the calls.
+        def stage_a(req):
+            torch.cuda.set_device(dev)
+            return finish_a(launch_a(req))
+
+        it = iter(requests)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        if self._a_pool is None:
+            self._a_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dtts-stage-a")
+        fut = self._a_pool.submit(stage_a, first)
+        pending = None
+        while fut is not None:
+            st = fut.result()                   # the only wait on the GPU: this request's codes (their lengths size stage B)
+            try:
+                fut = self._a_pool.submit(stage_a, next(it))     # next request's stage A starts now, under this request's diffusion
+            except StopIteration:
+                fut = None
+            out = launch_bc(st)                 # stage B / C of this request: enqueued, not waited for
+            if pending is not None:
+                pending[2].synchronize()
+                yield pending[0], pending[1]
+            pending = out
+        pending[2].synchronize()
+        yield pending[0], pending[1]
 
     def infer_gpt(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
                   forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False):

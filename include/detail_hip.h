@@ -18,7 +18,14 @@
  * [B, C, T] (channel-major, time contiguous) buffers owned by the caller; `lens`/`sample_ids`
  * arrays are HOST int32 arrays of B entries; all launches are asynchronous on `stream`
  * (a hipStream_t passed as void*), with no hidden synchronisation except when the internal
- * workspace has to grow.  One handle per (device, stream); not thread-safe.
+ * workspace has to grow.
+ *
+ * Threads: one handle per device.  A handle may be driven by TWO host threads at once under this split: one thread issues only the
+ * decode-session calls (dtts_gpt_prefill / _decode_step / _decode / _steps / _all_finished / _finish: stage A, own scratch and state),
+ * the other thread everything else (stages B and C), each on its own streams.  That is how the next request's GPT decode is issued
+ * under this request's diffusion (SynthesizerTrn.infer_stream); the host cannot do it from one thread because a launch call blocks
+ * once the stream's hardware queue is full.  dtts_last_error returns the calling thread's last message.  Any other concurrent use
+ * of one handle is not supported.
  */
 #ifndef DETAIL_HIP_H
 #define DETAIL_HIP_H
@@ -221,15 +228,18 @@ int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int 
  *   "gpt_graph"   (default 0): 1 = dtts_gpt_decode replays captured hipGraphs (16-step chunks); 0 = the same launches issued
  *                 eagerly, 16 steps per call (measured faster on ROCm 7.2: a replayed kernel node costs ~0.8 us more than an eager
  *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
- *   "conv_x3"     (default 1): diffusion-trunk convs and attention on the split-precision path (every fp32 operand as three
- *                 bf16 planes, six bf16 MFMA products per fp32 product, fp32 accumulate: fp32-class error at 1.7-2.3x the fp32
- *                 MFMA rate); 0 = the exact fp32-MFMA kernels. */
+ *   "conv_x3"     (default 1): diffusion-trunk convs and attention on the split-precision path (every fp32 operand as two
+ *                 scaled fp16 planes, three fp16 MFMA products per fp32 product, fp32 accumulate: fp32-GEMM-class error);
+ *                 0 = the exact fp32-MFMA kernels. */
 int dtts_set_option(dtts_handle* h, const char* key, int value);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch hipEvent profiling of the MFMA kernels (conv GEMM, flash attention), recorded on the launch stream.
  * enable(1) resets the totals and brackets the MFMA kernels; enable(2) also the bandwidth-only helpers (GroupNorm / split passes);
- * the events are created at enable time.  report() synchronises and returns the number of entries written. */
+ * the events are created at enable time.  report() synchronises and returns the number of entries written.
+ * sampling(n): inside dtts_diff_sample bracket only the launches of every n-th sampling step (all of them, on every stream, so the
+ * union of the launch intervals keeps its meaning); n = 1 (default) brackets every step.  Launches outside dtts_diff_sample are
+ * always bracketed. */
 typedef struct dtts_kernel_stat {
     char name[64];
     long long launches;
@@ -239,6 +249,7 @@ typedef struct dtts_kernel_stat {
     double bytes;       /* algorithmic bytes (inputs + outputs + weights once) */
 } dtts_kernel_stat;
 int dtts_profile_enable(int on);
+int dtts_profile_sampling(int every);
 int dtts_profile_report(dtts_kernel_stat* out, int max_entries);
 
 /* ---- unit entry points for parity tests ------------------------------------------------------- */

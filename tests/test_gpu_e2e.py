@@ -204,3 +204,26 @@ def test_long_form_batch4_streaming_vocoder(model):
     full = model.dec(z, g=g)
     cat = torch.cat(list(model.dec.stream(z, g, chunk=64)), -1)
     assert float((cat - full).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("suppress_eos", [True, False])
+def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
+    """SynthesizerTrn.infer_stream (stage A of request i + 1 on a high-priority stream under stage B of request i, stage C on a third
+    stream) hands out, in order, exactly the waveforms of one infer() call per request: same codes, same lengths, same samples."""
+    rs = np.random.RandomState(9)
+    reqs = []
+    for i, (B, Tr, Lt) in enumerate([(2, 220, 14), (3, 180, 9), (1, 260, 20), (2, 200, 11)]):
+        refer = torch.from_numpy((rs.randn(B, 128, Tr) * 2 - 5).astype(np.float32))
+        text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, Lt)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+        reqs.append(dict(text=text, text_length=torch.full((B,), Lt + 1), refer=refer, refer_lengths=torch.tensor([Tr - 8 * b for b in range(B)]),
+                         seed=300 + i, sample_ids=[10 * i + b for b in range(B)]))
+    G = 24
+    outs = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos))
+    assert len(outs) == len(reqs)
+    for r, (wav, lens) in zip(reqs, outs):
+        ref, rlens = model.infer(r["text"], r["text_length"], r["refer"], r["refer_lengths"], batch=True, seed=r["seed"],
+                                 sample_ids=r["sample_ids"], max_generate_length=G, suppress_eos=suppress_eos, return_lengths=True)
+        assert lens == rlens
+        assert wav.shape == ref.shape and torch.equal(wav, ref)
+        assert bool(torch.isfinite(wav).all()) and float(wav.pow(2).mean().sqrt()) > 1e-5
+    assert list(model.infer_stream(iter([]))) == []
