@@ -385,6 +385,19 @@ void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, con
     (void)hipMemcpy(Xp, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
     const float os = 1.f / (sw * sx);
     printf("---- %s, M = %d\n", NPL == 3 ? "3 x bf16 planes, 6 products" : "2 x fp16 planes, 3 products", M);
+    if (getenv("UB_SMALL")) {      // under-filled launches (B = 8, M = 768: 240 workgroups of 128 x 192): do smaller tiles pay?
+        for (int rep = 0; rep < 2; ++rep) {
+            run<NPL, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 4 waves (64x96)", os);
+            run<NPL, 2, 2, 2, 2, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x128 4 waves (64x64)", os);
+            run<NPL, 2, 2, 1, 3, 4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "64x192 4 waves (32x96)", os);
+            run<NPL, 2, 1, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x96 2 waves (64x96)", os);
+            run<NPL, 4, 1, 1, 3, 4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x96 4 waves (32x96)", os);
+            run<NPL, 2, 1, 1, 3, 4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "64x96 2 waves (32x96)", os);
+            run<NPL, 1, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "64x192 2 waves (64x96)", os);
+        }
+        (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
+        return;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         if (NPL == 2) { run_pp<3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); run_pp<4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); run_pp<5>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); }
         run<NPL, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 global_load_lds", os);
@@ -400,7 +413,7 @@ void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, con
 }
 
 int main() {
-    const int C = 768, T = 936, B = 16, Tp = 1024 + 2 + 256;
+    const int C = getenv("UB_C") ? atoi(getenv("UB_C")) : 768, T = 936, B = getenv("UB_B") ? atoi(getenv("UB_B")) : 16, Tp = 1024 + 2 + 256;
     for (int M : {768, 2304}) {
         std::vector<float> hw((size_t)M * C), hx((size_t)B * C * T);
         srand(1);
