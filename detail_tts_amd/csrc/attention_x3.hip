@@ -29,15 +29,23 @@ constexpr int VCH = 3 * 2 * 4 * 16;            // V chunks per plane
 constexpr int NPL = XS_PLANES;
 constexpr int BUF_BYTES = NPL * (KCH + VCH) * 16;   // 24 KiB per stage
 constexpr float QK_SCALE = 16.f, P_SHIFT = 10.f, V_SCALE = 16.f;
+constexpr float M_SLACK = 3.f;                      // the running max is raised only when a tile exceeds it by more than 2^3 (P <= 8192)
 constexpr int NBUF = 2;                            // LDS stages (1: single buffer, two barriers per tile, half the LDS)
 
 __device__ __forceinline__ hf8 as_hf(const uint4& q) { return __builtin_bit_cast(hf8, q); }
+__device__ __forceinline__ hf4 as_hf4(const uint2& q) { return __builtin_bit_cast(hf4, q); }
 
 // the three significant cross products, smallest first
 #define DTTS_X3_MFMA(acc, A, Bq)                                                         \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], Bq[0], acc, 0, 0, 0);             \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], Bq[1], acc, 0, 0, 0);             \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], Bq[0], acc, 0, 0, 0);
+
+// channels 32..47: one 16-channel MFMA (4 halfs per lane: the (g & 1) half of chunk 4 + (g >> 1))
+#define DTTS_X3_MFMA16(acc, A, Bq)                                                       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A[1], Bq[0], acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A[0], Bq[1], acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A[0], Bq[0], acc, 0, 0, 0);
 
 // 512 threads = 8 waves x 16 queries: <= 128 VGPRs -> 2 workgroups (16 waves) per CU share each staged K/V tile 8 ways
 // PLANES: q / k / v arrive as AttnPlanes operand images written by the qkv conv (attention.h): Q fragments are plain 16-byte loads,
@@ -70,39 +78,37 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     // ---- Q fragments: B operand, lane (query j, g) holds channels kb*32 + 8g .. +7 of each plane, pre-scaled by scale*log2(e)*16
     const int tq0 = q0 + wave * QPW;
     const float qs = p.scale * LOG2E * QK_SCALE;
-    hf8 qf[2][NPL];
+    hf8 qf0[NPL], qf1[NPL];           // channels 8g .. 8g+7 and 32 + 8g .. +7 (zero beyond channel 47)
     if (PLANES) {
         const int t = tq0 + j, tc = t < Tq ? t : Tq - 1;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int c8 = kb * 4 + g;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                uint4 w = make_uint4(0, 0, 0, 0);
-                if (c8 < D / 8) w = *reinterpret_cast<const uint4*>(himg + ((size_t)(pl * (D / 8) + c8) * Tq + tc) * 16);
-                qf[kb][pl] = as_hf(w);
-            }
+        for (int pl = 0; pl < NPL; ++pl) {
+            qf0[pl] = as_hf(*reinterpret_cast<const uint4*>(himg + ((size_t)(pl * (D / 8) + g) * Tq + tc) * 16));
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (g < 2) w = *reinterpret_cast<const uint4*>(himg + ((size_t)(pl * (D / 8) + 4 + g) * Tq + tc) * 16);
+            qf1[pl] = as_hf(w);
         }
     } else {
         const int t = tq0 + j;
         const int tc = t < len ? t : len - 1;
+        float v[8];
+        uint4 w0, w1;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float v[8];
-            const int c0 = kb * 32 + 8 * g;
+        for (int e = 0; e < 8; ++e) v[e] = qp[(long long)(8 * g + e) * p.cs + tc] * qs;
+        split8(v, w0, w1);
+        qf0[0] = as_hf(w0);
+        qf0[1] = as_hf(w1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (c0 < D) ? qp[(long long)(c0 + e < D ? c0 + e : 0) * p.cs + tc] * qs : 0.f;
-            uint4 w0, w1;
-            split8(v, w0, w1);
-            qf[kb][0] = as_hf(w0);
-            qf[kb][1] = as_hf(w1);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = g < 2 ? qp[(long long)(32 + 8 * g + e) * p.cs + tc] * qs : 0.f;
+        split8(v, w0, w1);
+        qf1[0] = as_hf(w0);
+        qf1[1] = as_hf(w1);
     }
 
     floatx4 oacc[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) oacc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY;
     const int ntiles = (len + KT - 1) / KT;
     const bool wave_active = tq0 < len;
 
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     // A-operand chunk column of this lane for the two channel blocks: kb 0 -> c8 = g; kb 1 -> c8 = 4 + (g & 1) (lanes g >= 2 meet
     // zero Q channels 48..63, any finite chunk will do)
     const int kcol0 = g * KT + j, kcol1 = (4 + (g & 1)) * KT + j;
+    float l_lane = 0.f;             // this lane's share of the denominator (its 16 keys of every tile); combined over g at the end
 
     for (int kt = 0; kt < ntiles; ++kt) {
         const int s0 = kt * KT, buf = NBUF == 2 ? (kt & 1) : 0;
@@ -205,22 +212,22 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                 hf8 a[NPL];
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) a[pl] = as_hf(Kb[pl * KCH + kcol0 + ks * 16]);
-                DTTS_X3_MFMA(sacc[ks], a, qf[0])
+                DTTS_X3_MFMA(sacc[ks], a, qf0)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) a[pl] = as_hf(Kb[pl * KCH + kcol1 + ks * 16]);
-                DTTS_X3_MFMA(sacc[ks], a, qf[1])
+                DTTS_X3_MFMA(sacc[ks], a, qf1)
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                // exponent arguments e = s + bias (log2 domain) of this lane's 8 keys, and their maximum
                 float mx = -INFINITY;
                 if (far) {
+                    float r = -INFINITY;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            sacc[2 * u + q][r] = fmaf(sacc[2 * u + q][r], SU, bfar);
-                            mx = fmaxf(mx, sacc[2 * u + q][r]);
-                        }
+                        for (int i = 0; i < 4; ++i) r = fmaxf(r, sacc[2 * u + q][i]);
+                    mx = fmaf(r, SU, bfar);                              // SU > 0: the maximum commutes with the affine map
                 } else {
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
@@ -235,32 +242,40 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                             mx = fmaxf(mx, v);
                         }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run, mx);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-                const float m_sub = m_use - P_SHIFT;
-                float sum = 0.f;
+                // Lazy running maximum: raise it (exchange over the query's 4 lanes, rescale O and l) only when some query of this wave
+                // sees a tile maximum more than 2^M_SLACK above it - rare after the first tiles; otherwise P = exp2(e - m + 10) <= 8192
+                // stays far inside fp16's range and nothing needs rescaling.
+                if (__builtin_amdgcn_ballot_w64(mx > m_run + M_SLACK) != 0ull) {
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    // per query: a query's sequence of maxima depends on its own scores only, never on its wave neighbours' (which
+                    // may be padding) - results stay invariant to batch composition and to whatever the padded rows hold
+                    const float m_new = (mx > m_run + M_SLACK) ? mx : m_run;
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+                    l_lane *= alpha;
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) oacc[ct] *= alpha;
+                    m_run = m_new;
+                }
+                const float m_sub = ((m_run == -INFINITY) ? 0.f : m_run) - P_SHIFT;
                 float pv[8];
+                if (far) {
+                    const float c0 = bfar - m_sub;
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(sacc[2 * u + q][r] - m_sub);      // 1024 P: the scale is free in the exponent
-                        pv[q * 4 + r] = e;
-                        sum += e;
-                    }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                l_run = l_run * alpha + sum;
-                m_run = m_new;
+                        for (int r = 0; r < 4; ++r) pv[q * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * u + q][r], SU, c0));   // 1024 P: the scale is free
+                } else {
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) oacc[ct] *= alpha;
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[q * 4 + r] = __builtin_amdgcn_exp2f(sacc[2 * u + q][r] - m_sub);
+                }
+                l_lane += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
                 hf8 pf[NPL];
                 {
                     uint4 w0, w1;
-                    split8(pv, w0, w1);
+                    split8_inrange(pv, w0, w1);
                     pf[0] = as_hf(w0);
                     pf[1] = as_hf(w1);
                 }
@@ -283,6 +298,9 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     }
 
     if (!wave_active) return;
+    float l_run = l_lane;
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
     const int t = tq0 + j;
     if (t >= len) return;
     const float inv = 1.f / (l_run * V_SCALE);          // acc = (1024 P)(16 V), l_run = sum of 1024 P

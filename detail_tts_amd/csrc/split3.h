@@ -7,6 +7,7 @@ namespace dtts {
 
 typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XS_PLANES = 2;
@@ -24,6 +25,21 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsig
     const hf2 p1 = __builtin_convertvector(r1, hf2);
     w0 = __builtin_bit_cast(unsigned, p0);
     w1 = __builtin_bit_cast(unsigned, p1);
+}
+// the same for values known to lie inside fp16's range (softmax numerators): no clamp
+__device__ __forceinline__ void split_pair_inrange(float x, float y, unsigned& w0, unsigned& w1) {
+    const f32x2 v = {x, y};
+    const hf2 p0 = __builtin_convertvector(v, hf2);
+    const f32x2 r1 = v - __builtin_convertvector(p0, f32x2);
+    const hf2 p1 = __builtin_convertvector(r1, hf2);
+    w0 = __builtin_bit_cast(unsigned, p0);
+    w1 = __builtin_bit_cast(unsigned, p1);
+}
+__device__ __forceinline__ void split8_inrange(const float* v, uint4& q0, uint4& q1) {
+    split_pair_inrange(v[0], v[1], q0.x, q1.x);
+    split_pair_inrange(v[2], v[3], q0.y, q1.y);
+    split_pair_inrange(v[4], v[5], q0.z, q1.z);
+    split_pair_inrange(v[6], v[7], q0.w, q1.w);
 }
 // v[0..7] (already scaled) -> one 16-byte chunk per plane
 __device__ __forceinline__ void split8(const float* v, uint4& q0, uint4& q1) {
