@@ -167,6 +167,89 @@ __global__ __launch_bounds__(1024) void gn_split_planes_kernel(const float* __re
     }
 }
 
+// The same with the slab held in REGISTERS between the two phases (one HBM read): thread <-> NI (8-channel chunk, column) items of the
+// output, loaded as 8 row-strided floats each (a wave reads 256 contiguous bytes per row), reduced, then normalised and split where
+// they sit.  Covers cpg/8 x Tp <= NI x 1024 items (T <= 1022 at cpg = 24); longer sequences take the two-pass kernel above.
+template <int ACT, int NI>
+__global__ __launch_bounds__(1024) void gn_split_planes_reg_kernel(const float* __restrict__ x, long long x_bs, int x_cs,
+                                                                  const int* __restrict__ lens, int T, int C, int groups,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                  const float* __restrict__ ada, int ada_stride, int ada_bs, int Tp,
+                                                                  uint4* __restrict__ out, const int* __restrict__ ada_idx) {
+    __shared__ float red[2][16];
+    __shared__ float sa[64], sd[64];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = lens ? lens[b] : T;
+    const int cpg = C / groups, c8n = cpg >> 3, C8 = C >> 3, nitems = c8n * Tp;
+    const float* xg = x + (long long)b * x_bs + (long long)(g * cpg) * x_cs;
+    const float k = xg[0];
+    float v[NI][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int item = tid + q * 1024, c8l = item / Tp, t = item - c8l * Tp - X3_HALO;
+        const bool ok = item < nitems && t >= 0 && t < len;
+        const float* xr = xg + (long long)(ok ? c8l * 8 : 0) * x_cs + (ok ? t : 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][e] = xr[(long long)e * x_cs];
+        if (ok) {
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = v[q][e] - k;
+            s1 += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+            s2 += ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) + ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S1 += red[0][i]; S2 += red[1][i]; }
+    const float n = (float)(cpg * len);
+    S1 /= n;
+    S2 /= n;
+    const float mean = k + S1, var = fmaxf(S2 - S1 * S1, 0.f), rstd = rsqrtf(var + eps);
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        float a = rstd * gamma[c];
+        float d = beta[c] - mean * a;
+        if (ada) {
+            const float* ad = ada + (ada_idx ? (long long)ada_idx[b] : (long long)b * ada_bs);
+            const float sc = 1.f + ad[(long long)c * ada_stride], sh = ad[(long long)(C + c) * ada_stride];
+            a *= sc;
+            d = d * sc + sh;
+        }
+        sa[tid] = a;
+        sd[tid] = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int item = tid + q * 1024;
+        if (item >= nitems) continue;
+        const int c8l = item / Tp, tp = item - c8l * Tp, t = tp - X3_HALO;
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+        if (t >= 0 && t < len) {
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                w[e] = sa[c8l * 8 + e] * v[q][e] + sd[c8l * 8 + e];
+                if (ACT == ACT_SILU) w[e] = w[e] * __frcp_rn(1.f + __expf(-w[e]));
+                w[e] *= XS_SCALE_X;
+            }
+            split8(w, q0, q1);
+        }
+        uint4* o = out + ((long long)(b * C8 + g * c8n + c8l) * NPL) * Tp + tp;
+        o[0] = q0;
+        o[Tp] = q1;
+    }
+}
+
 // EPI 0: bias (+ residual); 1: + activation / out_scale.   KW3: three taps (else one).  NSTG: LDS stages (2: every K-step waits for
 // the loads issued during the previous one; 3: loads run two steps ahead and the wait is a counted vmcnt).
 // K loop order is (16-channel block, tap): the X tile of a channel block carries its halo (192 + KW - 1 columns) and is fetched
@@ -431,9 +514,21 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
     DTTS_REQUIRE(act == ACT_NONE || act == ACT_SILU, "gn_split_planes: activation");
     const int Tp = x3_tp(T);
     uint4* o = static_cast<uint4*>(out);
-    ProfScope ps("gn_split_planes_kernel", 0.0, (double)B * C * T * 12.0, s);
+    ProfScope ps("gn_split_planes_kernel", 0.0, (double)B * C * T * 8.0, s);      // fp32 in, two fp16 planes out
     static const int ns = []() { const char* v = getenv("DTTS_GN_SPLIT_NS"); return v ? atoi(v) : 1; }();
     static const int nt = []() { const char* v = getenv("DTTS_GN_SPLIT_NT"); return v ? atoi(v) : 1024; }();
+    static const bool reg_ok = []() { const char* v = getenv("DTTS_GN_SPLIT_REG"); return !(v && v[0] == '0'); }();
+    constexpr int NI = 3;
+    if (reg_ok && ns == 1 && (C / groups / 8) * Tp <= NI * 1024) {          // the slab fits the workgroup's registers: one HBM read
+        if (act == ACT_SILU)
+            hipLaunchKernelGGL((gn_split_planes_reg_kernel<ACT_SILU, NI>), dim3(groups, B), dim3(1024), 0, s, x, x_bs, x_cs, lens, T, C, groups,
+                               gamma, beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);
+        else
+            hipLaunchKernelGGL((gn_split_planes_reg_kernel<ACT_NONE, NI>), dim3(groups, B), dim3(1024), 0, s, x, x_bs, x_cs, lens, T, C, groups,
+                               gamma, beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);
+        DTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     if (act == ACT_SILU)
         hipLaunchKernelGGL(gn_split_planes_kernel<ACT_SILU>, dim3(groups, B, ns), dim3(nt), 0, s, x, x_bs, x_cs, lens, T, C, groups, gamma,
                            beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);

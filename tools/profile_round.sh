@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 1500 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 DB=$(find /tmp/${TAG}_stats -name '*.db' | head -1)
-python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_bench_kernel_stats.txt "${TAG}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline (the driver's command; 27 passes: 5 warm-up, 1 stage-timing, 20 timed, + 1 vocoder-only pass under the event profiler; batch 8; the cond / uncond halves of every diffusion forward run on two HIP streams, so launch durations include time shared with the other stream's kernels)"
+python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_bench_kernel_stats.txt "${TAG}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline (the driver's command; 27 passes: 5 warm-up, 1 stage-timing, 20 timed, + 1 vocoder-only pass under the event profiler; batch 8; the timed passes are software-pipelined (stage A of batch i + 1 and stage C of batch i run under stage B of batch i + 1 / i on their own streams) and the cond / uncond halves of every diffusion forward run on two HIP streams, so launch durations include time shared with co-running kernels)"
 rm -rf /tmp/${TAG}_stats
 export BB=8
 for c in FETCH_SIZE WRITE_SIZE; do
