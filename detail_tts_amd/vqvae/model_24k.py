@@ -218,7 +218,7 @@ class SynthesizerTrn:
         """Batch server: `infer(..., batch=True)` over a sequence of request batches, software-pipelined over three HIP streams.
 
         requests: iterable of dicts with keys text [B,Lt], text_length [B], refer [B,128,Tr], refer_lengths [B] and optionally seed,
-        sample_ids (B <= 8 per request: one decode session).  Yields (wav [B,1,1024*n_max], lengths) per request, in order; every
+        sample_ids (any B; up to 8 utterances share one decode session).  Yields (wav [B,1,1024*n_max], lengths) per request, in order; every
         result is bit-identical to `infer(**request, batch=True)` with the same seed and sample ids.
 
         Stage A of request i+1 (GPT prefill + decode: a chain of short latency-bound kernels that leaves the chip mostly idle) runs
@@ -244,8 +244,6 @@ class SynthesizerTrn:
             tl = torch.as_tensor(req["text_length"]).reshape(-1).tolist()
             rl = [int(v) for v in torch.as_tensor(req["refer_lengths"]).reshape(-1).tolist()]
             B = text.shape[0]
-            if B > 8:
-                raise ValueError("infer_stream: at most 8 utterances per request (one decode session); split the batch")
             seed = req.get("seed")
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
@@ -261,20 +259,27 @@ class SynthesizerTrn:
                 if tr:
                     tr["ev_a0"].record(sa)
                 refer = torch.as_tensor(req["refer"]).to(dev, torch.float32).contiguous()
-                self.rt.gpt_prefill(refer, rl, texts, seed, sids, **kw)
-                if suppress_eos:                               # fixed length: the whole decode is enqueued without a host round trip
-                    self.rt.gpt_decode(max_generate_length)
+                gen = None
+                if B <= 8:
+                    self.rt.gpt_prefill(refer, rl, texts, seed, sids, **kw)
+                    if suppress_eos:                           # fixed length: the whole decode is enqueued without a host round trip
+                        self.rt.gpt_decode(max_generate_length)
+                else:                                          # more than one decode session: group after group, on this thread / stream
+                    gen = self.rt.gpt_generate(refer, rl, texts, seed, sids, **kw)
             if tr:
                 tr["host_a1"] = time.perf_counter()
-            return dict(refer=refer, rl=rl, seed=seed, sids=sids, tr=tr)
+            return dict(refer=refer, rl=rl, seed=seed, sids=sids, tr=tr, gen=gen)
 
         def finish_a(st):
             with torch.cuda.stream(sa):
-                while self.rt.gpt_steps() < max_generate_length:
-                    if not suppress_eos and self.rt.gpt_all_finished():
-                        break
-                    self.rt.gpt_decode(16)
-                codes, ncodes, lat = self.rt.gpt_finish()          # waits for stream A only
+                if st["gen"] is not None:
+                    codes, ncodes, lat = st.pop("gen")
+                else:
+                    while self.rt.gpt_steps() < max_generate_length:
+                        if not suppress_eos and self.rt.gpt_all_finished():
+                            break
+                        self.rt.gpt_decode(16)
+                    codes, ncodes, lat = self.rt.gpt_finish()      # waits for stream A only
                 n = [int(c) - 1 for c in ncodes]
                 if min(n) < 1:
                     raise ValueError("an utterance produced no mel codes (stop token first)")
