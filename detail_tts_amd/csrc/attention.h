@@ -34,10 +34,11 @@ struct AttnParams {
 // LDS-DMA / direct fragment loads - no staging arithmetic in the attention kernel.  16-byte chunks of 8 fp16; two planes (split3.h);
 // Q carries scale * log2(e) * 16, K and V carry 16.  Per (sample, head):
 //   Q  [plane 2][c8 6][Tq]            chunk = 8 channels of one query
-//   KV [tile][ K: plane 2 x (c8 6 x key 64) | V: plane 2 x (ct 3 x u 2 x g 4 x c16 16) ]   = the kernel's 24 KiB LDS stage image;
-//      V chunk (ct, u, g, c16) = keys {4g..4g+3, 16+4g..16+4g+3} + 32u of channel 16 ct + c16; keys >= len hold zeros
+//   KV [tile][ K: plane 2 x (c8 6 x key 64) | V: plane 2 x (u 2 x j 2 x hh 2 x channel 48) ]   = the kernel's 24 KiB LDS stage image;
+//      V chunk (u, j, hh, c) = keys 32 u + 16 j + 4 hh + {0..3, 8..11} of channel c - the order in which a lane of the 32 x 32 score
+//      tile (rows (r & 3) + 8 (r >> 2) + 4 hh) holds its keys, so P feeds the PV product from registers; keys >= len hold zeros
 struct AttnPlanes {
-    static constexpr int D = 48, KT = 64, TILE_BYTES = 2 * (6 * 64 + 3 * 2 * 4 * 16) * 16;      // 24576
+    static constexpr int D = 48, KT = 64, TILE_BYTES = 2 * (6 * 64 + 8 * 48) * 16;      // 24576
     __host__ __device__ static inline int tq(int T) { return (T + KT - 1) / KT * KT; }
     __host__ __device__ static inline int nt64(int T) { return (T + KT - 1) / KT; }
     __host__ __device__ static inline size_t q_bytes(int T) { return (size_t)2 * 6 * tq(T) * 16; }
@@ -46,7 +47,8 @@ struct AttnPlanes {
 };
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream);
-void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3
+void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3 (fp32 q, k, v)
+void launch_flash_attention_x3w(const AttnParams& p, hipStream_t stream);  // ... when the operands are AttnPlanes images
 
 // VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)
 //   relk[b,h,t,r] = scale * sum_c q[c,t] * Ek[r][c]

@@ -264,7 +264,8 @@ void launch_flash_attention(const AttnParams& p, hipStream_t stream) {
     const double pairs = (double)p.B * p.H * (double)p.T * p.T * (p.causal ? 0.5 : 1.0);
     if (p.x3 && p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out) {
         ProfScope ps3("flash_attn_x3_kernel<48>", 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
-        launch_flash_attention_x3(p, stream);
+        if (p.planes) launch_flash_attention_x3w(p, stream);
+        else launch_flash_attention_x3(p, stream);
         return;
     }
     DTTS_REQUIRE(!p.out_x3, "split-precision attention output needs the x3 kernel (head dim 48, T5 bias)");

@@ -41,16 +41,9 @@ __device__ __forceinline__ hf4 as_hf4(const uint2& q) { return __builtin_bit_cas
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], Bq[1], acc, 0, 0, 0);             \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], Bq[0], acc, 0, 0, 0);
 
-// channels 32..47: one 16-channel MFMA (4 halfs per lane: the (g & 1) half of chunk 4 + (g >> 1))
-#define DTTS_X3_MFMA16(acc, A, Bq)                                                       \
-    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A[1], Bq[0], acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A[0], Bq[1], acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A[0], Bq[0], acc, 0, 0, 0);
-
 // 512 threads = 8 waves x 16 queries: <= 128 VGPRs -> 2 workgroups (16 waves) per CU share each staged K/V tile 8 ways
-// PLANES: q / k / v arrive as AttnPlanes operand images written by the qkv conv (attention.h): Q fragments are plain 16-byte loads,
-// K / V tiles are the 24 KiB LDS stage image, moved by LDS-DMA (3 x 1 KiB pieces per wave and tile) - no staging arithmetic.
-template <bool PLANES>
+// This kernel takes fp32 q / k / v and splits them while staging (unit entry points, DTTS_ATTN_PLANES=0); the trunk's default path
+// hands over AttnPlanes operand images and runs attention_x3w.hip.
 __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams p) {
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,29 +59,17 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     const int q0 = qb * QPB;
     if (q0 >= len) return;
 
-    const float* base = PLANES ? nullptr : p.qkv + (long long)b * p.bs;
-    const float* qp = PLANES ? nullptr : base + (long long)(p.q_off + h * p.head_stride) * p.cs;
-    const float* kp = PLANES ? nullptr : base + (long long)(p.k_off + h * p.head_stride) * p.cs;
-    const float* vp = PLANES ? nullptr : base + (long long)(p.v_off + h * p.head_stride) * p.cs;
-    const int Tq = AttnPlanes::tq(p.T);
-    const unsigned char* himg = PLANES ? static_cast<const unsigned char*>(p.planes) + ((size_t)b * p.H + h) * AttnPlanes::head_bytes(p.T) : nullptr;
-    const unsigned char* kvimg = PLANES ? himg + AttnPlanes::q_bytes(p.T) : nullptr;
+    const float* base = p.qkv + (long long)b * p.bs;
+    const float* qp = base + (long long)(p.q_off + h * p.head_stride) * p.cs;
+    const float* kp = base + (long long)(p.k_off + h * p.head_stride) * p.cs;
+    const float* vp = base + (long long)(p.v_off + h * p.head_stride) * p.cs;
     if (tid < 2 * BIAS_CLIP + 1) bias_s[tid] = p.bias_tab[h * (2 * BIAS_CLIP + 1) + tid] * LOG2E;
 
     // ---- Q fragments: B operand, lane (query j, g) holds channels kb*32 + 8g .. +7 of each plane, pre-scaled by scale*log2(e)*16
     const int tq0 = q0 + wave * QPW;
     const float qs = p.scale * LOG2E * QK_SCALE;
     hf8 qf0[NPL], qf1[NPL];           // channels 8g .. 8g+7 and 32 + 8g .. +7 (zero beyond channel 47)
-    if (PLANES) {
-        const int t = tq0 + j, tc = t < Tq ? t : Tq - 1;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            qf0[pl] = as_hf(*reinterpret_cast<const uint4*>(himg + ((size_t)(pl * (D / 8) + g) * Tq + tc) * 16));
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (g < 2) w = *reinterpret_cast<const uint4*>(himg + ((size_t)(pl * (D / 8) + 4 + g) * Tq + tc) * 16);
-            qf1[pl] = as_hf(w);
-        }
-    } else {
+    {
         const int t = tq0 + j;
         const int tc = t < len ? t : len - 1;
         float v[8];
@@ -163,22 +144,8 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
             vd[0 * VCH + vidx] = w0; vd[1 * VCH + vidx] = w1;
         }
     };
-    // LDS-DMA of one tile image: piece i of 24 (1 KiB): waves take pieces wave, wave + 8, wave + 16
-    auto dma_tile = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int piece = wave + 8 * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kvimg + (size_t)kt * AttnPlanes::TILE_BYTES + piece * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * BUF_BYTES + piece * 1024), 16, 0, 0);
-        }
-    };
-    if (PLANES) {
-        dma_tile(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        load_tile(0);
-        store_tile(0);
-    }
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
 
     // A-operand chunk column of this lane for the two channel blocks: kb 0 -> c8 = g; kb 1 -> c8 = 4 + (g & 1) (lanes g >= 2 meet
@@ -189,10 +156,7 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
     for (int kt = 0; kt < ntiles; ++kt) {
         const int s0 = kt * KT, buf = NBUF == 2 ? (kt & 1) : 0;
         const bool has_next = kt + 1 < ntiles;
-        if (has_next) {
-            if (PLANES) dma_tile(kt + 1, NBUF == 2 ? (buf ^ 1) : 0);
-            else load_tile(kt + 1);
-        }
+        if (has_next) load_tile(kt + 1);
         if (wave_active) {
             const uint4* Kb = reinterpret_cast<const uint4*>(smem + buf * BUF_BYTES);
             const uint4* Vb = Kb + NPL * KCH;
@@ -288,12 +252,8 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
                 }
             }
         }
-        if (PLANES) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (this wave's pieces; the barrier covers the others')
-        } else {
-            if (NBUF == 1) __syncthreads();             // everyone is done reading the tile before it is overwritten
-            if (has_next) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
-        }
+        if (NBUF == 1) __syncthreads();                 // everyone is done reading the tile before it is overwritten
+        if (has_next) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -329,19 +289,15 @@ __global__ __launch_bounds__(512, 4) void flash_attn_x3_kernel(const AttnParams 
 }  // namespace
 
 void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream) {
-    DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out, "attention_x3 covers head dim 48 with the T5 bias only");
-    static_assert(NBUF == 2, "the LDS-DMA staging refills the other buffer while this one is read");
-    static_assert(BUF_BYTES == AttnPlanes::TILE_BYTES, "the K/V tile image is the LDS stage image");
+    DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out && !p.planes, "attention_x3 covers head dim 48 with the T5 bias, fp32 operands");
     constexpr size_t lds = NBUF * BUF_BYTES + sizeof(float) * (2 * BIAS_CLIP + 1);
     static bool attr = false;
     if (!attr) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const dim3 grid(cdiv(p.T, QPB) * p.H * p.B);
-    if (p.planes) hipLaunchKernelGGL(flash_attn_x3_kernel<true>, grid, dim3(NW * 64), lds, stream, p);
-    else hipLaunchKernelGGL(flash_attn_x3_kernel<false>, grid, dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL(flash_attn_x3_kernel, grid, dim3(NW * 64), lds, stream, p);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -441,9 +441,10 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
                         unsigned w0[2], w1[2];
                         split_pair(t[0], t[1], w0[0], w1[0]);
                         split_pair(t[2], t[3], w0[1], w1[1]);
-                        const int ch = c + q4, kb = n - q4, k64 = kb & 63, u = k64 >> 5, k32 = k64 & 31;
-                        const int chunk = (((ch >> 4) * 2 + u) * 4 + ((k32 & 15) >> 2)) * 16 + (ch & 15);
-                        unsigned char* o = hp + qb + (size_t)(kb >> 6) * (2 * (6 * KT + 384) * 16) + (size_t)2 * 6 * KT * 16 + (size_t)chunk * 16 + (k32 >> 4) * 8;
+                        // V chunk (key block u, key step j, half hh, channel): keys 32 u + 16 j + 4 hh + {0..3} | + 8 + {0..3} (attention.h)
+                        const int ch = c + q4, kb = n - q4, k64 = kb & 63, u = k64 >> 5, j16 = (k64 >> 4) & 1, grp = (k64 & 15) >> 2;
+                        const int chunk = ((u * 2 + j16) * 2 + (grp & 1)) * D + ch;
+                        unsigned char* o = hp + qb + (size_t)(kb >> 6) * (2 * (6 * KT + 384) * 16) + (size_t)2 * 6 * KT * 16 + (size_t)chunk * 16 + (grp >> 1) * 8;
                         *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
                         *reinterpret_cast<uint2*>(o + 384 * 16) = make_uint2(w1[0], w1[1]);
                     }

@@ -26,14 +26,15 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsig
     w0 = __builtin_bit_cast(unsigned, p0);
     w1 = __builtin_bit_cast(unsigned, p1);
 }
-// the same for values known to lie inside fp16's range (softmax numerators): no clamp
+// the same for values known to lie inside fp16's range (softmax numerators): no clamp, and the residual as ONE mixed-precision fma
+// per element (v_fma_mix_f32 reads the fp16 half in place: x - float(h) without converting back; the compiler does not select it)
 __device__ __forceinline__ void split_pair_inrange(float x, float y, unsigned& w0, unsigned& w1) {
     const f32x2 v = {x, y};
-    const hf2 p0 = __builtin_convertvector(v, hf2);
-    const f32x2 r1 = v - __builtin_convertvector(p0, f32x2);
-    const hf2 p1 = __builtin_convertvector(r1, hf2);
-    w0 = __builtin_bit_cast(unsigned, p0);
-    w1 = __builtin_bit_cast(unsigned, p1);
+    w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, hf2));
+    f32x2 r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r1[0]) : "v"(w0), "v"(x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1[1]) : "v"(w0), "v"(y));
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, hf2));
 }
 __device__ __forceinline__ void split8_inrange(const float* v, uint4& q0, uint4& q1) {
     split_pair_inrange(v[0], v[1], q0.x, q1.x);

@@ -44,6 +44,61 @@ __global__ __launch_bounds__(256) void peak(const uint4* __restrict__ ops, float
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Do the matrix and the vector pipe overlap, or does the chip run at constant power?  Workgroups of 512 threads: waves 0-3 (one per SIMD)
+// run the 32x32x16 f16 MFMA loop, waves 4-7 (MODE 1) a loop of independent v_fma_f32 (MODE 2: v_exp_f32), MODE 0: they exit at once.
+template <int MODE>
+__global__ __launch_bounds__(512) void mixed(const uint4* __restrict__ ops, float* out, int iters) {
+    const int wave = threadIdx.x >> 6;
+    const uint4 ua = ops[threadIdx.x & 255], ub = ops[256 + (threadIdx.x & 255)];
+    if (wave < 4) {
+        f16v acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, ua), __builtin_bit_cast(hf8, ub), acc[i], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][r];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
+    } else if (MODE) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(float, ua.x) * (i + 1) * 1e-3f;
+        const float c = 1.0001f, d = 1e-7f;
+        // 4 MFMAs of 8 passes = 128 cycles per outer iteration of the MFMA waves; 32 VALU ops (4 cycles each) fill the same time
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < (MODE == 3 ? 1 : 2); ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = MODE == 2 ? __builtin_amdgcn_exp2f(v[i]) : __builtin_fmaf(v[i], c, d);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += v[i];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
+    }
+}
+
+template <int MODE>
+void run_mixed(const uint4* ops, float* out, const char* name) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    const int iters = 400000;
+    hipLaunchKernelGGL(mixed<MODE>, dim3(256), dim3(512), 0, 0, ops, out, 200);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(mixed<MODE>, dim3(256), dim3(512), 0, 0, ops, out, iters);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    const double fl = 2.0 * 32 * 32 * 16 * 4 * (double)iters * 256 * 4;
+    printf("mixed: 1 MFMA wave/SIMD + %-28s %7.1f ms   MFMA rate %7.1f TFLOP/s\n", name, ms, fl / (ms * 1e-3) / 1e12);
+}
+
 template <int KIND, int NACC>
 void sweep(const char* name, const uint4* ops, float* out, const char* data) {
     const double flop_per = KIND == 2 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 16;
@@ -66,7 +121,7 @@ void sweep(const char* name, const uint4* ops, float* out, const char* data) {
 
 int main() {
     uint4* ops; float* out;
-    (void)hipMalloc(&ops, 512 * 16); (void)hipMalloc(&out, 256 * 4 * 1024 * 4);
+    (void)hipMalloc(&ops, 512 * 16); (void)hipMalloc(&out, 256 * 4 * 1024 * 4 * 2);
     for (int pass = 0; pass < 2; ++pass) {
         std::vector<unsigned short> h(512 * 8);
         srand(3);
@@ -80,6 +135,11 @@ int main() {
         sweep<0, 4>("32x32x16 f16", ops, out, data);
         sweep<1, 4>("32x32x16 bf16", ops, out, data);
         sweep<2, 8>("16x16x32 f16", ops, out, data);
+        printf("operands: %s\n", data);
+        run_mixed<0>(ops, out, "nothing");
+        run_mixed<1>(ops, out, "1 v_fma_f32 wave/SIMD");
+        run_mixed<3>(ops, out, "1 v_fma_f32 wave/SIMD, half");
+        run_mixed<2>(ops, out, "1 v_exp_f32 wave/SIMD");
     }
     return 0;
 }
