@@ -546,7 +546,13 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
     DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
-    static const int nstg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 2; return n == 3 ? 3 : 2; }();
+    // LDS stages: three (loads two K-steps ahead, counted vmcnt, 61 KiB -> 2 workgroups per CU) for launches of at most
+    // DTTS_CONV_STAGES3_MAXWG (600) workgroups, where each workgroup's own dependency chain DMA -> barrier -> fragment reads -> MFMA is exposed;
+    // two (41 KiB -> 3 per CU) for launches that fill the chip several times over.  DTTS_CONV_STAGES = 2 / 3 forces one.
+    static const int force_stg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 0; return n == 3 ? 3 : (n == 2 ? 2 : 0); }();
+    static const long long max3 = []() { const char* v = getenv("DTTS_CONV_STAGES3_MAXWG"); return v ? atoll(v) : 600LL; }();
+    const long long nwg = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
+    const int nstg = force_stg ? force_stg : (nwg <= max3 ? 3 : 2);
     const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float);
     static bool attr = false;
     if (!attr) {

@@ -188,7 +188,7 @@ public:
         if (key == "two_streams") opt_two_streams_ = value != 0;
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
-        else if (key == "cfg_streams") opt_cfg_streams_ = value < 1 ? 1 : value;
+        else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -276,7 +276,7 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
-    int opt_cfg_streams_ = 2;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into
+    int opt_cfg_streams_ = 0;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into; 0 = by batch size
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies
     static constexpr int MAX_CFG_STREAMS = 4;

@@ -547,7 +547,8 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     // cond | uncond on two streams - the HBM-bound GroupNorm/split passes and the VALU-bound attention of one chunk run under the
     // matrix work of the other (measured 3.3 % faster end to end than NS = 1 with the fp16-plane kernels); option "cfg_streams".
     static const int env_ns = []() { const char* v = getenv("DTTS_CFG_STREAMS"); return v ? atoi(v) : 0; }();
-    int NS = env_ns > 0 ? env_ns : opt_cfg_streams_;
+    // default (option 0): 2 chunks from batch 5 up, 1 below (<= 8 samples per layer: a single launch sequence is faster, measured at B = 1, 2, 4)
+    int NS = env_ns > 0 ? env_ns : (opt_cfg_streams_ > 0 ? opt_cfg_streams_ : (B <= 4 ? 1 : 2));
     if (!two_streams) NS = 1;
     if (NS > MAX_CFG_STREAMS) NS = MAX_CFG_STREAMS;
     while (NS > 1 && ((2 * B) % NS != 0 || (B % ((2 * B) / NS) != 0 && ((2 * B) / NS) % B != 0))) --NS;

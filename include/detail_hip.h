@@ -224,7 +224,9 @@ int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int 
                          void* stream);
 
 /* Runtime options:
- *   "two_streams" (default 1): run the cond / uncond halves of every diffusion forward on two HIP streams;
+ *   "cfg_streams" (default 0 = by batch size: 1 up to batch 4, 2 above): the cond | uncond stack of a diffusion forward (2B samples on
+ *                 the same weights) is cut into this many chunks, each a launch sequence on its own HIP stream; "two_streams" 0
+ *                 forces 1; env DTTS_CFG_STREAMS overrides;
  *   "gpt_graph"   (default 0): 1 = dtts_gpt_decode replays captured hipGraphs (16-step chunks); 0 = the same launches issued
  *                 eagerly, 16 steps per call (measured faster on ROCm 7.2: a replayed kernel node costs ~0.8 us more than an eager
  *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
