@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
         // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
         // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
         if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KW3 ? 3 : 5) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned char* As = smem + (ks % NSTG) * WTILE + lhi * (BM * 16);
         const unsigned char* Xb = smem + XOFF + (c16 % NSTG) * XBUF;
@@ -546,24 +546,28 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
     DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
-    // LDS stages: three (loads two K-steps ahead, counted vmcnt, 61 KiB -> 2 workgroups per CU) for launches of at most
-    // DTTS_CONV_STAGES3_MAXWG (600) workgroups, where each workgroup's own dependency chain DMA -> barrier -> fragment reads -> MFMA is exposed;
-    // two (41 KiB -> 3 per CU) for launches that fill the chip several times over.  DTTS_CONV_STAGES = 2 / 3 forces one.
-    static const int force_stg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 0; return n == 3 ? 3 : (n == 2 ? 2 : 0); }();
+    // LDS stages by launch size.  Small launches expose each workgroup's own dependency chain DMA -> barrier -> fragment reads -> MFMA,
+    // so the loads run further ahead (counted vmcnt): four stages (82 KiB, one workgroup per CU) up to DTTS_CONV_STAGES4_MAXWG = 128
+    // workgroups (half the CUs: batch 1), three (61 KiB, two per CU) up to DTTS_CONV_STAGES3_MAXWG = 600, two (41 KiB, three per CU)
+    // for launches that fill the chip several times over.  DTTS_CONV_STAGES = 2 / 3 / 4 forces one.
+    static const int force_stg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 0; return n >= 2 && n <= 4 ? n : 0; }();
     static const long long max3 = []() { const char* v = getenv("DTTS_CONV_STAGES3_MAXWG"); return v ? atoll(v) : 600LL; }();
+    static const long long max4 = []() { const char* v = getenv("DTTS_CONV_STAGES4_MAXWG"); return v ? atoll(v) : 128LL; }();
     const long long nwg = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
-    const int nstg = force_stg ? force_stg : (nwg <= max3 ? 3 : 2);
+    const int nstg = force_stg ? force_stg : (nwg <= max4 ? 4 : (nwg <= max3 ? 3 : 2));
     const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        const int l3 = 3 * (WTILE + XBUF) + BM * (int)sizeof(float);
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, l3));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<2, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, l3));
-        const void* fns[8] = {reinterpret_cast<const void*>(conv_x3_kernel<0, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 2>),
-                              reinterpret_cast<const void*>(conv_x3_kernel<0, true, 2>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 2>),
-                              reinterpret_cast<const void*>(conv_x3_kernel<0, false, 3>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 3>),
-                              reinterpret_cast<const void*>(conv_x3_kernel<0, true, 3>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 3>)};
-        for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
+        const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float);
+        const void* fns[] = {reinterpret_cast<const void*>(conv_x3_kernel<2, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<2, false, 3>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<2, false, 4>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<0, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 2>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<0, true, 2>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 2>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<0, false, 3>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 3>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<0, true, 3>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 3>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<0, false, 4>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 4>),
+                             reinterpret_cast<const void*>(conv_x3_kernel<0, true, 4>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 4>)};
+        for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
         attr = true;
     }
     const dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);
@@ -578,7 +582,8 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
         const bool epi = p.epi_act != ACT_NONE || p.out_scale != 1.f;
 #define DTTS_LAUNCH_X3(E, K3)                                                                                          \
     do {                                                                                                               \
-        if (nstg == 3) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p);                      \
+        if (nstg == 4) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 4>), grid, dim3(256), lds, s, p);                      \
+        else if (nstg == 3) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p);                 \
         else hipLaunchKernelGGL((conv_x3_kernel<E, K3, 2>), grid, dim3(256), lds, s, p);                                \
     } while (0)
         if (p.qkv_planes) {
