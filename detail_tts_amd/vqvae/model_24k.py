@@ -338,19 +338,27 @@ class SynthesizerTrn:
             self._a_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dtts-stage-a")
         fut = self._a_pool.submit(stage_a, first)
         pending = None
-        while fut is not None:
-            st = fut.result()                   # the only wait on the GPU: this request's codes (their lengths size stage B)
-            try:
-                fut = self._a_pool.submit(stage_a, next(it))     # next request's stage A starts now, under this request's diffusion
-            except StopIteration:
-                fut = None
-            out = launch_bc(st)                 # stage B / C of this request: enqueued, not waited for
-            if pending is not None:
-                pending[2].synchronize()
-                yield pending[0], pending[1]
-            pending = out
-        pending[2].synchronize()
-        yield pending[0], pending[1]
+        try:
+            while fut is not None:
+                st, fut = fut.result(), None    # the only wait on the GPU: this request's codes (their lengths size stage B)
+                try:
+                    fut = self._a_pool.submit(stage_a, next(it))     # next request's stage A starts now, under this request's diffusion
+                except StopIteration:
+                    pass
+                out = launch_bc(st)             # stage B / C of this request: enqueued, not waited for
+                if pending is not None:
+                    pending[2].synchronize()
+                    yield pending[0], pending[1]
+                pending = out
+            pending[2].synchronize()
+            yield pending[0], pending[1]
+        finally:
+            # closed early or failed: the decode session in flight must end before this handle's stage-A entry points are used again
+            if fut is not None:
+                try:
+                    fut.result()
+                except Exception:
+                    pass
 
     def infer_gpt(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
                   forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False):

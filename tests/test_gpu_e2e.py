@@ -227,3 +227,21 @@ def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
         assert wav.shape == ref.shape and torch.equal(wav, ref)
         assert bool(torch.isfinite(wav).all()) and float(wav.pow(2).mean().sqrt()) > 1e-5
     assert list(model.infer_stream(iter([]))) == []
+
+
+def test_infer_stream_closed_early_leaves_the_handle_usable(model):
+    """Abandoning the generator after the first result waits for the decode session in flight; a plain infer() afterwards is unaffected."""
+    rs = np.random.RandomState(10)
+    B, Tr, Lt = 2, 200, 10
+    refer = torch.from_numpy((rs.randn(B, 128, Tr) * 2 - 5).astype(np.float32))
+    text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, Lt)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+    req = dict(text=text, text_length=torch.full((B,), Lt + 1), refer=refer, refer_lengths=torch.full((B,), Tr), seed=5, sample_ids=[0, 1])
+    ref = model.infer(text, req["text_length"], refer, req["refer_lengths"], batch=True, seed=5, sample_ids=[0, 1], max_generate_length=12,
+                      suppress_eos=True)
+    gen = model.infer_stream(iter([req, dict(req, seed=6), dict(req, seed=7)]), max_generate_length=12, suppress_eos=True)
+    wav, _ = next(gen)
+    gen.close()
+    assert torch.equal(wav, ref)
+    again = model.infer(text, req["text_length"], refer, req["refer_lengths"], batch=True, seed=5, sample_ids=[0, 1], max_generate_length=12,
+                        suppress_eos=True)
+    assert torch.equal(again, ref)
