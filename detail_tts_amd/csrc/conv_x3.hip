@@ -521,19 +521,11 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
     static const bool reg_ok = []() { const char* v = getenv("DTTS_GN_SPLIT_REG"); return !(v && v[0] == '0'); }();
     constexpr int NI = 3;
     if (reg_ok && ns == 1 && (C / groups / 8) * Tp <= NI * 1024) {          // the slab fits the workgroup's registers: one HBM read
-        // experiment knob: dynamic LDS the kernel never touches, to keep two of these 1024-thread workgroups off one CU
-        static const size_t pad = []() { const char* v = getenv("DTTS_GN_LDS_KB"); return (size_t)(v ? atoi(v) : 0) * 1024; }();
-        static bool attr = false;
-        if (pad && !attr) {
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_split_planes_reg_kernel<ACT_SILU, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_split_planes_reg_kernel<ACT_NONE, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            attr = true;
-        }
         if (act == ACT_SILU)
-            hipLaunchKernelGGL((gn_split_planes_reg_kernel<ACT_SILU, NI>), dim3(groups, B), dim3(1024), pad, s, x, x_bs, x_cs, lens, T, C, groups,
+            hipLaunchKernelGGL((gn_split_planes_reg_kernel<ACT_SILU, NI>), dim3(groups, B), dim3(1024), 0, s, x, x_bs, x_cs, lens, T, C, groups,
                                gamma, beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);
         else
-            hipLaunchKernelGGL((gn_split_planes_reg_kernel<ACT_NONE, NI>), dim3(groups, B), dim3(1024), pad, s, x, x_bs, x_cs, lens, T, C, groups,
+            hipLaunchKernelGGL((gn_split_planes_reg_kernel<ACT_NONE, NI>), dim3(groups, B), dim3(1024), 0, s, x, x_bs, x_cs, lens, T, C, groups,
                                gamma, beta, eps, ada, ada_stride, ada_bs, Tp, o, ada_idx);
         DTTS_CHECK_HIP(hipGetLastError());
         return;
