@@ -57,6 +57,12 @@ struct ConvParams {
     void* qkv_planes = nullptr;
     int qkv_heads = 0, qkv_nt64 = 0, qkv_tq = 0;
     float qkv_qscale = 1.f;        // softmax scale * log2(e), folded into the Q planes
+    // conv_x3 only, filled by its launcher: split-K for launches far smaller than the chip (batch 1).  The channel blocks are divided
+    // among `ksplit` workgroups per output tile; each leaves its raw accumulators in `kpart`, the last to arrive (counter in `kcount`)
+    // sums them in split order - deterministic - and runs the epilogue.
+    int ksplit = 1;
+    float* kpart = nullptr;
+    int* kcount = nullptr;
     int ablate = 0;                // experiments only (DTTS_CONV_ABLATE): 1 skip global loads, 2 skip LDS stores, 4 skip barriers
 };
 

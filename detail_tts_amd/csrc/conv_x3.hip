@@ -5,6 +5,9 @@
 // loads (1 KiB each: 2 of the W tile, 3 of the X tile), 10 ds_read_b128 and 18 MFMAs behind ONE barrier.  Tile shape from
 // tools/ubench/gemm_x3v.hip (M = 768 / 2304, B = 16, T = 936): 128 x 192 beats 128 x 128 by 8-10 % (2.5 instead of 8.6 % padded
 // columns, 17 % fewer LDS-DMA bytes per MFMA); deeper pipelines and 256-row tiles measured within +-3 % of it.
+#include <algorithm>
+#include <mutex>
+
 #include "conv_x3.h"
 #include <cstdlib>
 #include "prof.h"
@@ -264,16 +267,19 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: the M tiles of one (sample, N tile) are adjacent logical ids -> they share the X tile in one L2
     const int mtiles = p.CoutP / BM, ntiles = (p.Nout + BN - 1) / BN;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int Ls = xcd_remap(blockIdx.x, gridDim.x);
+    const int S = p.ksplit, L = Ls / S, z = Ls - L * S;                  // the splits of a tile are adjacent logical ids (one XCD)
     const int mt = L % mtiles, nb = L / mtiles;
     const int b = nb / ntiles;
     const int m0 = mt * BM, n0 = (nb - b * ntiles) * BN;
     const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
     if (n0 >= nvalid) return;
-    const int C8 = p.Cin >> 3, c16n = p.Cin >> 4, nks = KW * c16n, Tp = p.x3_tp;
+    const int C8 = p.Cin >> 3, call = p.Cin >> 4, Tp = p.x3_tp;
+    // split z owns channel blocks [cbeg, cend): the loop below indexes them from 0 through the shifted base pointers
+    const int cbeg = (int)((long long)call * z / S), c16n = (int)((long long)call * (z + 1) / S) - cbeg, nks = KW * c16n;
     const int bin = p.x_bidx ? p.x_bidx[b] : b;
-    const uint4* wbase = static_cast<const uint4*>(p.w3) + m0 + lane;
-    const uint4* xbase = static_cast<const uint4*>(p.x3) + (long long)bin * C8 * NPL * Tp + n0 + (X3_HALO - p.pad) + lane;
+    const uint4* wbase = static_cast<const uint4*>(p.w3) + m0 + lane + (long long)(2 * cbeg) * NPL * p.CoutP;
+    const uint4* xbase = static_cast<const uint4*>(p.x3) + (long long)bin * C8 * NPL * Tp + n0 + (X3_HALO - p.pad) + lane + (long long)(2 * cbeg) * NPL * Tp;
     const long long wtap = (long long)C8 * NPL * p.CoutP;
 
     // LDS-DMA pieces (1 KiB = 64 rows / columns of one (plane, k-half) "kind"): 8 per W tile, 12 (+ the 8 halo chunks) per X tile.
@@ -367,6 +373,44 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
         if (++tap == KW) { tap = 0; ++c16; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail refetches must land before the LDS is released
+
+    if (S > 1) {
+        // raw accumulators -> this split's slab (lane-contiguous: one 256-byte run per register and wave); the last workgroup of the tile
+        // to arrive adds the S slabs in split order (its own included, from memory: the order never depends on who arrives last)
+        // Every slab access is an agent-scope (sc1) access: coherent across the XCDs' L2s one by one, WITHOUT the bulk L2 write-back /
+        // invalidate a release / acquire fence costs here (measured: +40 us per launch).
+        float* slab = p.kpart + ((size_t)L * S) * (96 * 256);
+        float* mine = slab + (size_t)z * (96 * 256) + tid;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + ((i * 3 + j) * 16 + r) * 256, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's stores have reached the coherent level
+        __syncthreads();
+        int* s_last = reinterpret_cast<int*>(bias_s + BM);      // dynamic LDS (a second __shared__ object would cost the K loop its counted waits)
+        if (tid == 0) *s_last = __hip_atomic_fetch_add(p.kcount + L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1 ? 1 : 0;
+        __syncthreads();
+        if (!*s_last) return;
+        if (tid == 0) __hip_atomic_store(p.kcount + L, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int zz = 0; zz < S; ++zz) {
+            const float* src = slab + (size_t)zz * (96 * 256) + tid;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += __hip_atomic_load(src + ((i * 3 + j) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // bias of this lane's 32 output rows from the LDS copy made at kernel start: no global latency here, no registers held
@@ -539,7 +583,52 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-void launch_conv_x3(const ConvParams& p, hipStream_t s) {
+// Split-K scratch per launch stream: slabs of raw accumulators (96 x 256 floats per workgroup) and one arrival counter per output tile
+// (zero between launches: the reducing workgroup resets it).  Launches on one stream are ordered; different streams get different slots.
+namespace {
+struct KSplitWs {
+    float* part;
+    int* count;
+};
+KSplitWs ksplit_workspace(hipStream_t s, size_t nslabs) {
+    constexpr int SLOTS = 8;
+    constexpr size_t MAX_SLABS = 256, MAX_TILES = 128;
+    static std::mutex mu;
+    static hipStream_t owner[SLOTS];
+    static int owner_dev[SLOTS];
+    static float* part[SLOTS];
+    static int* count[SLOTS];
+    static int used = 0, victim = 0;
+    DTTS_REQUIRE(nslabs <= MAX_SLABS, "conv_x3 split-K: launch too large");
+    int dev = 0;
+    DTTS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    int k = 0;
+    while (k < used && !(owner[k] == s && owner_dev[k] == dev)) ++k;
+    if (k == used) {
+        if (used == SLOTS) {                            // every slot taken: drain the device and hand the oldest slot of this device on
+            DTTS_CHECK_HIP(hipDeviceSynchronize());
+            for (int t = 0; t < SLOTS; ++t, victim = (victim + 1) % SLOTS)
+                if (owner_dev[victim] == dev) break;
+            DTTS_REQUIRE(owner_dev[victim] == dev, "conv_x3 split-K: no scratch slot on this device");
+            k = victim;
+            victim = (victim + 1) % SLOTS;
+            owner[k] = s;
+            return {part[k], count[k]};
+        }
+        DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&part[k]), MAX_SLABS * 96 * 256 * sizeof(float)));
+        DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&count[k]), MAX_TILES * sizeof(int)));
+        DTTS_CHECK_HIP(hipMemset(count[k], 0, MAX_TILES * sizeof(int)));
+        owner[k] = s;
+        owner_dev[k] = dev;
+        ++used;
+    }
+    return {part[k], count[k]};
+}
+}  // namespace
+
+void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
+    ConvParams p = p_in;
     DTTS_REQUIRE(p.w3 && p.x3 && (p.y || p.qkv_planes) && p.x3_tp > 0, "conv_x3: operands");
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
     DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3: channel padding");
@@ -553,9 +642,22 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
     static const int force_stg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 0; return n >= 2 && n <= 4 ? n : 0; }();
     static const long long max3 = []() { const char* v = getenv("DTTS_CONV_STAGES3_MAXWG"); return v ? atoll(v) : 600LL; }();
     static const long long max4 = []() { const char* v = getenv("DTTS_CONV_STAGES4_MAXWG"); return v ? atoll(v) : 128LL; }();
-    const long long nwg = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
+    const long long ntile = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
+    // split-K: launches of at most 128 tiles (half the CUs: batch 1) divide the channel blocks among up to 4 workgroups per tile
+    static const int max_split = []() { const char* v = getenv("DTTS_CONV_KSPLIT"); const int n = v ? atoi(v) : 4; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
+    int S = 1;
+    // (k = 3: 144 K-steps per tile; the 48 steps of a 1x1 conv barely pay for the exchange: at most 2 there)
+    if (ntile <= 128) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), 256 / ntile), (p.Cin >> 4) / 8);
+    if (S < 1) S = 1;
+    p.ksplit = S;
+    if (S > 1) {
+        const KSplitWs w = ksplit_workspace(s, (size_t)ntile * S);
+        p.kpart = w.part;
+        p.kcount = w.count;
+    }
+    const long long nwg = ntile * S;
     const int nstg = force_stg ? force_stg : (nwg <= max4 ? 4 : (nwg <= max3 ? 3 : 2));
-    const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float);
+    const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16;
     static bool attr = false;
     if (!attr) {
         const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float);
@@ -570,7 +672,7 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s) {
         for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
         attr = true;
     }
-    const dim3 grid((p.CoutP / BM) * cdiv(p.Nout, BN) * p.B);
+    const dim3 grid((unsigned)nwg);
     const double cols = (double)p.B * p.Nout;
     const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 3x this in fp16
     const double bytes = 4.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 4.0 * (double)p.Cout * p.Cin * p.KW;
