@@ -592,7 +592,7 @@ struct KSplitWs {
 };
 KSplitWs ksplit_workspace(hipStream_t s, size_t nslabs) {
     constexpr int SLOTS = 8;
-    constexpr size_t MAX_SLABS = 256, MAX_TILES = 128;
+    constexpr size_t MAX_SLABS = 1024, MAX_TILES = 512;
     static std::mutex mu;
     static hipStream_t owner[SLOTS];
     static int owner_dev[SLOTS];
@@ -647,7 +647,9 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     static const int max_split = []() { const char* v = getenv("DTTS_CONV_KSPLIT"); const int n = v ? atoi(v) : 4; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
     int S = 1;
     // (k = 3: 144 K-steps per tile; the 48 steps of a 1x1 conv barely pay for the exchange: at most 2 there)
-    if (ntile <= 128) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), 256 / ntile), (p.Cin >> 4) / 8);
+    static const long long split_tiles = []() { const char* v = getenv("DTTS_CONV_KSPLIT_MAXTILE"); return v ? atoll(v) : 128LL; }();
+    static const long long split_wgs = []() { const char* v = getenv("DTTS_CONV_KSPLIT_WGS"); return v ? atoll(v) : 256LL; }();
+    if (ntile <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile), (p.Cin >> 4) / 8);
     if (S < 1) S = 1;
     p.ksplit = S;
     if (S > 1) {
