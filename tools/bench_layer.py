@@ -8,7 +8,9 @@ from detail_tts_amd.weights import synthetic_state_dict, fold_weight_norm
 B, T = int(os.environ.get("BB", 8)), int(os.environ.get("TT", 936))
 W = fold_weight_norm(synthetic_state_dict(0, only_prefixes=["diffusion."]))
 rt = Runtime(W, folded=True, parts=("diffusion",))
-x = torch.randn(B, 768, T, device="cuda")
+# XSCALE: scale of the random input.  XSCALE=0 feeds zeros: every activation of the layer becomes a per-channel constant (the biases), the
+# matrix pipe's operands barely toggle, and the kernels show what they do when power / clock is not the limit.
+x = torch.randn(B, 768, T, device="cuda") * float(os.environ.get("XSCALE", 1.0))
 
 
 def layer():
