@@ -105,8 +105,8 @@ def decode_bytes_per_token(cfg, B, lp_mean, n_codes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
     ap.add_argument("--codes", type=int, default=N_CODES, help="codes per utterance (234 = the BASELINE config; smaller only for dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
