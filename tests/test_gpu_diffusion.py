@@ -257,3 +257,22 @@ def test_trunk_blocks_random_shapes(rt, weights):
             assert maxabs(y[b, :, :L], ref) < 1e-4, ("resblock", T, b)
             ref = D.attention_block(weights, "diffusion.layers.5.attn", x[b:b + 1, :, :L], 16)[0]
             assert maxabs(z[b, :, :L], ref) < 1e-4, ("attention", T, b)
+
+
+def test_small_launch_split_k_is_deterministic_under_load(rt):
+    """Small launches split their K range over several workgroups that meet through an arrival counter; the sums are taken in split
+    order, so repeated runs are bit-identical - also while another stream keeps the chip busy."""
+    rs = np.random.RandomState(11)
+    x = dev(rs.randn(2, 768, 100).astype(np.float32))
+    big = torch.randn(4096, 4096, device="cuda")
+    ref = rt.op_resblock("diffusion.layers.2.resblk", x, 9, [100, 71])
+    ref_a = rt.op_attention_block("diffusion.layers.2.attn", ref, [100, 71])
+    side = torch.cuda.Stream()
+    for i in range(40):
+        if i % 4 == 0:                      # unrelated work on another stream (a handle's own entry points are one-at-a-time per stage)
+            with torch.cuda.stream(side):
+                big = torch.tanh(big @ big) * 0.01
+        y = rt.op_resblock("diffusion.layers.2.resblk", x, 9, [100, 71])
+        a = rt.op_attention_block("diffusion.layers.2.attn", y, [100, 71])
+        assert torch.equal(y, ref) and torch.equal(a, ref_a), i
+    torch.cuda.synchronize()
