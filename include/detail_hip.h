@@ -25,7 +25,8 @@
  * the other thread everything else (stages B and C), each on its own streams.  That is how the next request's GPT decode is issued
  * under this request's diffusion (SynthesizerTrn.infer_stream); the host cannot do it from one thread because a launch call blocks
  * once the stream's hardware queue is full.  dtts_last_error returns the calling thread's last message.  Any other concurrent use
- * of one handle is not supported.
+ * of one handle is not supported - in particular, calls of the same stage share that stage's scratch, so they must be ordered on the
+ * device too (one stream per stage, or events between streams): two of them running at once on different streams corrupt each other.
  */
 #ifndef DETAIL_HIP_H
 #define DETAIL_HIP_H
