@@ -81,6 +81,8 @@ SIGNATURES = {
     "dtts_op_mel_style": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_attention_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_resblock": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dtts_op_resblock1": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dtts_op_wn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_conv1d": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_op_philox_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_int, C.c_int, C.c_void_p]),

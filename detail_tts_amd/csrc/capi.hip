@@ -48,6 +48,18 @@ void dtts_default_config(dtts_config* c) {
     for (int i = 0; i < 3; ++i) { c->resblock_kernels[i] = rk[i]; c->resblock_dilations[i] = rd[i]; }
 }
 
+int dtts_op_resblock1(dtts_handle* h, int stage, int branch, const float* x, const int* lens, int B, int T, float* y, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_resblock1(stage, branch, x, lens, B, T, y, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_op_wn(dtts_handle* h, int flow, const float* hidden, const float* g, const int* lens, int B, int T, float* out, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_wn(flow, hidden, g, lens, B, T, out, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
                    int B, float* mel_out, void* stream) {
     DTTS_API_BEGIN

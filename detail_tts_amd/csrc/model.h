@@ -167,6 +167,8 @@ public:
     void generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs = 0,
                    int z_cs = 0);
     void op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
+    void op_resblock1(int stage, int branch, const float* x, const int* lens_host, int B, int T, float* y, hipStream_t s);
+    void op_wn(int flow, const float* h, const float* g, const int* lens_host, int B, int T, float* out, hipStream_t s);
     // ---- VQ decode path (infer_gpt)
     void vq_decode(const int* codes_host, const int* ncodes_host, int nmax, const float* refer, const int* refer_lens_host, int Tr,
                    int B, float* mel_out, hipStream_t s);
@@ -202,6 +204,9 @@ private:
     PackedConv conv(const std::string& name, int Cin, int Cout, int KW, bool bias = true, int cout_p = 0) const;
     AttnBlockW attn_block(const std::string& prefix, int C, int H) const;
     ResBlockW res_block(const std::string& prefix, int C, int index) const;
+    void resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, float* out, int ch, const int* lens, int B, int T, hipStream_t s);
+    void wn_fwd(const CouplingW& c, float* h, const float* g, int gin, float* Gc, float* acts, float* h2, float* skip, const int* dl, int B,
+                int T, hipStream_t s);
     void build_diffusion(hipStream_t s);
     void build_vocoder();
     void build_gpt(hipStream_t s);

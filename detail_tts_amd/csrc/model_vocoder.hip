@@ -169,6 +169,57 @@ void Model::op_mel_style(const char* which, const float* mel, const int* lens_ho
 
 // Generator.forward (vqvae/model_24k.py:269-288).  z [B,192,T], g [B,768] -> wav [B,1,256*T]
 // z may be a window of a longer buffer: element (b, c, t) at z[b * z_bs + c * z_cs + t]
+// modules.ResBlock1.forward (vqvae/modules/modules.py:315-328): three times x = convs2[l](lrelu(convs1[l](lrelu(x)))) + x with
+// dilations (1, 3, 5) in convs1; leaky-relu prologues and the residual epilogue are fused into the convs.  x is not modified.
+void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, float* out, int ch, const int* lens, int B, int T, hipStream_t s) {
+    auto cp = [&](const float* in, float* o) {
+        ConvParams p;
+        p.B = B;
+        p.Tin = T;
+        p.Nout = T;
+        p.len_in = lens;
+        p.len_out = lens;
+        p.x = in;
+        p.x_bs = (long long)ch * T;
+        p.x_cs = T;
+        p.y = o;
+        p.y_bs = (long long)ch * T;
+        p.y_cs = T;
+        p.pro_act = ACT_LRELU;
+        p.pro_slope = 0.1f;
+        return p;
+    };
+    const float* cur = x;
+    for (int li = 0; li < 3; ++li) {
+        const int d = cfg.resblock_dilations[li];
+        ConvParams a = cp(cur, tmp);
+        a.dil = d;
+        a.pad = (rb.k * d - d) / 2;
+        run_conv(rb.c1[li], a, s);
+        ConvParams c = cp(tmp, out);
+        c.pad = (rb.k - 1) / 2;
+        c.res = cur;
+        c.res_bs = (long long)ch * T;
+        c.res_cs = T;
+        run_conv(rb.c2[li], c, s);
+        cur = out;
+    }
+}
+
+// unit entry point: dec.resblocks[stage * 3 + branch] on x [B, ch(stage), T]
+void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_host, int B, int T, float* y, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    DTTS_REQUIRE(stage >= 0 && stage < (int)gen_.size() && branch >= 0 && branch < cfg.n_resblock_kernels, "resblock index");
+    ArenaUse use_stage_c_arena(ws_voc_);
+    const int ch = gen_[stage].cout;
+    ws().ensure(sizeof(float) * (size_t)B * ch * T + 4096);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    float* tmp = ws().f32((size_t)B * ch * T);
+    resblock1_fwd(gen_[stage].rb[branch], x, tmp, y, ch, dl, B, T, s);
+}
+
 void Model::generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs,
                       int z_cs) {
     DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
@@ -238,28 +289,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
         u.y_cs = Tn;
         run_conv(st.up, u, s);
         // three ResBlock1 branches on T1 -> R[j]
-        for (int j = 0; j < cfg.n_resblock_kernels; ++j) {
-            const ResBlock1W& rb = st.rb[j];
-            const float* cur = T1;
-            for (int li = 0; li < 3; ++li) {
-                const int d = cfg.resblock_dilations[li];
-                ConvParams a = cp(cur, cn, T2, cn, B, Tn, Tn, dln);
-                a.pro_act = ACT_LRELU;
-                a.pro_slope = 0.1f;
-                a.dil = d;
-                a.pad = (rb.k * d - d) / 2;
-                run_conv(rb.c1[li], a, s);
-                ConvParams c = cp(T2, cn, R[j], cn, B, Tn, Tn, dln);
-                c.pro_act = ACT_LRELU;
-                c.pro_slope = 0.1f;
-                c.pad = (rb.k - 1) / 2;
-                c.res = cur;
-                c.res_bs = (long long)cn * Tn;
-                c.res_cs = Tn;
-                run_conv(rb.c2[li], c, s);
-                cur = R[j];
-            }
-        }
+        for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s);
         launch_add3_scale(R[0], R[1], R[2], 1.f / 3.f, X, (long long)B * cn * Tn, s);
         ch = cn;
         Tc = Tn;
@@ -291,6 +321,85 @@ void Model::op_generator(const float* z, const float* g, const int* lens_host, i
     ws().ensure(generator_ws(cfg, B, T) + 8192);
     DTTS_CHECK_HIP(hipMemsetAsync(wav, 0, sizeof(float) * (size_t)B * 256 * T, s));
     generator(z, g, lens_host, B, T, wav, s);
+}
+
+// modules.WN.forward (vqvae/modules/modules.py:204-229) of one coupling layer: h [B,192,T] (overwritten), g [B,gin] -> skip [B,192,T].
+// Gc [B, cond.CoutP], acts / h2 [B,192,T] are scratch.
+void Model::wn_fwd(const CouplingW& c, float* h, const float* g, int gin, float* Gc, float* acts, float* h2, float* skip, const int* dl,
+                   int B, int T, hipStream_t s) {
+    const int hid = cfg.hidden_channels;
+    auto cp = [&](const float* in, float* o) {
+        ConvParams p;
+        p.B = B;
+        p.Tin = T;
+        p.Nout = T;
+        p.len_in = dl;
+        p.len_out = dl;
+        p.x = in;
+        p.x_bs = (long long)hid * T;
+        p.x_cs = T;
+        p.y = o;
+        p.y_bs = (long long)hid * T;
+        p.y_cs = T;
+        return p;
+    };
+    // G = cond_layer(g): [B, 1536] in packed (gate-interleaved) row order
+    ConvParams q;
+    q.B = B;
+    q.Tin = 1;
+    q.Nout = 1;
+    q.x = g;
+    q.x_bs = gin;
+    q.x_cs = 1;
+    q.y = Gc;
+    q.y_bs = c.cond.CoutP;
+    q.y_cs = 1;
+    run_conv(c.cond, q, s);
+    float* hc = h;
+    float* hn = h2;
+    for (int li = 0; li < 4; ++li) {
+        // acts = tanh(a + g_l) * sigmoid(b + g_l), (a|b) = in_layer(h)   (modules.py:15-22, 212-221)
+        ConvParams p = cp(hc, acts);
+        p.pad = 2;
+        p.gate = GATE_TANH_SIGMOID;
+        p.badd = Gc + (size_t)li * 2 * hid;
+        p.badd_bs = c.cond.CoutP;
+        run_conv(c.in[li], p, s);
+        if (li < 3) {
+            p = cp(acts, hn);                      // x = (x + res_acts) * mask
+            p.res = hc;
+            p.res_bs = (long long)hid * T;
+            p.res_cs = T;
+            run_conv(c.res[li], p, s);
+        }
+        p = cp(acts, skip);                        // output += skip_acts
+        if (li > 0) {
+            p.res = skip;
+            p.res_bs = (long long)hid * T;
+            p.res_cs = T;
+        }
+        run_conv(c.skip[li], p, s);
+        if (li < 3) std::swap(hc, hn);
+    }
+}
+
+// unit entry point: flow.flows[2 * flow].enc on h [B,192,T] with g [B,gin] -> out [B,192,T]
+void Model::op_wn(int flow, const float* h_in, const float* g, const int* lens_host, int B, int T, float* out, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    DTTS_REQUIRE(flow >= 0 && flow < (int)flows_.size(), "flow index");
+    ArenaUse use_stage_c_arena(ws_voc_);
+    const int hid = cfg.hidden_channels, gin = cfg.gin_channels;
+    const size_t a = (size_t)B * hid * T;
+    ws().ensure(sizeof(float) * (3 * a + (size_t)B * flows_[flow].cond.CoutP) + 8192);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    float* h = ws().f32(a);
+    float* acts = ws().f32(a);
+    float* h2 = ws().f32(a);
+    float* Gc = ws().f32((size_t)B * flows_[flow].cond.CoutP);
+    DTTS_CHECK_HIP(hipMemcpyAsync(h, h_in, sizeof(float) * a, hipMemcpyDeviceToDevice, s));
+    wn_fwd(flows_[flow], h, g, gin, Gc, acts, h2, out, dl, B, T, s);
 }
 
 // SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863), batched with per-sample lengths.
@@ -393,48 +502,11 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     float* mbuf = ffn;                 // [B,96,T]
     for (int f = (int)flows_.size() - 1; f >= 0; --f) {
         const CouplingW& c = flows_[f];
-        // G = cond_layer(g): [B, 1536] in packed (gate-interleaved) row order
-        ConvParams q;
-        q.B = B;
-        q.Tin = 1;
-        q.Nout = 1;
-        q.x = g;
-        q.x_bs = gin;
-        q.x_cs = 1;
-        q.y = Gc;
-        q.y_bs = c.cond.CoutP;
-        q.y_cs = 1;
-        run_conv(c.cond, q, s);
         // h = pre(x0) * mask
-        p = cp(zc, inter / 2, h, hid, B, T, T, dl);
+        ConvParams p = cp(zc, inter / 2, h, hid, B, T, T, dl);
         p.x_bs = (long long)inter * T;            // x0 = first half of the channels
         run_conv(c.pre, p, s);
-        float* hc = h;
-        float* hn = h2;
-        for (int li = 0; li < 4; ++li) {
-            // acts = tanh(a + g_l) * sigmoid(b + g_l), (a|b) = in_layer(h)   (modules.py:15-22, 212-221)
-            p = cp(hc, hid, acts, hid, B, T, T, dl);
-            p.pad = 2;
-            p.gate = GATE_TANH_SIGMOID;
-            p.badd = Gc + (size_t)li * 2 * hid;
-            p.badd_bs = c.cond.CoutP;
-            run_conv(c.in[li], p, s);
-            if (li < 3) {
-                p = cp(acts, hid, hn, hid, B, T, T, dl);       // x = (x + res_acts) * mask
-                p.res = hc;
-                p.res_bs = (long long)hid * T;
-                p.res_cs = T;
-                run_conv(c.res[li], p, s);
-            }
-            p = cp(acts, hid, skip, hid, B, T, T, dl);         // output += skip_acts
-            if (li > 0) {
-                p.res = skip;
-                p.res_bs = (long long)hid * T;
-                p.res_cs = T;
-            }
-            run_conv(c.skip[li], p, s);
-            if (li < 3) std::swap(hc, hn);
-        }
+        wn_fwd(c, h, g, gin, Gc, acts, h2, skip, dl, B, T, s);
         // m = post(out) * mask ; x1 = (x1 - m) * mask ; then Flip (fused) unless this is the last flow
         p = cp(skip, hid, mbuf, inter / 2, B, T, T, dl);
         run_conv(c.post, p, s);

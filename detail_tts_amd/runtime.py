@@ -392,6 +392,24 @@ class Runtime:
         self._rc(self.lib.dtts_op_resblock(self.h, prefix.encode(), _ptr(x), li[0] if li else None, B, T, int(step), _ptr(y), self._stream()))
         return y
 
+    def op_resblock1(self, stage, branch, x, lens=None):
+        """HiFiGAN ResBlock1 dec.resblocks[stage * 3 + branch] on x [B, C(stage), T]"""
+        _check(x, "x")
+        B, _, T = x.shape
+        y = torch.zeros_like(x)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_op_resblock1(self.h, int(stage), int(branch), _ptr(x), li[0] if li else None, B, T, _ptr(y), self._stream()))
+        return y
+
+    def op_wn(self, flow, hidden, g, lens=None):
+        """WaveNet of coupling layer `flow` (flow.flows[2 * flow].enc): hidden [B,192,T], g [B,gin] -> summed skips [B,192,T]"""
+        _check(hidden, "hidden"); _check(g, "g")
+        B, _, T = hidden.shape
+        out = torch.zeros_like(hidden)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_op_wn(self.h, int(flow), _ptr(hidden), _ptr(g), li[0] if li else None, B, T, _ptr(out), self._stream()))
+        return out
+
     def op_conv1d(self, name, x, cout, kw, stride=1, dil=1, pad=0, pro_act=0, epi_act=0, gate=0, phases=1, res=None, lens_in=None):
         _check(x, "x"); _check(res, "res")
         B, Cin, Tin = x.shape

@@ -256,6 +256,12 @@ int dtts_profile_sampling(int every);
 int dtts_profile_report(dtts_kernel_stat* out, int max_entries);
 
 /* ---- unit entry points for parity tests ------------------------------------------------------- */
+/* HiFiGAN ResBlock1 `dec.resblocks[stage * 3 + branch]` (vqvae/modules/modules.py:315-328) on x [B, C(stage), T] -> y (same shape);
+ * C(stage) = upsample_initial_channel / 2^(stage + 1).  lens HOST (null -> T). */
+int dtts_op_resblock1(dtts_handle* h, int stage, int branch, const float* x, const int* lens, int B, int T, float* y, void* stream);
+/* WaveNet of coupling layer `flow` (`flow.flows[2 * flow].enc`, vqvae/modules/modules.py:204-229): hidden [B, 192, T] (after the layer's
+ * `pre` conv), g [B, gin] -> out [B, 192, T] (the summed skip connections, masked). */
+int dtts_op_wn(dtts_handle* h, int flow, const float* hidden, const float* g, const int* lens, int B, int T, float* out, void* stream);
 /* AttentionBlock.forward (vqvae/utils/diff_util.py:209-215) of the block whose weights start with `prefix` */
 int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T,
                             float* y, void* stream);

@@ -197,3 +197,35 @@ def test_generator_stream_equals_full_and_wav_writer(weights, tmp_path):
         assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 24000, 150 * 256)
         pcm = np.frombuffer(f.readframes(f.getnframes()), np.int16)
     assert np.abs(pcm / 32767.0 - full[0, 0].clamp(-1, 1).cpu().numpy()).max() < 1.0 / 32767 + 1e-6
+
+
+@pytest.mark.parametrize("stage,branch", [(0, 0), (0, 2), (1, 1), (3, 2), (4, 0)])
+def test_unit_resblock1_vs_oracle(rt, weights, stage, branch):
+    """dtts_op_resblock1: one HiFiGAN ResBlock1 (kernel 3 / 7 / 11, dilations 1, 3, 5) against the oracle, ragged batch."""
+    from oracle import vocoder as V
+    rs = np.random.RandomState(20 + stage * 3 + branch)
+    ch = 400 >> (stage + 1)
+    T = 160
+    x = (rs.randn(2, ch, T) * 0.5).astype(np.float32)
+    lens = [T, T - 37]
+    y = host(rt.op_resblock1(stage, branch, dev(x), lens))
+    for b, L in enumerate(lens):
+        ref = V.resblock1(weights, f"dec.resblocks.{stage * 3 + branch}", x[b:b + 1, :, :L], (3, 7, 11)[branch])[0]
+        assert maxabs(y[b, :, :L], ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), (stage, branch, b)
+
+
+@pytest.mark.parametrize("flow", [0, 3])
+def test_unit_wn_vs_oracle(rt, weights, flow):
+    """dtts_op_wn: the WaveNet of one residual coupling layer (gated tanh * sigmoid, res / skip convs, global conditioning)."""
+    from oracle import vocoder as V
+    rs = np.random.RandomState(40 + flow)
+    T = 120
+    h = (rs.randn(2, 192, T) * 0.7).astype(np.float32)
+    g = (rs.randn(2, 768) * 0.3).astype(np.float32)
+    lens = [T, T - 29]
+    out = host(rt.op_wn(flow, dev(h), dev(g), lens))
+    for b, L in enumerate(lens):
+        mf = np.ones((1, 1, L), np.float32)
+        ref = V.wn(weights, f"flow.flows.{2 * flow}.enc", h[b:b + 1, :, :L], mf, g[b:b + 1, :, None])[0]
+        assert maxabs(out[b, :, :L], ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), (flow, b)
+        assert np.all(out[b, :, L:] == 0)
