@@ -52,6 +52,7 @@ struct ConvParams {
     const void* w3 = nullptr;
     const void* x3 = nullptr;
     int x3_tp = 0;
+    int x3_halo = 1;               // zero columns left of t = 0 in the planes (conv_x3d: >= pad; conv_x3 uses X3_HALO = 1)
     // conv_x3 only, the trunk's qkv conv: write the output as the split-precision attention's operand images (attention.h:
     // AttnPlanes) instead of fp32 rows - Q / K chunks straight from the accumulator layout, V through a 4 x 4 lane transpose
     void* qkv_planes = nullptr;

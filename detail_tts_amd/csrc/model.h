@@ -204,11 +204,13 @@ private:
     PackedConv conv(const std::string& name, int Cin, int Cout, int KW, bool bias = true, int cout_p = 0) const;
     AttnBlockW attn_block(const std::string& prefix, int C, int H) const;
     ResBlockW res_block(const std::string& prefix, int C, int index) const;
-    void resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, float* out, int ch, const int* lens, int B, int T, hipStream_t s);
+    void resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, float* out, int ch, const int* lens, int B, int T, hipStream_t s,
+                       void* xs = nullptr);
+    bool vocoder_x3() const;
     void wn_fwd(const CouplingW& c, float* h, const float* g, int gin, float* Gc, float* acts, float* h2, float* skip, const int* dl, int B,
                 int T, hipStream_t s);
     void build_diffusion(hipStream_t s);
-    void build_vocoder();
+    void build_vocoder(hipStream_t s);
     void build_gpt(hipStream_t s);
     void gpt_head_and_sample(hipStream_t s);
     void gpt_step_launches(hipStream_t s);
@@ -284,6 +286,7 @@ private:
     int opt_cfg_streams_ = 0;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into; 0 = by batch size
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies
+    Arena w3_voc_;                        // ... of the generator's wide ResBlock1 convs
     static constexpr int MAX_CFG_STREAMS = 4;
     hipStream_t sx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};   // extra streams of the diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_joinx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};

@@ -131,7 +131,7 @@ void Model::bind_weights(const void* blob, size_t nbytes, const char* const* nam
     }
     if (weights_.count("diffusion.inp_block.wp")) build_diffusion(stream);
     has_vocoder_ = weights_.count("dec.conv_pre.wp") != 0;
-    if (has_vocoder_) build_vocoder();
+    if (has_vocoder_) build_vocoder(stream);
     has_gpt_ = weights_.count("gpt.mel_head.wp") != 0;
     if (has_gpt_) build_gpt(stream);
     has_vq_ = weights_.count("quantizer.table") != 0;

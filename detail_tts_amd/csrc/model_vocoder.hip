@@ -4,6 +4,7 @@
 #include <cmath>
 
 #include "model.h"
+#include "conv_x3.h"
 
 namespace dtts {
 
@@ -22,7 +23,7 @@ MelStyleW Model::mel_style_w(const std::string& p, int n_mel, int hidden, int ou
     return w;
 }
 
-void Model::build_vocoder() {
+void Model::build_vocoder(hipStream_t stream) {
     const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
     ref_enc_ = mel_style_w("ref_enc", cfg.mel_channels, 128, gin);
     in_proj_ = conv("in_proj", cfg.mel_channels, inter, 3);
@@ -85,6 +86,22 @@ void Model::build_vocoder() {
         gen_.push_back(g);
     }
     dec_post_ = conv("dec.conv_post", ch, 1, 7, false);
+    // split-precision copies of the ResBlock1 weights of the wide generator stages (conv_x3d.hip): channels > 64 (CoutP a multiple of 128)
+    std::vector<PackedConv*> wide;
+    for (auto& g : gen_)
+        if (g.cout > 64)
+            for (int j = 0; j < cfg.n_resblock_kernels; ++j)
+                if (g.rb[j].k == 3 || g.rb[j].k == 7 || g.rb[j].k == 11)
+                    for (int l = 0; l < 3; ++l) { wide.push_back(&g.rb[j].c1[l]); wide.push_back(&g.rb[j].c2[l]); }
+    size_t total = 0;
+    for (PackedConv* pc : wide) total += (size_t)pc->KW * pc->CinP * pc->CoutP * 4 + 256;
+    w3_voc_.ensure(total + 4096);
+    for (PackedConv* pc : wide) {
+        if (pc->CinP % 16 || pc->CoutP % 128) continue;
+        void* dst = w3_voc_.raw((size_t)pc->KW * pc->CinP * pc->CoutP * 4);
+        launch_split_weights(pc->w, pc->KW, pc->CinP, pc->CoutP, dst, stream);
+        pc->w3 = dst;
+    }
 }
 
 // MelStyleEncoder.forward.  mel [B,n_mel,T] (positions >= len are treated as zero == the reference's x*mask /
@@ -169,9 +186,23 @@ void Model::op_mel_style(const char* which, const float* mel, const int* lens_ho
 
 // Generator.forward (vqvae/model_24k.py:269-288).  z [B,192,T], g [B,768] -> wav [B,1,256*T]
 // z may be a window of a longer buffer: element (b, c, t) at z[b * z_bs + c * z_cs + t]
+// bytes of the fp16 operand planes the wide (> 64 channels) generator stages need for their split-precision ResBlock1 convs
+static size_t generator_planes_bytes(const dtts_config& cfg, int B, int T) {
+    size_t best = 0;
+    int ch = cfg.upsample_initial_channel;
+    long long t = T;
+    for (int i = 0; i < cfg.n_upsamples; ++i) {
+        ch /= 2;
+        t *= cfg.upsample_rates[i];
+        if (ch > 64) best = std::max(best, x3d_bytes(B, round_up(ch, 16), (int)t));
+    }
+    return best ? best + 256 : 0;
+}
+
 // modules.ResBlock1.forward (vqvae/modules/modules.py:315-328): three times x = convs2[l](lrelu(convs1[l](lrelu(x)))) + x with
 // dilations (1, 3, 5) in convs1; leaky-relu prologues and the residual epilogue are fused into the convs.  x is not modified.
-void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, float* out, int ch, const int* lens, int B, int T, hipStream_t s) {
+void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, float* out, int ch, const int* lens, int B, int T, hipStream_t s,
+                          void* xs) {
     auto cp = [&](const float* in, float* o) {
         ConvParams p;
         p.B = B;
@@ -189,21 +220,46 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
         p.pro_slope = 0.1f;
         return p;
     };
+    // wide stages: leaky-relu + split into fp16 planes as one pass, then the dilated split-precision conv (conv_x3d.hip)
+    const bool x3 = xs && rb.c1[0].w3 && vocoder_x3();
+    auto conv3 = [&](const PackedConv& pc, ConvParams p, const float* in) {
+        const int Tp = x3d_tp(T);
+        launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s);
+        p.w3 = pc.w3;
+        p.x3 = xs;
+        p.x3_tp = Tp;
+        p.x3_halo = X3D_HALO;
+        p.bias = pc.b;
+        p.Cin = pc.CinP;
+        p.CinP = pc.CinP;
+        p.Cout = pc.Cout;
+        p.CoutP = pc.CoutP;
+        p.KW = pc.KW;
+        p.pro_act = ACT_NONE;
+        launch_conv_x3d(p, s);
+    };
     const float* cur = x;
     for (int li = 0; li < 3; ++li) {
         const int d = cfg.resblock_dilations[li];
         ConvParams a = cp(cur, tmp);
         a.dil = d;
         a.pad = (rb.k * d - d) / 2;
-        run_conv(rb.c1[li], a, s);
+        if (x3) conv3(rb.c1[li], a, cur);
+        else run_conv(rb.c1[li], a, s);
         ConvParams c = cp(tmp, out);
         c.pad = (rb.k - 1) / 2;
         c.res = cur;
         c.res_bs = (long long)ch * T;
         c.res_cs = T;
-        run_conv(rb.c2[li], c, s);
+        if (x3) conv3(rb.c2[li], c, tmp);
+        else run_conv(rb.c2[li], c, s);
         cur = out;
     }
+}
+
+bool Model::vocoder_x3() const {
+    static const bool env_on = []() { const char* v = getenv("DTTS_VOC_X3"); return !(v && v[0] == '0'); }();
+    return env_on && use_x3();
 }
 
 // unit entry point: dec.resblocks[stage * 3 + branch] on x [B, ch(stage), T]
@@ -212,12 +268,13 @@ void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_
     DTTS_REQUIRE(stage >= 0 && stage < (int)gen_.size() && branch >= 0 && branch < cfg.n_resblock_kernels, "resblock index");
     ArenaUse use_stage_c_arena(ws_voc_);
     const int ch = gen_[stage].cout;
-    ws().ensure(sizeof(float) * (size_t)B * ch * T + 4096);
+    ws().ensure(sizeof(float) * (size_t)B * ch * T + x3d_bytes(B, round_up(ch, 16), T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
     float* tmp = ws().f32((size_t)B * ch * T);
-    resblock1_fwd(gen_[stage].rb[branch], x, tmp, y, ch, dl, B, T, s);
+    void* xs = ws().raw(x3d_bytes(B, round_up(ch, 16), T));
+    resblock1_fwd(gen_[stage].rb[branch], x, tmp, y, ch, dl, B, T, s, xs);
 }
 
 void Model::generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs,
@@ -241,6 +298,8 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     float* T1 = ws().f32(buf);
     float* T2 = ws().f32(buf);
     float* gc = ws().f32((size_t)B * dec_cond_.CoutP);
+    void* planes = nullptr;                            // fp16 operand planes of the wide stages' ResBlock1 convs
+    if (size_t pb = generator_planes_bytes(cfg, B, T)) planes = ws().raw(pb);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -289,7 +348,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
         u.y_cs = Tn;
         run_conv(st.up, u, s);
         // three ResBlock1 branches on T1 -> R[j]
-        for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s);
+        for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s, cn > 64 ? planes : nullptr);
         launch_add3_scale(R[0], R[1], R[2], 1.f / 3.f, X, (long long)B * cn * Tn, s);
         ch = cn;
         Tc = Tn;
@@ -313,7 +372,7 @@ static size_t generator_ws(const dtts_config& cfg, int B, int T) {
         t *= cfg.upsample_rates[i];
         biggest = std::max(biggest, ch * t);
     }
-    return sizeof(float) * (6 * (size_t)B * biggest + (size_t)B * 1024) + 16 * 256;
+    return sizeof(float) * (6 * (size_t)B * biggest + (size_t)B * 1024) + generator_planes_bytes(cfg, B, T) + 16 * 256;
 }
 
 void Model::op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s) {
