@@ -241,7 +241,9 @@ def main():
         voc = {"ms": round(vms, 2), "tflops": round(vf / vms / 1e9, 2), "gbs_algorithmic": round(vb / vms / 1e6, 1),
                "frac_fp32_mfma": round(vf / vms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4), "frac_hbm": round(vb / vms / 1e6 / HBM_PEAK_GBS, 4),
                "note": "whole stage C (ref_enc, enc_p, flow^-1, HiFiGAN) under the hipEvent profiler with launch brackets on every kernel "
-                       "(slower than the unprofiled stage_ms); fp32 MFMA arithmetic"}
+                       "(slower than the unprofiled stage_ms); the ResBlock1 convs of the two wide generator stages run on the split-precision "
+                       "fp16 pipe (conv_x3d), everything else on fp32 MFMA - `frac_fp32_mfma` quotes the fp32-equivalent FLOP/s of the whole "
+                       "stage against the fp32 MFMA peak"}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if dist.get_backend() == "gloo":
