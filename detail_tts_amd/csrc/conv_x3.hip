@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
 }  // namespace
 
 void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* out, hipStream_t s) {
-    DTTS_REQUIRE(CinP % 16 == 0 && CoutP % BM == 0, "split_weights: padding");
+    DTTS_REQUIRE(CinP % 16 == 0 && CoutP % 64 == 0, "split_weights: padding");
     hipLaunchKernelGGL(split_weights_kernel, dim3(cdiv(CoutP, 256), CinP / 8, KW), dim3(256), 0, s, wp, CinP / 8, CoutP,
                        static_cast<uint4*>(out));
     DTTS_CHECK_HIP(hipGetLastError());

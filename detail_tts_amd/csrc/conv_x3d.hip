@@ -19,13 +19,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int NPL = XS_PLANES, NK = 2 * NPL;
-constexpr int BM = 128, BN = X3_BN, XCOLS = 256;
-constexpr int WTILE = NK * BM * 16;                  // 8 KiB
+constexpr int BN = X3_BN, XCOLS = 256;
 constexpr int XTILE = NK * XCOLS * 16;               // 16 KiB
-constexpr int XOFF = 2 * WTILE;
 
-template <int KW>
+// MI: 32-row MFMA blocks per wave: M tile 128 (MI = 2) or 64 (MI = 1: 50-channel stage, CoutP = 64)
+template <int KW, int MI>
 __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
+    constexpr int BM = 64 * MI, WTILE = NK * BM * 16, XOFF = 2 * WTILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
     const int mtiles = p.CoutP / BM, ntiles = (p.Nout + BN - 1) / BN;
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
-    auto w_piece = [&](int j, int c16, int tap, int stage) {            // j = kind * 2 + row half
-        const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
+    auto w_piece = [&](int j, int c16, int tap, int stage) {            // j = kind * MI + 64-row block
+        const int kind = j / MI, pl = kind >> 1, h = kind & 1, rh = j - kind * MI;
         dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * NPL + pl) * p.CoutP + rh * 64, stage * WTILE + kind * (BM * 16) + rh * 1024);
     };
     auto x_piece = [&](int j, int c16, int stage) {                      // j = kind * 4 + column block
@@ -54,18 +54,18 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
         dma(xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + cb * 64, XOFF + stage * XTILE + kind * (XCOLS * 16) + cb * 1024);
     };
 
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
-    f32x16 acc[2][3];
+    const int wm0 = (wave >> 1) * (32 * MI), wn0 = (wave & 1) * 96;
+    f32x16 acc[MI][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // prologue: W of step (block 0, tap 0) and X of block 0
-    w_piece(wave * 2, 0, 0, 0);
-    w_piece(wave * 2 + 1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) w_piece(wave * MI + i, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) x_piece(wave + 4 * k, 0, 0);
     float* bias_s = reinterpret_cast<float*>(smem + XOFF + 2 * XTILE);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // everything issued during the previous step has landed
             __builtin_amdgcn_s_barrier();                                // ... for every wave; and the stages refilled below are free
             const unsigned char* As = smem + (ks & 1) * WTILE + lhi * (BM * 16);
-            hf8 a[2][NPL], bb[3][NPL];
+            hf8 a[MI][NPL], bb[3][NPL];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const unsigned char* xq = Xb + lhi * (XCOLS * 16) + (wn0 + j * 32 + l31 + tap * dil) * 16;
@@ -88,11 +88,9 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
                 for (int pl = 0; pl < NPL; ++pl) bb[j][pl] = *reinterpret_cast<const hf8*>(xq + pl * (2 * XCOLS * 16));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) a[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
-            // next step's W tile (2 pieces per wave) and this wave's share of the next block's X tile (4 pieces spread over the taps),
-            // one LDS-DMA instruction after every three MFMAs
             const bool last_tap = tap == KW - 1;
             const bool next_w = !last_tap || more_blocks;
             const int nc16 = last_tap ? c16 + 1 : c16, ntap = last_tap ? 0 : tap + 1;
@@ -101,15 +99,21 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (slot < 2) {
-                        if (next_w) w_piece(wave * 2 + slot, nc16, ntap, (ks + 1) & 1);
-                    } else if (slot < 6 && more_blocks) {
-                        const int k = slot - 2;                          // this wave's k-th X piece goes out at tap k KW / 4
-                        if (tap == k * KW / 4) x_piece(wave + 4 * k, c16 + 1, (c16 + 1) & 1);
+                    // one LDS-DMA issue point after every three MFMAs (3 MI slots per step): the wave's MI W pieces of the next step first,
+                    // then its 4 X pieces of the next block, piece k at tap k KW / 4
+                    if (slot < MI) {
+                        if (next_w) w_piece(wave * MI + slot, nc16, ntap, (ks + 1) & 1);
+                    }
+                    if (more_blocks) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int xslot = MI == 2 ? 2 + k : ((KW == 3 && k == 1) ? 2 : 1);
+                            if (tap == k * KW / 4 && slot == xslot) x_piece(wave + 4 * k, c16 + 1, (c16 + 1) & 1);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     ++slot;
@@ -119,16 +123,16 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue (as conv_x3.hip, EPI 0 / 1): bias, activation / out_scale, residual, var-len masking
-    float bv[2][16];
+    float bv[MI][16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[i][r] = bias_s[wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
     float* yb = p.y + (long long)b * p.y_bs;
     const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
     const bool epi = p.epi_act != ACT_NONE || p.out_scale != 1.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int n = n0 + wn0 + j * 32 + l31;
@@ -196,26 +200,35 @@ void launch_split_planes_ex(const float* x, long long x_bs, int x_cs, int act, f
 void launch_conv_x3d(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.w3 && p.x3 && p.y && p.x3_tp > 0, "conv_x3d: operands");
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
-    DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3d: channel padding");
+    DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % 64 == 0, "conv_x3d: channel padding");
     DTTS_REQUIRE(p.stride == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd && p.dil >= 1, "conv_x3d: unsupported conv form");
     DTTS_REQUIRE(p.KW == 3 || p.KW == 7 || p.KW == 11, "conv_x3d: kernel width 3, 7 or 11");
     DTTS_REQUIRE(BN + (p.KW - 1) * p.dil <= XCOLS && p.pad <= p.x3_halo, "conv_x3d: dilated halo exceeds the staged tile");
     DTTS_REQUIRE(round_up(p.Nout, BN) + (XCOLS - BN) + p.x3_halo <= p.x3_tp, "conv_x3d: time padding");
-    constexpr size_t lds = XOFF + 2 * XTILE + BM * sizeof(float);
+    const int MI = p.CoutP % 128 == 0 ? 2 : 1, BM = 64 * MI;
+    const size_t lds = (size_t)2 * NK * BM * 16 + 2 * XTILE + BM * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3d_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3d_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3d_kernel<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int lmax = 2 * NK * 128 * 16 + 2 * XTILE + 128 * (int)sizeof(float);
+        const void* fns[] = {reinterpret_cast<const void*>(conv_x3d_kernel<3, 2>), reinterpret_cast<const void*>(conv_x3d_kernel<7, 2>),
+                             reinterpret_cast<const void*>(conv_x3d_kernel<11, 2>), reinterpret_cast<const void*>(conv_x3d_kernel<3, 1>),
+                             reinterpret_cast<const void*>(conv_x3d_kernel<7, 1>), reinterpret_cast<const void*>(conv_x3d_kernel<11, 1>)};
+        for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lmax));
         attr = true;
     }
     const dim3 grid((unsigned)((long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B));
     const double cols = (double)p.B * p.Nout;
-    ProfScope ps("conv_x3d_kernel<128,192>", 2.0 * p.Cout * p.Cin * p.KW * cols,
+    ProfScope ps(MI == 2 ? "conv_x3d_kernel<128,192>" : "conv_x3d_kernel<64,192>", 2.0 * p.Cout * p.Cin * p.KW * cols,
                  4.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 4.0 * (double)p.Cout * p.Cin * p.KW, s);
-    if (p.KW == 3) hipLaunchKernelGGL(conv_x3d_kernel<3>, grid, dim3(256), lds, s, p);
-    else if (p.KW == 7) hipLaunchKernelGGL(conv_x3d_kernel<7>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(conv_x3d_kernel<11>, grid, dim3(256), lds, s, p);
+#define DTTS_LAUNCH_X3D(K)                                                                            \
+    do {                                                                                              \
+        if (MI == 2) hipLaunchKernelGGL((conv_x3d_kernel<K, 2>), grid, dim3(256), lds, s, p);          \
+        else hipLaunchKernelGGL((conv_x3d_kernel<K, 1>), grid, dim3(256), lds, s, p);                  \
+    } while (0)
+    if (p.KW == 3) DTTS_LAUNCH_X3D(3);
+    else if (p.KW == 7) DTTS_LAUNCH_X3D(7);
+    else DTTS_LAUNCH_X3D(11);
+#undef DTTS_LAUNCH_X3D
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

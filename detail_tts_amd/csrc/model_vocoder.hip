@@ -86,10 +86,10 @@ void Model::build_vocoder(hipStream_t stream) {
         gen_.push_back(g);
     }
     dec_post_ = conv("dec.conv_post", ch, 1, 7, false);
-    // split-precision copies of the ResBlock1 weights of the wide generator stages (conv_x3d.hip): channels > 64 (CoutP a multiple of 128)
+    // split-precision copies of the ResBlock1 weights of the wide generator stages (conv_x3d.hip): channels > 32 (CoutP a multiple of 64)
     std::vector<PackedConv*> wide;
     for (auto& g : gen_)
-        if (g.cout > 64)
+        if (g.cout > 32)
             for (int j = 0; j < cfg.n_resblock_kernels; ++j)
                 if (g.rb[j].k == 3 || g.rb[j].k == 7 || g.rb[j].k == 11)
                     for (int l = 0; l < 3; ++l) { wide.push_back(&g.rb[j].c1[l]); wide.push_back(&g.rb[j].c2[l]); }
@@ -97,7 +97,7 @@ void Model::build_vocoder(hipStream_t stream) {
     for (PackedConv* pc : wide) total += (size_t)pc->KW * pc->CinP * pc->CoutP * 4 + 256;
     w3_voc_.ensure(total + 4096);
     for (PackedConv* pc : wide) {
-        if (pc->CinP % 16 || pc->CoutP % 128) continue;
+        if (pc->CinP % 16 || pc->CoutP % 64) continue;
         void* dst = w3_voc_.raw((size_t)pc->KW * pc->CinP * pc->CoutP * 4);
         launch_split_weights(pc->w, pc->KW, pc->CinP, pc->CoutP, dst, stream);
         pc->w3 = dst;
@@ -194,7 +194,7 @@ static size_t generator_planes_bytes(const dtts_config& cfg, int B, int T) {
     for (int i = 0; i < cfg.n_upsamples; ++i) {
         ch /= 2;
         t *= cfg.upsample_rates[i];
-        if (ch > 64) best = std::max(best, x3d_bytes(B, round_up(ch, 16), (int)t));
+        if (ch > 32) best = std::max(best, x3d_bytes(B, round_up(ch, 16), (int)t));
     }
     return best ? best + 256 : 0;
 }
@@ -348,7 +348,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
         u.y_cs = Tn;
         run_conv(st.up, u, s);
         // three ResBlock1 branches on T1 -> R[j]
-        for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s, cn > 64 ? planes : nullptr);
+        for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s, cn > 32 ? planes : nullptr);
         launch_add3_scale(R[0], R[1], R[2], 1.f / 3.f, X, (long long)B * cn * Tn, s);
         ch = cn;
         Tc = Tn;

@@ -199,7 +199,7 @@ def test_generator_stream_equals_full_and_wav_writer(weights, tmp_path):
     assert np.abs(pcm / 32767.0 - full[0, 0].clamp(-1, 1).cpu().numpy()).max() < 1.0 / 32767 + 1e-6
 
 
-@pytest.mark.parametrize("stage,branch", [(0, 0), (0, 2), (1, 1), (3, 2), (4, 0)])
+@pytest.mark.parametrize("stage,branch", [(0, 0), (0, 2), (1, 1), (2, 0), (2, 1), (2, 2), (3, 2), (4, 0)])
 def test_unit_resblock1_vs_oracle(rt, weights, stage, branch):
     """dtts_op_resblock1: one HiFiGAN ResBlock1 (kernel 3 / 7 / 11, dilations 1, 3, 5) against the oracle, ragged batch."""
     from oracle import vocoder as V
