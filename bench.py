@@ -102,6 +102,29 @@ def decode_bytes_per_token(cfg, B, lp_mean, n_codes):
     return weights, kv
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command as N ranks (one process per GPU, LOCAL_RANK -> device) under
+    `torch.distributed.run` on 127.0.0.1 and hand its exit code back.  Under the driver's own `torch.distributed.run` WORLD_SIZE is set
+    and this is never reached."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    if env.get("DTTS_BENCH_ONE_GPU") != "1" and env.get("DTTS_BENCH_LAUNCH_ONLY") != "1":
+        import torch
+        if torch.cuda.device_count() < n:
+            raise SystemExit(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} device(s) are visible")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,22 +137,42 @@ def main():
     args = ap.parse_args()
     n_codes = args.codes
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))         # `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {args.gpus})")
+    one_gpu = os.environ.get("DTTS_BENCH_ONE_GPU") == "1"               # the N>1 path with every rank on GPU 0 (tests on a 1-GPU box)
+    backend = os.environ.get("DTTS_BENCH_BACKEND", "nccl")              # "gloo": host-staged broadcast (tests); "nccl" is RCCL
+    if os.environ.get("DTTS_BENCH_LAUNCH_ONLY") == "1":                 # launcher check (CPU tests): rendezvous, count the ranks, leave
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([1.0])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launched_ranks": int(t.item()), "n_gpus": args.gpus, "local_ranks_seen": world}))
+        dist.destroy_process_group()
+        return
+    if one_gpu:
+        local = 0
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local} but only {ndev} device(s) are visible (--gpus {args.gpus})")
+    torch.cuda.set_device(local)
+    # DTTS_BENCH_FORCE_DIST=1: take the process-group path at world size 1 too (RCCL init + broadcast + reductions on a 1-GPU box)
+    multi = world > 1 or os.environ.get("DTTS_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("DTTS_BENCH_BACKEND", "nccl")          # "gloo" + DTTS_BENCH_ONE_GPU=1: the N>1 path on one GPU (tests)
-        if os.environ.get("DTTS_BENCH_ONE_GPU") == "1":
-            local = 0
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
     from detail_tts_amd.sharding import gather_results, shard_utterances
@@ -145,13 +188,22 @@ def main():
                 zero[k[:-2] + "_v"][...] = 1.0      # avoid 0/0 in the fold
         W = select_inference_params(zero)
     model = SynthesizerTrn(W, folded=True, device=dev)
-    if world > 1:
+    bcast = None
+    if multi:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
         if dist.get_backend() == "gloo":            # gloo moves host tensors: stage the blob through the host (tests only)
             host = model.rt.blob.cpu()
             dist.broadcast(host, src=0)
             model.rt.blob.copy_(host)
         else:
             model.rt.broadcast_weights(src=0)       # one RCCL broadcast of the 1.07 GB blob over xGMI
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        nbytes = model.rt.blob.numel() * model.rt.blob.element_size()
+        bcast = {"backend": dist.get_backend(), "bytes": int(nbytes), "ms": round(tb * 1e3, 2), "GBps": round(nbytes / tb / 1e9, 2),
+                 "note": "first collective of the process group: includes communicator set-up"}
         model.rt.rebind()                           # rebuild the device-side tables (timestep MLPs, LN-algebra vectors, split planes)
         dist.barrier()
     model.rt.set_option("gpt_graph", 1 if os.environ.get("DTTS_BENCH_GPT_GRAPH") == "1" else 0)
@@ -197,7 +249,7 @@ def main():
 
     run_steps(0, args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     model.stage_ms = {}
     step(99, pipelined=False)                # one untimed, un-pipelined pass with per-stage hipEvents (adds a sync, so not part of the timed region)
@@ -209,13 +261,13 @@ def main():
     model.rt.profile_sampling(PROF_EVERY)
     model.rt.profile_enable(os.environ.get("DTTS_BENCH_NO_PROF") != "1")
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     t0 = time.perf_counter()
     outs = run_steps(100, args.steps)
     wavs, lens = [o[0] for o in outs], outs[-1][1]
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = model.rt.profile_report()
@@ -244,15 +296,18 @@ def main():
                        "(slower than the unprofiled stage_ms); the ResBlock1 convs of the two wide generator stages run on the split-precision "
                        "fp16 pipe (conv_x3d), everything else on fp32 MFMA - `frac_fp32_mfma` quotes the fp32-equivalent FLOP/s of the whole "
                        "stage against the fp32 MFMA peak"}
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    rank_ms = [dt / args.steps * 1e3]
+    if multi:
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = dt
         if dist.get_backend() == "gloo":
             t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [round(float(v) / args.steps * 1e3, 2) for v in t.tolist()]
+        dt = float(t.max().item())                                # the job's time = the slowest rank's
         gather_results([(i, rank) for i in mine], world)          # every utterance accounted for exactly once
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
     audio_per_utt = n_codes * 1024 / 24000.0
@@ -325,6 +380,7 @@ def main():
                    "pipelining": ("stage A of batch i + 1 on a high-priority HIP stream under stage B of batch i, stage C of batch i under stage B of "
                                   "batch i + 1 (SynthesizerTrn.infer_stream)") if pipeline else
                                  ("stage C of batch i on a second HIP stream under the GPT decode of batch i + 1" if overlap else "none")},
+        "rank_ms_per_step": rank_ms, "weight_broadcast": bcast,
         "stage_ms": stage_ms,
         "roofline": roof,
         "roofline_attention": roof_att,
@@ -337,7 +393,7 @@ def main():
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W)
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

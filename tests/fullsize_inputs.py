@@ -26,3 +26,14 @@ def sub(a, g, ch_stride=None):
     """[C, T] -> the fixture's (strided block, tail block)"""
     cs = int(g["ch_stride"]) if ch_stride is None else ch_stride
     return a[::cs, ::int(g["t_stride"])], a[:, -int(g["tail"]):]
+
+
+def e2e_inputs(seed=21):
+    """Inputs of tests/golden/e2e_fullsize.npz / gpt_generate_fullsize.npz (make_golden_e2e_fullsize.py): the headline
+    configuration - 10 s prompt (936 frames), 60 text ids + the appended 0 (api.py:24-25), 234 forced codes."""
+    rs = np.random.RandomState(seed)
+    d = {"seed_inputs": seed}
+    d["refer"] = (rs.randn(1, 128, T) * 2 - 5).astype(np.float32)
+    d["text"] = np.concatenate([rs.randint(3, 255, (1, L_TEXT)), [[0]]], 1).astype(np.int32)
+    d["codes"] = rs.randint(0, 8192, (1, N_CODES)).astype(np.int64)
+    return d

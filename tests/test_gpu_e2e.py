@@ -173,17 +173,57 @@ def test_multi_rank_bench_path_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DTTS_BENCH_ONE_GPU="1", DTTS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     probe = str(tmp_path / "probe")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    # no launcher around it: `python bench.py --gpus 2` re-execs itself as 2 ranks (bench.py::launch_ranks)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--batch", "2", "--codes", "12", "--no-cpu-baseline", "--probe-out", probe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "replica x2"
+    assert len(line["rank_ms_per_step"]) == 2 and line["weight_broadcast"]["backend"] == "gloo" and line["weight_broadcast"]["bytes"] > 1e9
     h = [json.load(open(f"{probe}.rank{k}.json")) for k in range(2)]
     assert h[0]["blob_sha256"] == h[1]["blob_sha256"]
     assert h[0]["wav_sha256"] == h[1]["wav_sha256"] and h[0]["wav_rms"] > 1e-4
     assert h[0]["utterances"] != h[1]["utterances"]                     # disjoint shards of the global batch
+
+
+def _bench_nccl(tmp_path, n):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DTTS_BENCH_BACKEND="nccl", MASTER_PORT=str(29300 + os.getpid() % 200))
+    if n == 1:
+        env["DTTS_BENCH_FORCE_DIST"] = "1"
+    probe = str(tmp_path / "probe")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--batch", "2", "--codes", "12",
+           "--no-cpu-baseline", "--probe-out", probe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["value"] > 0 and line["weight_broadcast"]["backend"] == "nccl"
+    return line, [json.load(open(f"{probe}.rank{k}.json")) for k in range(n)]
+
+
+def test_bench_rccl_process_group_on_one_device(tmp_path):
+    """The RCCL branch of bench.py on the one GPU a test box has (DTTS_BENCH_FORCE_DIST: world size 1): `init_process_group("nccl",
+    device_id=...)`, `Runtime.broadcast_weights` on the DEVICE blob, rebind, the barriers and the device-tensor all-reduce of the
+    timings all execute through RCCL; the re-bound model still produces a waveform."""
+    line, h = _bench_nccl(tmp_path, 1)
+    assert h[0]["wav_rms"] > 1e-4 and len(line["rank_ms_per_step"]) == 1
+
+
+def test_bench_rccl_two_devices(tmp_path):
+    """BASELINE configs[3] in small: `python bench.py --gpus 2` over RCCL/xGMI when the box has two devices (skipped on 1-GPU boxes):
+    rank 1 starts from zero weights and must reproduce rank 0's probe waveform bit for bit after the broadcast."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible devices")
+    line, h = _bench_nccl(tmp_path, 2)
+    assert h[0]["blob_sha256"] == h[1]["blob_sha256"] and h[0]["wav_sha256"] == h[1]["wav_sha256"]
+    assert h[0]["utterances"] != h[1]["utterances"]
 
 
 def test_long_form_batch4_streaming_vocoder(model):
