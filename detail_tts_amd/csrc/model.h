@@ -2,6 +2,9 @@
 // Everything here enqueues work on the caller's HIP stream; no hidden synchronisation except
 // workspace growth (hipMalloc) which only happens when a call needs more memory than any before it.
 #pragma once
+#include <map>
+#include <memory>
+#include <thread>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -310,9 +313,21 @@ private:
     Arena ws_voc_;    // stage C's own scratch (stands in for the duration of a vocoder call)
     Arena ws_gpt_;    // stage A's session prefill scratch: the next batch's decode session may run under this batch's diffusion
     Arena persist_;   // tables built at bind time
-    int* lens_dev_ = nullptr;   // small ring of device int buffers
-    size_t lens_off_ = 0;
-    std::mutex ints_mu_;        // upload_ints is called from both issuing threads
+    // upload_ints: one ring PER ISSUING HOST THREAD (device ints + a pinned host mirror at the same offsets, 16 segments).  A segment
+    // is reused only after everything enqueued so far on the streams that consumed it has completed (event per stream at re-entry);
+    // with a ring per thread the consumers of a table were enqueued by program order before the thread laps its own ring.
+    struct IntRing {
+        static constexpr int SEGS = 16;
+        int* dev = nullptr;
+        int* pinned = nullptr;
+        size_t off = 0;
+        int seg = 0;
+        std::vector<hipStream_t> users[SEGS];   // streams whose launches read tables of this segment (current lap)
+        hipEvent_t ev = nullptr;
+    };
+    std::map<std::thread::id, std::unique_ptr<IntRing>> int_rings_;
+    std::mutex ints_mu_;        // guards the map only; a ring is touched by its own thread
+    IntRing& int_ring();
 };
 
 }  // namespace dtts

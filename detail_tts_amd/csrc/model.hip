@@ -1,5 +1,7 @@
 // Model runtime: weight lookup, workspace, diffusion-stage orchestration (see model.h).
 #include "model.h"
+#include <algorithm>
+#include <cstring>
 #include "conv_x3.h"
 #include "prof.h"
 
@@ -39,32 +41,66 @@ void* Arena::raw(size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------ Model
-static constexpr size_t INT_RING_BYTES = 1u << 20;
-Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) {
-    DTTS_CHECK_HIP(hipSetDevice(dev));
-    DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&lens_dev_), INT_RING_BYTES));
-}
+static constexpr size_t INT_RING_BYTES = 1u << 20;      // per issuing thread
+Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) { DTTS_CHECK_HIP(hipSetDevice(dev)); }
 
 Model::~Model() {
     gpt_drop_graphs();
-    if (lens_dev_) (void)hipFree(lens_dev_);
+    for (auto& kv : int_rings_) {
+        IntRing& r = *kv.second;
+        if (r.dev) (void)hipFree(r.dev);
+        if (r.pinned) (void)hipHostFree(r.pinned);
+        if (r.ev) (void)hipEventDestroy(r.ev);
+    }
     for (hipStream_t st : {sx_[0], sx_[1], sx_[2], sg_})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : {ev_fork_, ev_joinx_[0], ev_joinx_[1], ev_joinx_[2], ev_g0_, ev_g1_})
         if (e) (void)hipEventDestroy(e);
 }
 
-const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
-    // ring buffer of small host -> device int tables (lengths, ids, maps): 1 MiB, so an entry stays valid for the next >= 192 K ints
-    // of uploads - far beyond what one entry point uploads while its kernels are in flight (the largest: B * max_text ids of a GPT
-    // prefill = 6.4 K, 2 J (B + Nu) ints per integrator chunk)
-    const size_t cap = INT_RING_BYTES / sizeof(int);
-    DTTS_REQUIRE((size_t)n <= cap / 4, "int table too large for the upload ring");
+Model::IntRing& Model::int_ring() {
     std::lock_guard<std::mutex> lk(ints_mu_);
-    if (lens_off_ + n > cap) lens_off_ = 0;
-    int* dst = lens_dev_ + lens_off_;
-    lens_off_ += (size_t)((n + 15) & ~15);
-    DTTS_CHECK_HIP(hipMemcpyAsync(dst, host, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    auto& slot = int_rings_[std::this_thread::get_id()];
+    if (!slot) {
+        slot.reset(new IntRing());
+        DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&slot->dev), INT_RING_BYTES));
+        DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot->pinned), INT_RING_BYTES, hipHostMallocDefault));
+        DTTS_CHECK_HIP(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+    }
+    return *slot;
+}
+
+const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
+    // Small host -> device int tables (lengths, ids, maps).  The copy goes through the thread's pinned mirror, so hipMemcpyAsync is
+    // truly asynchronous (a pageable source makes the runtime stage - and wait - on the launch stream).  Lifetime: a table is read by
+    // launches the calling thread enqueues on `s` after this call; its segment is handed out again only after an event recorded on
+    // every stream that used it - at the time of reuse, i.e. behind those launches - has completed.
+    constexpr size_t cap = INT_RING_BYTES / sizeof(int), seg_ints = cap / IntRing::SEGS;
+    DTTS_REQUIRE(n >= 0 && (size_t)n <= cap / 4, "int table too large for the upload ring");
+    IntRing& r = int_ring();
+    const size_t len = (size_t)((n + 15) & ~15);
+    if (r.off + len > cap) r.off = 0;
+    const int first = (int)(r.off / seg_ints), last = (int)((r.off + (len ? len - 1 : 0)) / seg_ints);
+    for (int g = first; g <= last; ++g) {
+        if (g == r.seg && r.off != (size_t)g * seg_ints) continue;        // still inside the segment we are filling
+        if (g != r.seg || r.off == (size_t)g * seg_ints) {               // entering segment g: retire its previous lap
+            for (hipStream_t u : r.users[g]) {
+                DTTS_CHECK_HIP(hipEventRecord(r.ev, u));
+                DTTS_CHECK_HIP(hipEventSynchronize(r.ev));
+            }
+            r.users[g].clear();
+            r.seg = g;
+        }
+    }
+    for (int g = first; g <= last; ++g)
+        if (std::find(r.users[g].begin(), r.users[g].end(), s) == r.users[g].end()) r.users[g].push_back(s);
+    int* dst = r.dev + r.off;
+    int* stage = r.pinned + r.off;
+    r.off += len;
+    if (n > 0) {
+        std::memcpy(stage, host, sizeof(int) * (size_t)n);
+        DTTS_CHECK_HIP(hipMemcpyAsync(dst, stage, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    }
     return dst;
 }
 
@@ -690,7 +726,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     int ci = 0;
     for (int k0 = 0; k0 < NS; k0 += J, ++ci) {
         const Lane& L = lanes[two ? (ci & 1) : 0];
-        Profiler::get().gate = ((ci / 2) % Profiler::get().step_every) == 0;      // both lanes of a chunk pair, or neither
+        Profiler::gate() = ((ci / 2) % Profiler::get().step_every) == 0;      // both lanes of a chunk pair, or neither
         const int jn = std::min(J, NS - k0), nb = jn * Bi;
         for (int j = 0; j < jn; ++j)
             for (int b = 0; b < Bi; ++b) {
@@ -712,7 +748,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         DTTS_CHECK_HIP(hipEventRecord(ev_joinx_[0], sx_[0]));
         DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_joinx_[0], 0));
     }
-    Profiler::get().gate = true;
+    Profiler::gate() = true;
     ws().rewind(mark);
 }
 
@@ -798,7 +834,7 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     const size_t mark = ws().mark();
     for (int k = 0; k < n_steps; ++k) {
         const int i = n_steps_ - 1 - k;
-        Profiler::get().gate = (k % Profiler::get().step_every) == 0;
+        Profiler::gate() = (k % Profiler::get().step_every) == 0;
         ws().rewind(mark);                              // the forward's scratch is re-carved every step
         diff_forward_pair(x, cbuf0, lens2, pl.lens_i, pl.umap, B, pl.Nu, T, i, out2, s,
                           integ_all ? integ_all + (size_t)k * Bi * C * T : nullptr);
@@ -806,7 +842,7 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
         launch_diff_update(x, xbs, T, out2, (long long)OC * T, T, lens2, T, B, MC, step_coefs_[i], seed, sids, i,
                            step_noise ? step_noise + (size_t)k * B * MC * T : nullptr, (denorm && last) ? 1 : 0, s);
     }
-    Profiler::get().gate = true;
+    Profiler::gate() = true;
 }
 
 // GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at one sampling step, x in place

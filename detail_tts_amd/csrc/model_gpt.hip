@@ -353,8 +353,8 @@ void Model::gpt_step_launches(hipStream_t s) {
 
 void Model::gpt_decode_step(hipStream_t s) {
     DTTS_REQUIRE(gs_.active, "dtts_gpt_decode_step: no session (call dtts_gpt_prefill first)");
-    gpt_step_launches(s);
-    gs_.steps += 1;
+    gpt_step_launches(s);                 // beyond max_generate_length the kernels are device-side no-ops (GptCtl::max_steps)
+    gs_.steps = std::min(gs_.steps + 1, gs_.G);
 }
 
 void Model::gpt_drop_graphs() {
@@ -434,11 +434,16 @@ int Model::gpt_all_finished(hipStream_t s) {
 // results: codes include the stop token; rows that finished early are padded with 8193 (HF pad_token_id).  Synchronises.
 void Model::gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s) {
     DTTS_REQUIRE(gs_.active, "dtts_gpt_finish: no session");
-    const int B = gs_.B, G = gs_.G, Ga = gs_.G, done = gs_.steps;
+    const int B = gs_.B, G = gs_.G, Ga = gs_.G;
     std::vector<int> hc((size_t)B * Ga, 8193);
+    GptCtl hctl;
     DTTS_CHECK_HIP(hipMemcpyAsync(hc.data(), gs_.codes, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, s));
+    // the DEVICE step counters are the truth: the sampler advances them, also when the steps were replayed from a caller-owned graph
+    // (dtts_gpt_decode_step captured once, replayed n times: the host counter gs_.steps saw one call); steps >= G were device no-ops
+    DTTS_CHECK_HIP(hipMemcpyAsync(&hctl, gs_.ctl, sizeof(GptCtl), hipMemcpyDeviceToHost, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
     for (int b = 0; b < B; ++b) {
+        const int done = std::max(0, std::min(hctl.step[b], G));
         int n = done;
         for (int t = 0; t < done; ++t)
             if (hc[(size_t)b * Ga + t] == 8193) { n = t + 1; break; }

@@ -74,6 +74,7 @@ void Model::build_vocoder(hipStream_t stream) {
         g.cout = ch / 2;
         g.up = conv("dec.ups." + std::to_string(i), ch, u * (ch / 2), dmax - dmin + 1);
         ch /= 2;
+        DTTS_REQUIRE(cfg.n_resblock_kernels == 3, "the generator is built for 3 ResBlock1 branches per stage (resblock_kernel_sizes)");
         for (int j = 0; j < cfg.n_resblock_kernels; ++j) {
             ResBlock1W& r = g.rb[j];
             r.k = cfg.resblock_kernels[j];

@@ -28,7 +28,12 @@ public:
     }
     bool on = false;
     bool all = false;        // also bracket the bandwidth-only helper kernels (flops == 0); off in bench.py: fewer events
-    bool gate = true;        // false inside the sampling steps dtts_profile_sampling skips
+    // false inside the sampling steps dtts_profile_sampling skips.  Per THREAD: only the thread issuing dtts_diff_sample is gated, the
+    // stage-A thread of infer_stream keeps bracketing its launches ("launches outside dtts_diff_sample are always bracketed").
+    static bool& gate() {
+        static thread_local bool g = true;
+        return g;
+    }
     int step_every = 1;
     // events are created here, outside any timed region
     void reserve(size_t n) {
@@ -41,7 +46,7 @@ public:
     // begin / collect take the lock: a handle may be driven from two host threads (include/detail_hip.h, "Threads"), and two handles
     // from any.  begin returns the scope's stop event (nullptr: not recorded); each ProfScope lives on one thread.
     hipEvent_t begin(const char* tag, double flops, double bytes, hipStream_t s) {
-        if (!on || !gate || !(all || flops > 0.0)) return nullptr;
+        if (!on || !gate() || !(all || flops > 0.0)) return nullptr;
         std::lock_guard<std::mutex> lk(mu_);
         if (!base_) {
             (void)hipEventCreate(&base_);

@@ -61,8 +61,8 @@ class Runtime:
         c.inter_channels, c.hidden_channels, c.filter_channels = v["inter_channels"], v["hidden_channels"], v["filter_channels"]
         c.enc_heads, c.enc_layers, c.gin_channels = v["n_heads"], v["n_layers"], v["gin_channels"]
         c.upsample_initial_channel, c.n_upsamples = v["upsample_initial_channel"], len(v["upsample_rates"])
-        if c.n_upsamples > 8 or len(v["resblock_kernel_sizes"]) > 4 or str(v.get("resblock", "1")) != "1":
-            raise DttsError("vaegan config outside what libdetail_hip supports (<= 8 upsampling stages, <= 4 ResBlock1 kernels)")
+        if c.n_upsamples > 8 or len(v["resblock_kernel_sizes"]) != 3 or str(v.get("resblock", "1")) != "1":
+            raise DttsError("vaegan config outside what libdetail_hip supports (<= 8 upsampling stages, exactly 3 ResBlock1 kernels per stage)")
         if any(list(d) != list(v["resblock_dilation_sizes"][0]) for d in v["resblock_dilation_sizes"]) or len(v["resblock_dilation_sizes"][0]) != 3:
             raise DttsError("vaegan config: the ResBlock1 branches must share one set of 3 dilations")
         for i, (r, k) in enumerate(zip(v["upsample_rates"], v["upsample_kernel_sizes"])):

@@ -57,3 +57,18 @@ def test_vocoder_T936(weights, I, F):
     assert wav.shape[0] == 256 * T
     r = float(np.sqrt(np.mean((wav[::97].astype(np.float64) - F["voc_wav_s"]) ** 2)))
     assert r < 2e-5 and float(F["voc_wav_rms"]) > 1000 * r
+
+
+def test_oracle_free_sampling_234_tokens_vs_reference_hf_loop(weights, golden):
+    """oracle/gpt.py::generate (KV cache) vs the reference's own uncached HF sampling loop over 234 tokens at the 936-frame prompt
+    (gpt_generate_fullsize.npz): identical codes, or a first divergence on a CDF edge (margin < 1e-6)."""
+    from fullsize_inputs import e2e_inputs
+    from oracle import gpt as G
+    g, I = golden("gpt_generate_fullsize"), e2e_inputs()
+    codes = G.generate(weights, I["refer"], [I["refer"].shape[2]], I["text"].astype(np.int64), int(g["seed"]), [int(g["sample_id"])],
+                       max_generate_length=g["codes"].shape[1], suppress_eos=True)
+    ref = g["codes"][0]
+    got = codes[0][: ref.size]
+    if not np.array_equal(got, ref):
+        k = int(np.nonzero(got != ref)[0][0])
+        assert float(g["f64_margins"][k]) < 1e-6, (k, got[k], ref[k], float(g["f64_margins"][k]))
