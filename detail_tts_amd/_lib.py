@@ -49,6 +49,7 @@ SIGNATURES = {
     "dtts_vq_encode": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dtts_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dtts_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dtts_profile_enable": (C.c_int, [C.c_int]),
     "dtts_profile_sampling": (C.c_int, [C.c_int]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "dtts_op_resblock": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_resblock1": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_wn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dtts_op_enc_p": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dtts_op_conv1d": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dtts_op_philox_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_int, C.c_int, C.c_void_p]),

@@ -60,6 +60,12 @@ int dtts_op_wn(dtts_handle* h, int flow, const float* hidden, const float* g, co
     DTTS_API_END(h)
 }
 
+int dtts_op_enc_p(dtts_handle* h, const float* mel, const int* lens, int B, int T, float* m_p, float* logs_p, void* stream) {
+    DTTS_API_BEGIN
+    h->m->op_enc_p(mel, lens, B, T, m_p, logs_p, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
 int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
                    int B, float* mel_out, void* stream) {
     DTTS_API_BEGIN
@@ -84,6 +90,14 @@ int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int 
                          void* stream) {
     DTTS_API_BEGIN
     h->m->mel_spectrogram(wav, lens, B, L, n_fft, hop, mel_out, Tmax, (hipStream_t)stream);
+    DTTS_API_END(h)
+}
+
+int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, int L, int n_fft, int hop, float* spec_out, int Tmax,
+                     void* stream) {
+    DTTS_API_BEGIN
+    if (!spec_out) throw dtts::Error(-2, "dtts_spectrogram: spec_out is null");
+    h->m->mel_spectrogram(wav, lens, B, L, n_fft, hop, nullptr, Tmax, (hipStream_t)stream, spec_out);
     DTTS_API_END(h)
 }
 

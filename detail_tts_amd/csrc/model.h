@@ -172,12 +172,16 @@ public:
     void op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
     void op_resblock1(int stage, int branch, const float* x, const int* lens_host, int B, int T, float* y, hipStream_t s);
     void op_wn(int flow, const float* h, const float* g, const int* lens_host, int B, int T, float* out, hipStream_t s);
+    void op_enc_p(const float* mel, const int* lens_host, int B, int T, float* m_p, float* logs_p, hipStream_t s);
+    void enc_p_fwd(const float* mel, const int* dl, int B, int T, float* x, float* y, float* qkv, float* att, float* ffn, float* relk, float* ml,
+                   float* stats, hipStream_t s);
     // ---- VQ decode path (infer_gpt)
     void vq_decode(const int* codes_host, const int* ncodes_host, int nmax, const float* refer, const int* refer_lens_host, int Tr,
                    int B, float* mel_out, hipStream_t s);
     // ---- prompt front-end
     void resample(const float* x, int B, int L, const float* kernel, int orig, int neu, int width, float* y, int Lout, hipStream_t s);
-    void mel_spectrogram(const float* wav, const int* lens_host, int B, int L, int n_fft, int hop, float* mel_out, int Tmax, hipStream_t s);
+    void mel_spectrogram(const float* wav, const int* lens_host, int B, int L, int n_fft, int hop, float* mel_out, int Tmax, hipStream_t s,
+                         float* spec_out = nullptr);
     // SynthesizerTrn.encode: mel [B,128,T] -> codes DEVICE int32 [B][nmax] (nmax = ceil(ceil(T/2)/2)), optional x_vq [B,768,nmax]
     void vq_encode(const float* mel, const int* lens_host, int B, int T, int* codes_out, float* xvq_out, hipStream_t s);
     // ---- unit ops used by the parity tests

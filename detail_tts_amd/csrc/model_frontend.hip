@@ -63,7 +63,8 @@ void Model::resample(const float* x, int B, int L, const float* kernel, int orig
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
-void Model::mel_spectrogram(const float* wav, const int* lens_host, int B, int L, int n_fft, int hop, float* mel_out, int Tmax, hipStream_t s) {
+void Model::mel_spectrogram(const float* wav, const int* lens_host, int B, int L, int n_fft, int hop, float* mel_out, int Tmax, hipStream_t s,
+                            float* spec_out) {
     DTTS_REQUIRE(bound_ && has_frontend_, "front-end matrices not bound");
     DTTS_REQUIRE(n_fft == fe_nfft_ && hop > 0 && hop < n_fft && (n_fft - hop) % 2 == 0, "front-end geometry does not match the packed DFT matrix");
     const int T = L / hop, nf = n_fft / 2 + 1, pad = (n_fft - hop) / 2;
@@ -87,6 +88,11 @@ void Model::mel_spectrogram(const float* wav, const int* lens_host, int B, int L
     run_conv(fe_dft_, p, s);
     hipLaunchKernelGGL(magnitude_kernel, dim3(cdiv(T, 256), nf, B), dim3(256), 0, s, S, nf, T, M);
     DTTS_CHECK_HIP(hipGetLastError());
+    if (spec_out) {          // spectrogram_torch (vqvae/utils/data_utils.py:56-87): the linear magnitudes [B, n_fft/2+1, Tmax]
+        DTTS_CHECK_HIP(hipMemcpy2DAsync(spec_out, sizeof(float) * (size_t)Tmax, M, sizeof(float) * (size_t)T, sizeof(float) * (size_t)T,
+                                        (size_t)B * nf, hipMemcpyDeviceToDevice, s));
+        if (!mel_out) return;
+    }
     ConvParams q = cp(M, nf, mel_out, cfg.mel_channels, B, T, T, dtl);
     q.y_bs = (long long)cfg.mel_channels * Tmax;
     q.y_cs = Tmax;

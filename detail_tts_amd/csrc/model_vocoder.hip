@@ -462,46 +462,12 @@ void Model::op_wn(int flow, const float* h_in, const float* g, const int* lens_h
     wn_fwd(flows_[flow], h, g, gin, Gc, acts, h2, out, dl, B, T, s);
 }
 
-// SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863), batched with per-sample lengths.
-// gen_chunk > 0: the generator (purely convolutional, receptive field 13.2 frames) runs window by window - gen_chunk frames + a
-// 16-frame halo on each side, only the interior is kept - so its scratch is one window instead of the whole utterance (60 s
-// utterances, BASELINE configs[4]); enc_p / flow need the whole sequence and run once.  Stage C owns its own arena: a vocoder call
-// on a second stream may overlap the next batch's GPT / diffusion calls on the first.
-void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
-                    float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s, int gen_chunk) {
-    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
-    DTTS_REQUIRE(T % 4 == 0, "mel length must be a multiple of 4 (assert y.shape[-1]%4==0, model_24k.py:851)");
-    DTTS_REQUIRE(gen_chunk >= 0, "generator chunk");
-    ArenaUse use_stage_c_arena(ws_voc_);
-    const int HALO = 16, Tg = gen_chunk > 0 ? std::min(T, gen_chunk + 2 * HALO) : T;
-    const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
+// in_proj + SpecEncoder / enc_p (vqvae/model_24k.py:856-857, :71-107; vqvae/modules/attentions.py:73-107 Encoder, :161-303 windowed
+// relative-position MultiHeadAttention, FFN): mel [B,128,T] -> stats [B, 2*inter, T] = (m_p | logs_p), masked.  Buffers from the caller.
+void Model::enc_p_fwd(const float* mel, const int* dl, int B, int T, float* x, float* y, float* qkv, float* att, float* ffn, float* relk,
+                      float* ml, float* stats, hipStream_t s) {
+    const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels;
     const int H = cfg.enc_heads, dk = hid / H;
-    const size_t a192 = (size_t)B * hid * T;
-    const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256;
-    ws().ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, Tg) + sizeof(float) * (size_t)B * 256 * Tg) + 8192);
-    std::vector<int> l(B);
-    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
-    const int* dl = upload_ints(l.data(), B, s);
-    const int* sids = upload_ints(sample_ids_host, B, s);
-
-    float* g = ws().f32((size_t)B * gin);
-    float* x = ws().f32(a192);
-    float* y = ws().f32(a192);
-    float* qkv = ws().f32(3 * a192);
-    float* att = ws().f32(a192);
-    float* ffn = ws().f32((size_t)B * filt * T);
-    float* relk = ws().f32((size_t)B * H * T * 9);
-    float* ml = ws().f32((size_t)B * H * T * 2);
-    float* stats = ws().f32(2 * a192);
-    float* Gc = ws().f32((size_t)B * 2048);
-
-    // g = ref_enc(y * y_mask, y_mask)  (:855)
-    {
-        const size_t m = ws().mark();
-        mel_style(ref_enc_, mel, dl, l.data(), B, T, g, s);
-        ws().rewind(m);
-    }
-    // x = in_proj(y) ; enc_p(x, y_lengths)  (:856-857)
     ConvParams p = cp(mel, cfg.mel_channels, x, inter, B, T, T, dl);
     p.pad = 1;
     run_conv(in_proj_, p, s);
@@ -549,6 +515,77 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     run_conv(enc_out_, p, s);
     p = cp(y, inter, stats, 2 * inter, B, T, T, dl);
     run_conv(enc_proj_, p, s);
+}
+
+// unit entry: (m_p, logs_p) of enc_p(in_proj(mel)) - the prior statistics infer_flowvae samples z_p from (vqvae/model_24k.py:857-860)
+void Model::op_enc_p(const float* mel, const int* lens_host, int B, int T, float* m_p, float* logs_p, hipStream_t s) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    DTTS_REQUIRE(B >= 1 && T >= 1, "enc_p shape");
+    ArenaUse use_stage_c_arena(ws_voc_);
+    const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, H = cfg.enc_heads;
+    const size_t a192 = (size_t)B * hid * T;
+    ws().ensure(sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11) + 64 * 256 + 8192);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) {
+        l[b] = lens_host ? lens_host[b] : T;
+        DTTS_REQUIRE(l[b] >= 1 && l[b] <= T, "mel length");
+    }
+    const int* dl = upload_ints(l.data(), B, s);
+    float* x = ws().f32(a192);
+    float* y = ws().f32(a192);
+    float* qkv = ws().f32(3 * a192);
+    float* att = ws().f32(a192);
+    float* ffn = ws().f32((size_t)B * filt * T);
+    float* relk = ws().f32((size_t)B * H * T * 9);
+    float* ml = ws().f32((size_t)B * H * T * 2);
+    float* stats = ws().f32(2 * a192);
+    enc_p_fwd(mel, dl, B, T, x, y, qkv, att, ffn, relk, ml, stats, s);
+    const size_t row = sizeof(float) * (size_t)inter * T;          // stats rows: [b][m_p (inter) | logs_p (inter)][T]
+    DTTS_CHECK_HIP(hipMemcpy2DAsync(m_p, row, stats, 2 * row, row, B, hipMemcpyDeviceToDevice, s));
+    DTTS_CHECK_HIP(hipMemcpy2DAsync(logs_p, row, stats + (size_t)inter * T, 2 * row, row, B, hipMemcpyDeviceToDevice, s));
+}
+
+// SynthesizerTrn.infer_flowvae (vqvae/model_24k.py:848-863), batched with per-sample lengths.
+// gen_chunk > 0: the generator (purely convolutional, receptive field 13.2 frames) runs window by window - gen_chunk frames + a
+// 16-frame halo on each side, only the interior is kept - so its scratch is one window instead of the whole utterance (60 s
+// utterances, BASELINE configs[4]); enc_p / flow need the whole sequence and run once.  Stage C owns its own arena: a vocoder call
+// on a second stream may overlap the next batch's GPT / diffusion calls on the first.
+void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsigned long long seed, const int* sample_ids_host,
+                    float noise_scale, const float* noise_override, float* wav, float* trace_z, hipStream_t s, int gen_chunk) {
+    DTTS_REQUIRE(bound_ && has_vocoder_, "vocoder weights not bound");
+    DTTS_REQUIRE(T % 4 == 0, "mel length must be a multiple of 4 (assert y.shape[-1]%4==0, model_24k.py:851)");
+    DTTS_REQUIRE(gen_chunk >= 0, "generator chunk");
+    ArenaUse use_stage_c_arena(ws_voc_);
+    const int HALO = 16, Tg = gen_chunk > 0 ? std::min(T, gen_chunk + 2 * HALO) : T;
+    const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
+    const int H = cfg.enc_heads, dk = hid / H;
+    const size_t a192 = (size_t)B * hid * T;
+    const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256;
+    ws().ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, Tg) + sizeof(float) * (size_t)B * 256 * Tg) + 8192);
+    std::vector<int> l(B);
+    for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
+    const int* dl = upload_ints(l.data(), B, s);
+    const int* sids = upload_ints(sample_ids_host, B, s);
+
+    float* g = ws().f32((size_t)B * gin);
+    float* x = ws().f32(a192);
+    float* y = ws().f32(a192);
+    float* qkv = ws().f32(3 * a192);
+    float* att = ws().f32(a192);
+    float* ffn = ws().f32((size_t)B * filt * T);
+    float* relk = ws().f32((size_t)B * H * T * 9);
+    float* ml = ws().f32((size_t)B * H * T * 2);
+    float* stats = ws().f32(2 * a192);
+    float* Gc = ws().f32((size_t)B * 2048);
+
+    // g = ref_enc(y * y_mask, y_mask)  (:855)
+    {
+        const size_t m = ws().mark();
+        mel_style(ref_enc_, mel, dl, l.data(), B, T, g, s);
+        ws().rewind(m);
+    }
+    // x = in_proj(y) ; enc_p(x, y_lengths)  (:856-857)
+    enc_p_fwd(mel, dl, B, T, x, y, qkv, att, ffn, relk, ml, stats, s);
     // z_p = m_p + randn * exp(logs_p) * noise_scale (:860), written channel-flipped (= the first Flip of the reversed flow)
     float* zc = x;
     float* zn = y;

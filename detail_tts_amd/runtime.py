@@ -375,6 +375,18 @@ class Runtime:
         self._rc(self.lib.dtts_mel_spectrogram(self.h, _ptr(wav), li[0], B, L, d["filter_length"], hop, _ptr(out), T, self._stream()))
         return out
 
+    def spectrogram(self, wav, lens=None):
+        """spectrogram_torch(y, 1024, 24000, 256, 1024) (vqvae/utils/data_utils.py:56-87): linear magnitudes [B, 513, L // hop]"""
+        _check(wav, "wav")
+        d = self.cfg["data"]
+        B, L = wav.shape
+        hop = d["hop_length"]
+        li = _ints(lens if lens is not None else [L] * B)
+        T = L // hop
+        out = torch.zeros((B, d["filter_length"] // 2 + 1, T), device=self.device, dtype=torch.float32)
+        self._rc(self.lib.dtts_spectrogram(self.h, _ptr(wav), li[0], B, L, d["filter_length"], hop, _ptr(out), T, self._stream()))
+        return out
+
     # ------------------------------------------------------------------ unit ops
     def op_attention_block(self, prefix, x, lens=None):
         _check(x, "x")
@@ -409,6 +421,17 @@ class Runtime:
         li = _ints(lens)
         self._rc(self.lib.dtts_op_wn(self.h, int(flow), _ptr(hidden), _ptr(g), li[0] if li else None, B, T, _ptr(out), self._stream()))
         return out
+
+    def op_enc_p(self, mel, lens=None):
+        """in_proj + enc_p (vqvae/model_24k.py:856-857): mel [B,128,T] -> (m_p, logs_p) [B,192,T]"""
+        _check(mel, "mel")
+        B, _, T = mel.shape
+        inter = self.cfg["vaegan"]["inter_channels"]
+        m_p = torch.zeros((B, inter, T), device=self.device, dtype=torch.float32)
+        logs_p = torch.zeros_like(m_p)
+        li = _ints(lens)
+        self._rc(self.lib.dtts_op_enc_p(self.h, _ptr(mel), li[0] if li else None, B, T, _ptr(m_p), _ptr(logs_p), self._stream()))
+        return m_p, logs_p
 
     def op_conv1d(self, name, x, cout, kw, stride=1, dil=1, pad=0, pro_act=0, epi_act=0, gate=0, phases=1, res=None, lens_in=None):
         _check(x, "x"); _check(res, "res")

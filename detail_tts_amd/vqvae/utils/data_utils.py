@@ -57,3 +57,18 @@ def mel_spectrogram_torch(y, n_fft, num_mels, sampling_rate, hop_size, win_size,
     if want != got:
         raise ValueError(f"front-end matrices were packed for {want}, called with {got}")
     return rt.mel_spectrogram(y.to(rt.device, torch.float32).contiguous(), lengths)
+
+
+def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False, *, lengths=None, rt=None):
+    """vqvae/utils/data_utils.py:56-87 (imported by api.py:29).  y [B, L] -> linear magnitude spectrogram [B, n_fft // 2 + 1, L // hop_size]."""
+    if center:
+        raise NotImplementedError("center=True is never used by the reference")
+    y = torch.as_tensor(y)
+    if y.dim() == 1:
+        y = y[None]
+    rt = _runtime(y.device, rt)
+    d = rt.cfg["data"]
+    want = (d["filter_length"], d["sampling_rate"], d["hop_length"], d["win_length"])
+    if want != (n_fft, sampling_rate, hop_size, win_size):
+        raise ValueError(f"front-end matrices were packed for {want}, called with {(n_fft, sampling_rate, hop_size, win_size)}")
+    return rt.spectrogram(y.to(rt.device, torch.float32).contiguous(), lengths)

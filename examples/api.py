@@ -3,7 +3,7 @@
 vocoder -> gen.wav.  Everything after reading the file runs in libdetail_hip.so.
 
     python examples/api.py --ckpt /path/model-480.pt --vocab /path/bpe_tokenizers/zh_tokenizer.json --wav 1.wav \\
-        --pinyin " da4 jia1 hao3 , jin1 tian1 lai2 dian3 da4 jia1 xiang3 kan4 de5 dong1 xi1 . "
+        --text "da4 jia1 hao3 ， jin1 tian1 lai2 dian3 da4 jia1 xiang3 kan4 de5 dong1 xi1 。"
     python examples/api.py --synthetic            # no checkpoint / vocabulary: seed-0 random weights, random ids, a synthetic prompt
 """
 import argparse
@@ -35,7 +35,10 @@ def main():
     ap.add_argument("--ckpt", default="synthetic:0")
     ap.add_argument("--vocab")
     ap.add_argument("--wav")
-    ap.add_argument("--pinyin", default=" da4 jia1 hao3 ")
+    ap.add_argument("--text", "--pinyin", dest="text", default="da4 jia1 hao3",
+                    help="the sentence AS PINYIN (pypinyin Style.TONE3, neutral tone 5, space separated: what api.py:21 produces from "
+                         "Chinese characters; pypinyin's dictionary is not available offline, so the conversion is the caller's)")
+    ap.add_argument("--print-ids", action="store_true", help="print the text token ids as JSON and exit (no GPU needed)")
     ap.add_argument("--ids", help="comma-separated text token ids (bypasses pypinyin + tokenizer: e.g. the demo.ipynb KAT ids)")
     ap.add_argument("--seed", type=int)
     ap.add_argument("--synthetic", action="store_true")
@@ -47,9 +50,13 @@ def main():
         ids = [int(v) for v in a.ids.split(",")]
     elif a.vocab:
         from detail_tts_amd.bpe_tokenizers.voice_tokenizer import VoiceBpeTokenizer
-        ids = VoiceBpeTokenizer(a.vocab).encode(a.pinyin)                                   # api.py:23-24
+        ids = VoiceBpeTokenizer(a.vocab).encode(" " + a.text.strip() + " ")                 # api.py:22-24
     else:
         ids = np.random.RandomState(0).randint(3, 255, 24).tolist()
+    if a.print_ids:
+        import json
+        print(json.dumps(ids))
+        return
     text_tokens = F.pad(torch.IntTensor(ids).unsqueeze(0), (0, 1))                          # api.py:24-25
     vqvae = load_model("vqvae", a.ckpt, None, device)                                       # api.py:33
     if a.wav:

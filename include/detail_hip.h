@@ -223,6 +223,10 @@ int dtts_resample(dtts_handle* h, const float* x, int B, int L, const float* ker
  * sqrt(re^2 + im^2 + 1e-6), mel filterbank GEMM ("frontend.mel"), log(clamp(., 1e-5)).  lens HOST (null -> L). */
 int dtts_mel_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, int L, int n_fft, int hop, float* mel_out, int Tmax,
                          void* stream);
+/* spectrogram_torch (vqvae/utils/data_utils.py:56-87, imported by api.py:29): the same framing + DFT, linear magnitudes
+ * sqrt(re^2 + im^2 + 1e-6) -> spec_out DEVICE [B, n_fft/2 + 1, Tmax] */
+int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, int L, int n_fft, int hop, float* spec_out, int Tmax,
+                     void* stream);
 
 /* Runtime options:
  *   "cfg_streams" (default 0 = by batch size: 1 up to batch 4, 2 above): the cond | uncond stack of a diffusion forward (2B samples on
@@ -262,6 +266,10 @@ int dtts_op_resblock1(dtts_handle* h, int stage, int branch, const float* x, con
 /* WaveNet of coupling layer `flow` (`flow.flows[2 * flow].enc`, vqvae/modules/modules.py:204-229): hidden [B, 192, T] (after the layer's
  * `pre` conv), g [B, gin] -> out [B, 192, T] (the summed skip connections, masked). */
 int dtts_op_wn(dtts_handle* h, int flow, const float* hidden, const float* g, const int* lens, int B, int T, float* out, void* stream);
+/* in_proj + enc_p / SpecEncoder (vqvae/model_24k.py:856-857 -> :71-107; vqvae/modules/attentions.py:73-107 Encoder, :161-303 windowed
+ * relative-position attention + FFN): mel [B,128,T] (de-normalised log-mel) -> m_p, logs_p [B,192,T] each (masked), the prior statistics
+ * infer_flowvae draws z_p from.  lens HOST (null -> T). */
+int dtts_op_enc_p(dtts_handle* h, const float* mel, const int* lens, int B, int T, float* m_p, float* logs_p, void* stream);
 /* AttentionBlock.forward (vqvae/utils/diff_util.py:209-215) of the block whose weights start with `prefix` */
 int dtts_op_attention_block(dtts_handle* h, const char* prefix, const float* x, const int* lens, int B, int C, int T,
                             float* y, void* stream);

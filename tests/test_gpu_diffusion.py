@@ -219,7 +219,7 @@ def test_errors_are_reported_not_crashes(rt):
 
 
 def test_split_precision_path_equals_fp32_path(rt):
-    """The trunk's default kernels compute every fp32 product as six bf16 MFMA products (3 x bf16 split operands, fp32
+    """The trunk's default kernels compute every fp32 product as three fp16 MFMA products (two fp16 planes per operand) (3 x bf16 split operands, fp32
     accumulate).  They must agree with the exact fp32-MFMA kernels (option conv_x3 = 0) to fp32 rounding, on a whole
     DiffusionTts.forward at a ragged length (T = 333 is not a multiple of any tile size)."""
     rs = np.random.RandomState(21)

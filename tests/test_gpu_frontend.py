@@ -27,6 +27,15 @@ def test_mel_spectrogram_vs_reference_fixture(rt, golden):
     assert float(np.abs(mel - g["mel"]).mean()) < 5e-5
 
 
+def test_spectrogram_torch_vs_reference_fixture(rt, golden):
+    """spectrogram_torch (vqvae/utils/data_utils.py:56-87, the name api.py:29 imports): linear magnitudes vs the reference's own."""
+    from detail_tts_amd.vqvae.utils.data_utils import spectrogram_torch
+    g = golden("frontend")
+    spec = spectrogram_torch(torch.from_numpy(g["wav"]).cuda(), 1024, 24000, 256, 1024, rt=rt).cpu().numpy()
+    assert spec.shape == g["spec"].shape
+    assert maxabs(spec, g["spec"]) < 2e-4 * max(1.0, float(np.abs(g["spec"]).max())), maxabs(spec, g["spec"])
+
+
 def test_mel_spectrogram_ragged_batch_vs_oracle(rt):
     from oracle import frontend as FE
     rs = np.random.RandomState(3)

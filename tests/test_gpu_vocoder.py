@@ -60,6 +60,24 @@ def test_infer_flowvae_golden(rt, golden):
     assert r < 1e-4, r
 
 
+def test_enc_p_unit_entry_vs_reference_and_oracle(rt, golden, weights):
+    """dtts_op_enc_p = in_proj + SpecEncoder (vqvae/model_24k.py:856-857 -> :71-107, attentions.py:73-107,161-303): m_p / logs_p vs the
+    REFERENCE's own (vocoder.npz), and a ragged batch of 2 vs the oracle per row."""
+    from oracle import ops, vocoder as V
+    g = golden("vocoder")
+    m_p, logs_p = rt.op_enc_p(dev(g["mel"]))
+    assert maxabs(host(m_p), g["m_p"]) < 2e-4 and maxabs(host(logs_p), g["logs_p"]) < 2e-4, (maxabs(host(m_p), g["m_p"]), maxabs(host(logs_p), g["logs_p"]))
+    assert float(np.abs(g["m_p"]).max()) > 1e-2
+    rs = np.random.RandomState(12)
+    mel = (rs.randn(2, 128, 44) * 2 - 5).astype(np.float32)
+    lens = [44, 31]
+    m_p, logs_p = rt.op_enc_p(dev(mel), lens=lens)
+    for b, L in enumerate(lens):
+        x = ops.conv1d(mel[b:b + 1, :, :L], weights["in_proj.weight"], weights["in_proj.bias"], padding=1)
+        _, rm, rl = V.spec_encoder(weights, x, [L])
+        assert maxabs(host(m_p)[b, :, :L], rm[0]) < 2e-4 and maxabs(host(logs_p)[b, :, :L], rl[0]) < 2e-4
+
+
 def test_vocoder_varlen_batch_vs_oracle(rt, weights):
     from oracle import vocoder as V
     rs = np.random.RandomState(11)

@@ -262,6 +262,49 @@ def test_voice_bpe_tokenizer_known_answers():
     assert remove_extraneous_punctuation("{a}[b]`c—d") == "(a)(b)'c-d" and remove_extraneous_punctuation("@") == ""
 
 
+def test_example_api_text_front_end_known_answer():
+    """examples/api.py takes the sentence as PINYIN (the output of api.py:21's lazy_pinyin call; pypinyin's dictionary
+    cannot be sourced offline) and reproduces api.py:22-24: pad with spaces, VoiceBpeTokenizer.encode -> the demo.ipynb ids (38)."""
+    import json
+    import subprocess
+    import sys
+    vocab = "/root/reference/bpe_tokenizers/zh_tokenizer.json"
+    if not os.path.exists(vocab):
+        pytest.skip("reference vocabulary file not available on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kat = json.load(open(os.path.join(root, "tests", "golden", "tokenizer_kat.json")))[0]
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "api.py"), "--vocab", vocab, "--text", kat["text"].strip(), "--print-ids"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == kat["ids"]
+
+
+def test_reference_api_imports_resolve_through_compat():
+    """compat/README.md: with compat/ first on sys.path every module api.py imports from the reference tree (api.py:10,27,29) - and the
+    ones its training / eval code imports - resolves to the MI355X-native mirrors, with the names api.py uses.  (Running api.py itself
+    needs a GPU, a checkpoint, torchaudio and pypinyin: none of which this container has.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "from bpe_tokenizers.voice_tokenizer import VoiceBpeTokenizer\n"
+        "from prepare.load_infer import load_model\n"
+        "from vqvae.utils.data_utils import spectrogram_torch, HParams, mel_spectrogram_torch\n"
+        "from vqvae.model_24k import SynthesizerTrn\n"
+        "from vqvae.diff_model import DiffusionTts\n"
+        "from gpt.model import UnifiedVoice\n"
+        "import detail_tts_amd\n"
+        "for o in (VoiceBpeTokenizer, load_model, mel_spectrogram_torch, HParams, SynthesizerTrn, DiffusionTts, UnifiedVoice):\n"
+        "    assert o.__module__.startswith('detail_tts_amd.'), (o, o.__module__)\n"
+        "assert callable(spectrogram_torch) and hasattr(SynthesizerTrn, 'infer') and hasattr(UnifiedVoice, 'inference_speech_tortoise')\n"
+        "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "compat"), root]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_configs0_cpu_plumbing_on_bundled_prompt(weights):
     """BASELINE configs[0]: the api.py flow on the reference's bundled 1.wav (44.1 kHz mono int16, 195 979 samples) with the
     demo.ipynb pinyin sentence (38 ids + trailing 0), random-init weights, on the CPU oracle: resample -> 416 mel frames -> 3 codes
