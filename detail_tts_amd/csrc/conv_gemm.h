@@ -62,6 +62,7 @@ struct ConvParams {
     // among `ksplit` workgroups per output tile; each leaves its raw accumulators in `kpart`, the last to arrive (counter in `kcount`)
     // sums them in split order - deterministic - and runs the epilogue.
     int ksplit = 1;
+    int epi_vec = 0;               // conv_x3: y / res rows are 16-byte aligned -> LDS-staged epilogue with 16-byte stores (set by the launcher)
     float* kpart = nullptr;
     int* kcount = nullptr;
     int ablate = 0;                // experiments only (DTTS_CONV_ABLATE): 1 skip global loads, 2 skip LDS stores, 4 skip barriers

@@ -328,15 +328,18 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     if (tid < BM) bias_s[tid] = (p.bias && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.f;
 
     int c16 = 0, tap = 0;                               // the step being computed
-    for (int ks = 0; ks < nks; ++ks) {
+    hf8 a[2][NPL], bb[3][NPL];
+    for (int ks = 0; ks < ((p.ablate & 16) ? 1 : nks); ++ks) {
         // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
         // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
+        if (!(p.ablate & 4)) {
         if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
         __builtin_amdgcn_s_barrier();
+        }
         const unsigned char* As = smem + (ks % NSTG) * WTILE + lhi * (BM * 16);
         const unsigned char* Xb = smem + XOFF + (c16 % NSTG) * XBUF;
-        hf8 a[2][NPL], bb[3][NPL];
+        if (!((p.ablate & 2) && ks > 0)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int nn = wn0 + j * 32 + l31 + tap;                    // column of the haloed tile
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) a[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
+        }
         // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first; ONE LDS-DMA piece after every
         // three MFMAs (as a burst the pieces of a CU's waves queue on the texture-address path while every MFMA pipe idles and the
         // co-resident workgroups fall into lock-step)
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
-                if (slot < 5) {
+                if (slot < 5 && !(p.ablate & 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (slot < 2) w_piece(wave * 2 + slot, ks + D);
                     else if (!KW3) x_piece(wave * 3 + (slot - 2), ks + D);
@@ -412,6 +416,66 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
         }
     }
 
+    if ((p.ablate & 8) && acc[0][0][0] != 12345.f) return;
+    if (EPI != 2 && p.epi_vec) {
+        // ---- LDS-staged epilogue (rows of y / res 16-byte aligned).  The MFMA C layout gives a lane ONE column and 16 rows: stored
+        // directly that is 96 global_store_dword per lane, 256 bytes per wave-instruction, and the kernel's tail is store-ISSUE
+        // bound (16 - 24 us of a 43 - 120 us launch at 240 tiles: ablation in DESIGN.md).  Instead each wave transposes its 64 x 96
+        // tile through its own LDS region in four rounds of 16 rows (24 ds_write_b32, 6 ds_read_b128) and moves 16 bytes per lane:
+        // 24 residual loads + 24 stores of 1 KiB per wave.  Region: 16 rows x (96 + 8) floats = 6.5 KiB per wave (the K loop's
+        // stages are free once every wave has left it: one barrier).
+        constexpr int EP_LD = 104;
+        __syncthreads();
+        float* st = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);
+        float* yb = p.y + (long long)b * p.y_bs;
+        const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
+        const int ncol0 = n0 + wn0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = q >> 1, rowt0 = wm0 + i * 32 + (q & 1) * 16;          // first tile row of this round
+            float4 rv[6];
+            if (rb) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + rowt0 + rl, n = ncol0 + c4 * 4;
+                    rv[k] = (row < p.Cout && n < nvalid) ? *reinterpret_cast<const float4*>(rb + (long long)row * p.res_cs + n)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = (q & 1) * 8 + rr, rl = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
+                    st[rl * EP_LD + j * 32 + l31] = acc[i][j][r];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + rowt0 + rl, n = ncol0 + c4 * 4;
+                const float4 a4 = *reinterpret_cast<const float4*>(st + rl * EP_LD + c4 * 4);
+                const float bz = bias_s[rowt0 + rl];
+                float o[4] = {a4.x * XS_ACC_SCALE + bz, a4.y * XS_ACC_SCALE + bz, a4.z * XS_ACC_SCALE + bz, a4.w * XS_ACC_SCALE + bz};
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], p.epi_act, p.epi_slope) * p.out_scale;
+                }
+                if (rb) {
+                    o[0] += p.res_scale * rv[k].x; o[1] += p.res_scale * rv[k].y; o[2] += p.res_scale * rv[k].z; o[3] += p.res_scale * rv[k].w;
+                }
+                if (row < p.Cout && n < nvalid) {
+                    float* dst = yb + (long long)row * p.y_cs + n;
+                    if (n + 3 < nvalid) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    else
+                        for (int e = 0; e < 4 && n + e < nvalid; ++e) dst[e] = o[e];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this round's reads are done before the next round's writes
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // bias of this lane's 32 output rows from the LDS copy made at kernel start: no global latency here, no registers held
     // across the K loop
@@ -436,33 +500,64 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
                 const int n = n0 + wn0 + j * 32 + l31;
                 if (((n0 + wn0 + j * 32) & ~63) >= nvalid) continue;               // its whole 64-key tile lies beyond the length (wave-uniform)
                 const bool ok = n < nvalid;
+                // Q and K: the 8 channels of a 16-byte chunk sit in TWO lanes (l, l + 32: rows + 4).  One v_permlane32_swap per packed
+                // word pairs the register groups (2k, 2k + 1): lanes 0..31 end up with the whole even chunk, lanes 32..63 with the odd
+                // one, and a lane stores 16 bytes per plane (the kernel's tail is store-issue bound: half the instructions, twice as wide).
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int r16 = m0 + wm0 + i * 32 + 16 * k2;                   // 16-row group: never straddles a head section (48 = 3 x 16)
+                    if (r16 >= p.Cout) continue;
+                    const int h = r16 / (3 * D), rem = r16 - h * 3 * D, sec = rem / D, c16 = rem - sec * D;
+                    if (sec == 2) continue;
+                    unsigned char* hp = pb + (size_t)h * hb;
+                    const float sc = sec == 0 ? p.qkv_qscale * 16.f : 16.f;
+                    unsigned we0[2], we1[2], wo0[2], wo1[2];
+                    {
+                        float ve[4], vo[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ve[e] = (acc[i][j][8 * k2 + e] * XS_ACC_SCALE + bv[i][8 * k2 + e]) * sc;
+                            vo[e] = (acc[i][j][8 * k2 + 4 + e] * XS_ACC_SCALE + bv[i][8 * k2 + 4 + e]) * sc;
+                            if (sec == 1 && !ok) ve[e] = vo[e] = 0.f;
+                        }
+                        split_pair(ve[0], ve[1], we0[0], we1[0]);
+                        split_pair(ve[2], ve[3], we0[1], we1[1]);
+                        split_pair(vo[0], vo[1], wo0[0], wo1[0]);
+                        split_pair(vo[2], vo[3], wo0[1], wo1[1]);
+                    }
+                    uint4 q0, q1;
+                    {
+                        const auto s00 = __builtin_amdgcn_permlane32_swap(we0[0], wo0[0], false, false);
+                        const auto s01 = __builtin_amdgcn_permlane32_swap(we0[1], wo0[1], false, false);
+                        const auto s10 = __builtin_amdgcn_permlane32_swap(we1[0], wo1[0], false, false);
+                        const auto s11 = __builtin_amdgcn_permlane32_swap(we1[1], wo1[1], false, false);
+                        q0 = make_uint4(s00[0], s01[0], s00[1], s01[1]);
+                        q1 = make_uint4(s10[0], s11[0], s10[1], s11[1]);
+                    }
+                    const int c8 = (c16 >> 3) + lhi;
+                    if (sec == 0) {
+                        if (ok) {
+                            unsigned char* o = hp + ((size_t)c8 * Tq + n) * 16;
+                            *reinterpret_cast<uint4*>(o) = q0;
+                            *reinterpret_cast<uint4*>(o + (size_t)6 * Tq * 16) = q1;
+                        }
+                    } else {
+                        unsigned char* o = hp + qb + (size_t)(n >> 6) * (2 * (6 * KT + 384) * 16) + ((size_t)c8 * KT + (n & 63)) * 16;
+                        *reinterpret_cast<uint4*>(o) = q0;
+                        *reinterpret_cast<uint4*>(o + 6 * KT * 16) = q1;
+                    }
+                }
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int row0 = m0 + wm0 + i * 32 + 8 * rg + 4 * lhi;         // first of this lane's 4 rows
                     if (row0 >= p.Cout) continue;
                     const int h = row0 / (3 * D), rem = row0 - h * 3 * D, sec = rem / D, c = rem - sec * D;
+                    if (sec != 2) continue;                                        // V only (Q / K above)
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] * XS_ACC_SCALE + bv[i][4 * rg + e];
                     unsigned char* hp = pb + (size_t)h * hb;
-                    if (sec == 0) {
-                        const float qs = p.qkv_qscale * 16.f;
-                        unsigned w0[2], w1[2];
-                        split_pair(v[0] * qs, v[1] * qs, w0[0], w1[0]);
-                        split_pair(v[2] * qs, v[3] * qs, w0[1], w1[1]);
-                        if (ok) {
-                            unsigned char* o = hp + ((size_t)(c >> 3) * Tq + n) * 16 + ((c >> 2) & 1) * 8;
-                            *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
-                            *reinterpret_cast<uint2*>(o + (size_t)6 * Tq * 16) = make_uint2(w1[0], w1[1]);
-                        }
-                    } else if (sec == 1) {
-                        unsigned w0[2], w1[2];
-                        split_pair(ok ? v[0] * 16.f : 0.f, ok ? v[1] * 16.f : 0.f, w0[0], w1[0]);
-                        split_pair(ok ? v[2] * 16.f : 0.f, ok ? v[3] * 16.f : 0.f, w0[1], w1[1]);
-                        unsigned char* o = hp + qb + (size_t)(n >> 6) * (2 * (6 * KT + 384) * 16) + ((size_t)(c >> 3) * KT + (n & 63)) * 16 + ((c >> 2) & 1) * 8;
-                        *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
-                        *reinterpret_cast<uint2*>(o + 6 * KT * 16) = make_uint2(w1[0], w1[1]);
-                    } else {
+                    {
                         // lane quad (keys n - q4 .. n - q4 + 3) x registers (channels c .. c + 3) -> transposed
                         float t[4];
 #pragma unroll
@@ -652,6 +747,11 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     if (ntile <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile), (p.Cin >> 4) / 8);
     if (S < 1) S = 1;
     p.ksplit = S;
+    static const int x3_ablate = []() { const char* v = getenv("DTTS_X3_ABLATE"); return v ? atoi(v) : 0; }();
+    p.ablate = x3_ablate;
+    static const bool epi_vec_on = []() { const char* v = getenv("DTTS_X3_EPI_VEC"); return !(v && v[0] == '0'); }();
+    auto al16 = [](const void* q, long long bs, int cs) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0 && (bs & 3) == 0 && (cs & 3) == 0; };
+    p.epi_vec = (epi_vec_on && p.y && al16(p.y, p.y_bs, p.y_cs) && (!p.res || al16(p.res, p.res_bs, p.res_cs))) ? 1 : 0;
     if (S > 1) {
         const KSplitWs w = ksplit_workspace(s, (size_t)ntile * S);
         p.kpart = w.part;
@@ -662,7 +762,7 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16;
     static bool attr = false;
     if (!attr) {
-        const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float);
+        const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float) + 16;
         const void* fns[] = {reinterpret_cast<const void*>(conv_x3_kernel<2, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<2, false, 3>),
                              reinterpret_cast<const void*>(conv_x3_kernel<2, false, 4>),
                              reinterpret_cast<const void*>(conv_x3_kernel<0, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 2>),
