@@ -6,7 +6,9 @@
 // tools/ubench/gemm_x3v.hip (M = 768 / 2304, B = 16, T = 936): 128 x 192 beats 128 x 128 by 8-10 % (2.5 instead of 8.6 % padded
 // columns, 17 % fewer LDS-DMA bytes per MFMA); deeper pipelines and 256-row tiles measured within +-3 % of it.
 #include <algorithm>
+#include <cstdio>
 #include <mutex>
+#include <vector>
 
 #include "conv_x3.h"
 #include <cstdlib>
@@ -278,31 +280,53 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     // split z owns channel blocks [cbeg, cend): the loop below indexes them from 0 through the shifted base pointers
     const int cbeg = (int)((long long)call * z / S), c16n = (int)((long long)call * (z + 1) / S) - cbeg, nks = KW * c16n;
     const int bin = p.x_bidx ? p.x_bidx[b] : b;
-    const uint4* wbase = static_cast<const uint4*>(p.w3) + m0 + lane + (long long)(2 * cbeg) * NPL * p.CoutP;
-    const uint4* xbase = static_cast<const uint4*>(p.x3) + (long long)bin * C8 * NPL * Tp + n0 + (X3_HALO - p.pad) + lane + (long long)(2 * cbeg) * NPL * Tp;
-    const long long wtap = (long long)C8 * NPL * p.CoutP;
-
-    // LDS-DMA pieces (1 KiB = 64 rows / columns of one (plane, k-half) "kind"): 8 per W tile, 12 (+ the 8 halo chunks) per X tile.
-    auto dma = [&](const uint4* g, int lds_off) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+    // ---- operand addressing: UNIFORM byte pointers (SGPR pairs) + one per-lane 32-bit offset (lane * 16), so that every LDS-DMA piece is
+    // `global_load_lds_dwordx4 v_lane16, s[ptr]`: no per-piece VALU address arithmetic, and the pointers advance by constant strides
+    // (round 2 recomputed each piece's address from (step, kind, half) - 45 SALU + 12 VALU per K-step against 18 MFMAs).
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned char* wb8 = static_cast<const unsigned char*>(p.w3) + ((long long)m0 + (long long)(2 * cbeg) * NPL * p.CoutP) * 16;
+    const unsigned char* xb8 = static_cast<const unsigned char*>(p.x3) +
+                               ((long long)bin * C8 * NPL * Tp + n0 + (X3_HALO - p.pad) + (long long)(2 * cbeg) * NPL * Tp) * 16;
+    const long long wtapB = (long long)C8 * NPL * p.CoutP * 16;           // bytes between taps
+    const long long wblkB = (long long)2 * NPL * p.CoutP * 16;            // bytes between 16-channel blocks (W)
+    const long long xblkB = (long long)2 * NPL * Tp * 16;                 //                              (X)
+    auto dma = [&](const unsigned char* g, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane16),
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
-    auto w_piece = [&](int j, int q) {                                  // j = kind*2 + row half; q = step (clamped to the last one)
-        const int qq = q < nks ? q : nks - 1, c16 = KW3 ? qq / 3 : qq, tap = KW3 ? qq - 3 * c16 : 0;
-        const int kind = j >> 1, pl = kind >> 1, h = kind & 1, rh = j & 1;
-        dma(wbase + tap * wtap + ((long long)(2 * c16 + h) * NPL + pl) * p.CoutP + rh * 64, (q % NSTG) * WTILE + kind * (BM * 16) + rh * 1024);
+    // This wave's pieces (1 KiB = 64 rows / columns of one (plane, k-half) "kind").  W: kind = wave, row halves 0 / 1.  X (k = 1): kind = wave,
+    // column blocks 0..2.  X (k = 3): the 12 pieces of a channel block are spread over its three taps, piece tap * 4 + wave at tap `tap`.
+    const int wkind = wave, wpl = wkind >> 1, wh = wkind & 1;
+    const unsigned char* wq = wb8 + (long long)(wh * NPL + wpl) * p.CoutP * 16;          // W piece pointer of the step being ISSUED (row half 0)
+    const int wlds = wkind * (BM * 16);                                                   // + stage * WTILE (+ 1024 for row half 1)
+    const unsigned char* xq = xb8 + (long long)(wh * NPL + wpl) * Tp * 16;               // k = 1: X pieces of the step being issued (column block 0)
+    const int xlds = XOFF + wkind * (BN * 16);
+    // k = 3: per-tap (kind, column block) of this wave's X piece
+    long long x3o[3];
+    int x3l[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int j = t * 4 + wave, kind = j / 3, cb = j - kind * 3;
+        x3o[t] = ((long long)((kind & 1) * NPL + (kind >> 1)) * Tp + cb * 64) * 16;
+        x3l[t] = XOFF + kind * (BN * 16) + cb * 1024;
+    }
+    // k = 3 halo: lanes 0..7 fetch (kind = lane >> 1, column 192 + (lane & 1)); expressed against the lane16 offset every piece carries
+    const long long halo_lane = (lane < 2 * NK) ? (((long long)(((lane >> 1) & 1) * NPL + (lane >> 2)) * Tp + BN + (lane & 1)) * 16 - (long long)lane16) : 0;
+    const unsigned char* xblk = xb8;                                                      // k = 3: block pointer of the X tile being issued
+    auto issue_w = [&](int i, int stage) { dma(wq + i * 1024, stage * WTILE + wlds + i * 1024); };
+    auto issue_x1 = [&](int i, int stage) { dma(xq + i * 1024, stage * XBUF + xlds + i * 1024); };
+    auto issue_x3 = [&](int t, int stage) { dma(xblk + x3o[t], stage * XBUF + x3l[t]); };
+    auto issue_halo = [&](int stage) {
+        if (lane < 2 * NK)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xblk + halo_lane + lane16),
+                                             (__attribute__((address_space(3))) void*)(smem + XOFF + stage * XBUF + XMAIN), 16, 0, 0);
     };
-    auto x_piece = [&](int j, int c) {                                   // j = kind*3 + column block; c = channel block (clamped)
-        const int c16 = c < c16n ? c : c16n - 1;
-        const int kind = j / 3, cb = j - kind * 3, pl = kind >> 1, h = kind & 1;
-        dma(xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + cb * 64, XOFF + (c % NSTG) * XBUF + kind * (BN * 16) + cb * 1024);
-    };
-    auto x_halo = [&](int c) {                                           // lanes 0..7: (kind, column 192 + r); every wave issues it
-        const int c16 = c < c16n ? c : c16n - 1;                         // (identical bytes) so that the instruction count is uniform
-        if (lane < 2 * NK) {
-            const int kind = lane >> 1, pl = kind >> 1, h = kind & 1, r = lane & 1;
-            dma(xbase - lane + ((long long)(2 * c16 + h) * NPL + pl) * Tp + BN + r, XOFF + (c % NSTG) * XBUF + XMAIN);
-        }
+    // advance the W pointer by one step: next tap, or the first tap of the next channel block
+    int itap = 0;                                       // tap of the step being issued (k = 3)
+    auto next_w = [&]() {
+        if (!KW3) wq += wblkB;
+        else if (itap < 2) { wq += wtapB; ++itap; }
+        else { wq += wblkB - 2 * wtapB; itap = 0; }
     };
 
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
@@ -314,48 +338,63 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // prologue, oldest data first: W of steps 0 .. D-1; X of steps 0 .. D-1 (k = 1) / of channel blocks 0 .. D-1 (k = 3)
+    // prologue, oldest data first: W of steps 0 .. D-1; X of steps 0 .. D-1 (k = 1) / of channel blocks 0 .. D-1 (k = 3).  Steps / blocks
+    // beyond the end are not issued at all; the counted waits below fall back to a full drain for the last D - 1 steps.
 #pragma unroll
     for (int q = 0; q < D; ++q) {
+        if (q < nks) {
+            issue_w(0, q);
+            issue_w(1, q);
+        }
+        next_w();
+        if (!KW3) {
+            if (q < nks) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) w_piece(wave * 2 + i, q);
+                for (int i = 0; i < 3; ++i) issue_x1(i, q);
+            }
+            xq += xblkB;
+        } else {
+            if (q < c16n) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) x_piece(wave * 3 + i, q);
-        if (KW3) x_halo(q);
+                for (int t = 0; t < 3; ++t) issue_x3(t, q);
+                issue_halo(q);
+            }
+            xblk += xblkB;
+        }
     }
     // the tile's 128 bias values -> LDS (read back in the epilogue; the first K-step barrier orders the write)
     float* bias_s = reinterpret_cast<float*>(smem + XOFF + NSTG * XBUF);
     if (tid < BM) bias_s[tid] = (p.bias && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.f;
 
     int c16 = 0, tap = 0;                               // the step being computed
+    int sw = 0, sx = 0;                                 // its W stage / X buffer; the step being issued uses (sw + D) % NSTG, (sx + D) % NSTG
     hf8 a[2][NPL], bb[3][NPL];
-    for (int ks = 0; ks < ((p.ablate & 16) ? 1 : nks); ++ks) {
+    for (int ks = 0; ks < nks; ++ks) {
         // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
         // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
-        if (!(p.ablate & 4)) {
-        if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // counted wait only while every one of the last D - 1 iterations issued its full set (2 W + 1 X for k = 3, 2 + 3 for k = 1)
+        if (NSTG == 2 || ks + D > nks || (KW3 && c16 + D >= c16n)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
         __builtin_amdgcn_s_barrier();
-        }
-        const unsigned char* As = smem + (ks % NSTG) * WTILE + lhi * (BM * 16);
-        const unsigned char* Xb = smem + XOFF + (c16 % NSTG) * XBUF;
-        if (!((p.ablate & 2) && ks > 0)) {
+        const unsigned char* As = smem + sw * WTILE + lhi * (BM * 16);
+        const unsigned char* Xb = smem + XOFF + sx * XBUF;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int nn = wn0 + j * 32 + l31 + tap;                    // column of the haloed tile
-            const unsigned char* xq = nn < BN ? Xb + lhi * (BN * 16) + nn * 16 : Xb + XMAIN + lhi * 32 + (nn - BN) * 16;
+            const unsigned char* xr = nn < BN ? Xb + lhi * (BN * 16) + nn * 16 : Xb + XMAIN + lhi * 32 + (nn - BN) * 16;
             const int xps = nn < BN ? 2 * BN * 16 : 64;                 // plane stride: main part / halo part
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) bb[j][pl] = *reinterpret_cast<const hf8*>(xq + pl * xps);
+            for (int pl = 0; pl < NPL; ++pl) bb[j][pl] = *reinterpret_cast<const hf8*>(xr + pl * xps);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) a[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
-        }
         // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first; ONE LDS-DMA piece after every
         // three MFMAs (as a burst the pieces of a CU's waves queue on the texture-address path while every MFMA pipe idles and the
         // co-resident workgroups fall into lock-step)
+        const int swi = sw + D >= NSTG ? sw + D - NSTG : sw + D, sxi = sx + D >= NSTG ? sx + D - NSTG : sx + D;
+        const bool wlive = ks + D < nks, xlive = KW3 ? c16 + D < c16n : ks + D < nks;
         constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
         int slot = 0;
 #pragma unroll
@@ -364,19 +403,27 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
-                if (slot < 5 && !(p.ablate & 1)) {
+                if (slot < 5) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (slot < 2) w_piece(wave * 2 + slot, ks + D);
-                    else if (!KW3) x_piece(wave * 3 + (slot - 2), ks + D);
-                    else if (slot == 2) x_piece(tap * 4 + wave, c16 + D);
-                    else if (slot == 3 && tap == 2) x_halo(c16 + D);
+                    if (slot < 2) { if (wlive) issue_w(slot, swi); }
+                    else if (!KW3) { if (xlive) issue_x1(slot - 2, sxi); }
+                    else if (slot == 2) { if (xlive) issue_x3(tap, sxi); }
+                    else if (slot == 3 && tap == 2) { if (xlive) issue_halo(sxi); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ++slot;
             }
-        if (++tap == KW) { tap = 0; ++c16; }
+        next_w();
+        if (!KW3) xq += xblkB;
+        sw = sw + 1 == NSTG ? 0 : sw + 1;
+        if (++tap == KW) {
+            tap = 0;
+            ++c16;
+            sx = sx + 1 == NSTG ? 0 : sx + 1;
+            if (KW3) xblk += xblkB;
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail refetches must land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (S > 1) {
         // raw accumulators -> this split's slab (lane-contiguous: one 256-byte run per register and wave); the last workgroup of the tile
@@ -416,7 +463,6 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
         }
     }
 
-    if ((p.ablate & 8) && acc[0][0][0] != 12345.f) return;
     if (EPI != 2 && p.epi_vec) {
         // ---- LDS-staged epilogue (rows of y / res 16-byte aligned).  The MFMA C layout gives a lane ONE column and 16 rows: stored
         // directly that is 96 global_store_dword per lane, 256 bytes per wave-instruction, and the kernel's tail is store-ISSUE
@@ -713,7 +759,9 @@ KSplitWs ksplit_workspace(hipStream_t s, size_t nslabs) {
         }
         DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&part[k]), MAX_SLABS * 96 * 256 * sizeof(float)));
         DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&count[k]), MAX_TILES * sizeof(int)));
-        DTTS_CHECK_HIP(hipMemset(count[k], 0, MAX_TILES * sizeof(int)));
+        // zeroed ON THE LAUNCH STREAM: a plain hipMemset runs on the null stream, which a non-blocking stream does not wait for - the
+        // first split-K kernel of such a stream could meet recycled (non-zero) counters, or have them zeroed under it
+        DTTS_CHECK_HIP(hipMemsetAsync(count[k], 0, MAX_TILES * sizeof(int), s));
         owner[k] = s;
         owner_dev[k] = dev;
         ++used;
@@ -747,8 +795,6 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     if (ntile <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile), (p.Cin >> 4) / 8);
     if (S < 1) S = 1;
     p.ksplit = S;
-    static const int x3_ablate = []() { const char* v = getenv("DTTS_X3_ABLATE"); return v ? atoi(v) : 0; }();
-    p.ablate = x3_ablate;
     static const bool epi_vec_on = []() { const char* v = getenv("DTTS_X3_EPI_VEC"); return !(v && v[0] == '0'); }();
     auto al16 = [](const void* q, long long bs, int cs) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0 && (bs & 3) == 0 && (cs & 3) == 0; };
     p.epi_vec = (epi_vec_on && p.y && al16(p.y, p.y_bs, p.y_cs) && (!p.res || al16(p.res, p.res_bs, p.res_cs))) ? 1 : 0;
