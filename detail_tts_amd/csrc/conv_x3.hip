@@ -368,51 +368,33 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
 
     int c16 = 0, tap = 0;                               // the step being computed
     int sw = 0, sx = 0;                                 // its W stage / X buffer; the step being issued uses (sw + D) % NSTG, (sx + D) % NSTG
-    hf8 a[2][NPL], bb[3][NPL];
-    for (int ks = 0; ks < nks; ++ks) {
-        // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
-        // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
-        // counted wait only while every one of the last D - 1 iterations issued its full set (2 W + 1 X for k = 3, 2 + 3 for k = 1)
-        if (NSTG == 2 || ks + D > nks || (KW3 && c16 + D >= c16n)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        const unsigned char* As = smem + sw * WTILE + lhi * (BM * 16);
-        const unsigned char* Xb = smem + XOFF + sx * XBUF;
+    // MFMA fragments of one K-step <- LDS
+    auto read_frags = [&](hf8 (&fa)[2][NPL], hf8 (&fb)[3][NPL], int stw, int stx, int tp) {
+        const unsigned char* As = smem + stw * WTILE + lhi * (BM * 16);
+        const unsigned char* Xb = smem + XOFF + stx * XBUF;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int nn = wn0 + j * 32 + l31 + tap;                    // column of the haloed tile
+            const int nn = wn0 + j * 32 + l31 + tp;                     // column of the haloed tile
             const unsigned char* xr = nn < BN ? Xb + lhi * (BN * 16) + nn * 16 : Xb + XMAIN + lhi * 32 + (nn - BN) * 16;
             const int xps = nn < BN ? 2 * BN * 16 : 64;                 // plane stride: main part / halo part
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) bb[j][pl] = *reinterpret_cast<const hf8*>(xr + pl * xps);
+            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const hf8*>(xr + pl * xps);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) a[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
-        // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first; ONE LDS-DMA piece after every
-        // three MFMAs (as a burst the pieces of a CU's waves queue on the texture-address path while every MFMA pipe idles and the
-        // co-resident workgroups fall into lock-step)
-        const int swi = sw + D >= NSTG ? sw + D - NSTG : sw + D, sxi = sx + D >= NSTG ? sx + D - NSTG : sx + D;
-        const bool wlive = ks + D < nks, xlive = KW3 ? c16 + D < c16n : ks + D < nks;
-        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
-        int slot = 0;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
-                if (slot < 5) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (slot < 2) { if (wlive) issue_w(slot, swi); }
-                    else if (!KW3) { if (xlive) issue_x1(slot - 2, sxi); }
-                    else if (slot == 2) { if (xlive) issue_x3(tap, sxi); }
-                    else if (slot == 3 && tap == 2) { if (xlive) issue_halo(sxi); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ++slot;
-            }
+            for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = *reinterpret_cast<const hf8*>(As + pl * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
+    };
+    // one LDS-DMA piece of the step being issued (slot 0..4 of the K-step: after the first five MFMA triples)
+    auto issue_slot = [&](int slot, int swi, int sxi, bool wlive, bool xlive) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot < 2) { if (wlive) issue_w(slot, swi); }
+        else if (!KW3) { if (xlive) issue_x1(slot - 2, sxi); }
+        else if (slot == 2) { if (xlive) issue_x3(tap, sxi); }
+        else if (slot == 3 && tap == 2) { if (xlive) issue_halo(sxi); }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto advance = [&]() {
         next_w();
         if (!KW3) xq += xblkB;
         sw = sw + 1 == NSTG ? 0 : sw + 1;
@@ -422,6 +404,37 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
             sx = sx + 1 == NSTG ? 0 : sx + 1;
             if (KW3) xblk += xblkB;
         }
+    };
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first
+    {
+    hf8 a[2][NPL], bb[3][NPL];
+    for (int ks = 0; ks < nks; ++ks) {
+        // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
+        // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
+        // counted wait only while every one of the last D - 1 iterations issued its full set (2 W + 1 X for k = 3, 2 + 3 for k = 1)
+        if (NSTG == 2 || ks + D > nks || (KW3 && c16 + D >= c16n)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        // (reading the NEXT step's fragments into a second register set under the last MFMA triples - the barrier moved inside the
+        // step - measured 38.6 -> 37.8 us for k = 1 and 107 -> 118 us for k = 3 at 240 tiles: the LDS port, not the read latency, is
+        // what the fragment reads cost; not kept)
+        read_frags(a, bb, sw, sx, tap);
+        // ONE LDS-DMA piece after every three MFMAs (as a burst the pieces of a CU's waves queue on the texture-address path while
+        // every MFMA pipe idles and the co-resident workgroups fall into lock-step)
+        const int swi = sw + D >= NSTG ? sw + D - NSTG : sw + D, sxi = sx + D >= NSTG ? sx + D - NSTG : sx + D;
+        const bool wlive = ks + D < nks, xlive = KW3 ? c16 + D < c16n : ks + D < nks;
+        int slot = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
+                if (slot < 5) issue_slot(slot, swi, sxi, wlive, xlive);
+                ++slot;
+            }
+        advance();
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

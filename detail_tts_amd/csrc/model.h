@@ -170,6 +170,8 @@ public:
     void generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs = 0,
                    int z_cs = 0);
     void op_generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s);
+    bool rb_fused_ok(const GenStageW& st, int ch) const;
+    void rb_fused(const GenStageW& st, const float* x, float* y, int ch, const int* lens, int B, int T, int branch_mask, float scale, hipStream_t s);
     void op_resblock1(int stage, int branch, const float* x, const int* lens_host, int B, int T, float* y, hipStream_t s);
     void op_wn(int flow, const float* h, const float* g, const int* lens_host, int B, int T, float* out, hipStream_t s);
     void op_enc_p(const float* mel, const int* lens_host, int B, int T, float* m_p, float* logs_p, hipStream_t s);

@@ -258,6 +258,43 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
     }
 }
 
+// the fused kernel covers stages of at most 32 channels with the (3, 7, 11) kernels (DTTS_VOC_FUSED=0: launch by launch as before)
+bool Model::rb_fused_ok(const GenStageW& st, int ch) const {
+    static const bool env_on = []() { const char* v = getenv("DTTS_VOC_FUSED"); return !(v && v[0] == '0'); }();
+    if (!env_on || ch > 32) return false;
+    int halo = 0;
+    for (int l = 0; l < 3; ++l) halo += 10 * (cfg.resblock_dilations[l] + 1) / 2;
+    return st.rb[0].k == 3 && st.rb[1].k == 7 && st.rb[2].k == 11 && halo <= 60 && st.rb[0].c1[0].CoutP == 32;
+}
+
+void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, const int* lens, int B, int T, int branch_mask, float scale,
+                     hipStream_t s) {
+    RbFusedParams p;
+    p.x = x;
+    p.y = y;
+    p.x_bs = p.y_bs = (long long)ch * T;
+    p.x_cs = p.y_cs = T;
+    p.lens = lens;
+    p.B = B;
+    p.C = ch;
+    p.T = T;
+    p.CinP = st.rb[0].c1[0].CinP;
+    p.CoutP = st.rb[0].c1[0].CoutP;
+    for (int j = 0; j < 3; ++j) {
+        p.k[j] = st.rb[j].k;
+        for (int l = 0; l < 3; ++l) {
+            p.w[(j * 3 + l) * 2] = st.rb[j].c1[l].w;
+            p.b[(j * 3 + l) * 2] = st.rb[j].c1[l].b;
+            p.w[(j * 3 + l) * 2 + 1] = st.rb[j].c2[l].w;
+            p.b[(j * 3 + l) * 2 + 1] = st.rb[j].c2[l].b;
+        }
+    }
+    for (int l = 0; l < 3; ++l) p.dil[l] = cfg.resblock_dilations[l];
+    p.branch_mask = branch_mask;
+    p.scale = scale;
+    launch_resblock1x3_fused(p, s);
+}
+
 bool Model::vocoder_x3() const {
     static const bool env_on = []() { const char* v = getenv("DTTS_VOC_X3"); return !(v && v[0] == '0'); }();
     return env_on && use_x3();
@@ -273,6 +310,10 @@ void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
+    if (rb_fused_ok(gen_[stage], ch)) {           // narrow stages: the same fused kernel the generator runs, one branch, no mean
+        rb_fused(gen_[stage], x, y, ch, dl, B, T, 1 << branch, 1.f, s);
+        return;
+    }
     float* tmp = ws().f32((size_t)B * ch * T);
     void* xs = ws().raw(x3d_bytes(B, round_up(ch, 16), T));
     resblock1_fwd(gen_[stage].rb[branch], x, tmp, y, ch, dl, B, T, s, xs);
@@ -348,9 +389,14 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
         u.y_bs = (long long)cn * Tn;
         u.y_cs = Tn;
         run_conv(st.up, u, s);
-        // three ResBlock1 branches on T1 -> R[j]
-        for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s, cn > 32 ? planes : nullptr);
-        launch_add3_scale(R[0], R[1], R[2], 1.f / 3.f, X, (long long)B * cn * Tn, s);
+        if (rb_fused_ok(st, cn)) {
+            // narrow stages: the three branches and their mean in one LDS-resident kernel (resblock1_fused.hip)
+            rb_fused(st, T1, X, cn, dln, B, Tn, 7, 1.f / 3.f, s);
+        } else {
+            // three ResBlock1 branches on T1 -> R[j]
+            for (int j = 0; j < cfg.n_resblock_kernels; ++j) resblock1_fwd(st.rb[j], T1, T2, R[j], cn, dln, B, Tn, s, cn > 32 ? planes : nullptr);
+            launch_add3_scale(R[0], R[1], R[2], 1.f / 3.f, X, (long long)B * cn * Tn, s);
+        }
         ch = cn;
         Tc = Tn;
         dl = dln;

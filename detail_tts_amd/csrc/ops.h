@@ -59,6 +59,25 @@ void launch_coupling_reverse(const float* x, const float* m, float* y, long long
                              int Ctot, int flip, hipStream_t s);
 
 // y[b,c,t] = alpha * (x0 + x1 + x2)  — mean of the three ResBlock1 branches (vqvae/model_24k.py:277-283)
+// LDS-resident fused ResBlock1 group of a narrow generator stage (resblock1_fused.hip): y = scale * sum over the branches in
+// `branch_mask` of ResBlock1_j(x), kernels (3, 7, 11), three (convs1 dilation dil[l], convs2 dilation 1) layer pairs each.
+// w / b: packed fp32 weights [KW][CinP][CoutP] / biases [CoutP] of conv (branch j, layer l, which) at index (j * 3 + l) * 2 + which.
+struct RbFusedParams {
+    const float* x = nullptr;
+    float* y = nullptr;
+    long long x_bs = 0, y_bs = 0;
+    int x_cs = 0, y_cs = 0;
+    const int* lens = nullptr;     // device, per sample (null: T)
+    int B = 0, C = 0, T = 0, CinP = 0, CoutP = 0;
+    int k[3] = {3, 7, 11}, dil[3] = {1, 3, 5};
+    const float* w[18] = {};
+    const float* b[18] = {};
+    int branch_mask = 7;
+    float scale = 1.f / 3.f;
+    int vec_ok = 0;                // set by the launcher
+};
+void launch_resblock1x3_fused(const RbFusedParams& p, hipStream_t s);
+int rb_fused_tile(int CP);         // interior samples per workgroup (CP = 16 | 32 padded channels)
 void launch_add3_scale(const float* x0, const float* x1, const float* x2, float alpha, float* y, long long n, hipStream_t s);
 
 }  // namespace dtts

@@ -217,7 +217,7 @@ def test_generator_stream_equals_full_and_wav_writer(weights, tmp_path):
     assert np.abs(pcm / 32767.0 - full[0, 0].clamp(-1, 1).cpu().numpy()).max() < 1.0 / 32767 + 1e-6
 
 
-@pytest.mark.parametrize("stage,branch", [(0, 0), (0, 2), (1, 1), (2, 0), (2, 1), (2, 2), (3, 2), (4, 0)])
+@pytest.mark.parametrize("stage,branch", [(0, 0), (0, 2), (1, 1), (2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 2), (4, 0), (4, 1), (4, 2)])
 def test_unit_resblock1_vs_oracle(rt, weights, stage, branch):
     """dtts_op_resblock1: one HiFiGAN ResBlock1 (kernel 3 / 7 / 11, dilations 1, 3, 5) against the oracle, ragged batch."""
     from oracle import vocoder as V
@@ -230,6 +230,23 @@ def test_unit_resblock1_vs_oracle(rt, weights, stage, branch):
     for b, L in enumerate(lens):
         ref = V.resblock1(weights, f"dec.resblocks.{stage * 3 + branch}", x[b:b + 1, :, :L], (3, 7, 11)[branch])[0]
         assert maxabs(y[b, :, :L], ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), (stage, branch, b)
+
+
+@pytest.mark.parametrize("stage,branch", [(3, 0), (3, 2), (4, 1), (4, 2)])
+def test_fused_resblock1_across_time_tiles_vs_oracle(rt, weights, stage, branch):
+    """The LDS-resident fused ResBlock1 of the narrow generator stages (resblock1_fused.hip: 25 and 12 channels) on sequences that span
+    several time tiles (interiors of 392 / 968 samples + 60-sample halos): tile seams, a ragged row ending inside a tile, and a row
+    ending inside a halo - every element against the oracle."""
+    from oracle import vocoder as V
+    rs = np.random.RandomState(60 + stage * 3 + branch)
+    ch = 400 >> (stage + 1)
+    T = 2600
+    x = (rs.randn(3, ch, T) * 0.5).astype(np.float32)
+    lens = [T, 1000, 1990]
+    y = host(rt.op_resblock1(stage, branch, dev(x), lens))
+    for b, L in enumerate(lens):
+        ref = V.resblock1(weights, f"dec.resblocks.{stage * 3 + branch}", x[b:b + 1, :, :L], (3, 7, 11)[branch])[0]
+        assert maxabs(y[b, :, :L], ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), (stage, branch, b, maxabs(y[b, :, :L], ref))
 
 
 @pytest.mark.parametrize("flow", [0, 3])
