@@ -4,7 +4,8 @@
 
 namespace dtts {
 
-constexpr int GEMV_MAXB = 8;                 // sequences per decode step (rows of the skinny GEMM); larger batches run in groups
+constexpr int GEMV_MAXB = 16;                // sequences per decode step (rows of the skinny GEMM): one request of <= 8, or two requests'
+                                             // stage A decoded as one session (the weights stream once for both); larger batches run in groups
 constexpr int GEMV_PART_FLOATS = 262144;     // per-row scratch of one split-K partial set (>= slices * CoutP for every decode GEMV)
 
 // Device-side control block of a decode session.  Everything that changes from token to token (step) or from call to call (seed,
@@ -14,7 +15,7 @@ struct GptCtl {
     int step[GEMV_MAXB];          // index of the token each row generates next (0-based); advanced by the sampler
     int lp[GEMV_MAXB];            // prefix length of the row: cond (1) + text positions + start_mel (1)
     int sample_id[GEMV_MAXB];     // Philox stream id of the row
-    unsigned long long seed;
+    unsigned long long seed[GEMV_MAXB];     // Philox seed of the row (rows of two requests may share a session)
     float repetition_penalty, temperature, top_p;
     int top_k;                    // <= 0: disabled
     int suppress_eos;

@@ -72,6 +72,20 @@ __device__ __forceinline__ void ln_row_stats(const float* __restrict__ st, int n
 // an L2 / fabric round trip: ALL loads of the element are issued before the first add (slice counts are 6, 12 or 24: a switch on
 // the uniform count selects a fully unrolled body; a rolled loop would expose one round trip per 4 slices).
 template <int N>
+__device__ __forceinline__ void load_parts_n(const float* __restrict__ p, long long slice_stride, float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[(long long)i * slice_stride];
+}
+template <int N>
+__device__ __forceinline__ float reduce_parts_n(const float (&v)[N]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) { a0 += v[i]; a1 += v[i + 1]; a2 += v[i + 2]; a3 += v[i + 3]; }
+#pragma unroll
+    for (int i = N & ~3; i < N; ++i) a0 += v[i];
+    return (a0 + a1) + (a2 + a3);
+}
+template <int N>
 __device__ __forceinline__ float sum_parts_n(const float* __restrict__ p, long long slice_stride) {
     float v[N];
 #pragma unroll
@@ -175,10 +189,11 @@ void launch_ln_fold_vectors(const float* W, int K, int CoutP, const float* gamma
 //   GP_LNPARTS v = act(r_b (sum_slices parts[sl][b][k] - mu_b c[k]) + d[k]) with (mu_b, r_b) from stats_in: the LN-algebra finish
 //              of the producing GEMV (c_fc) + GELU
 //   GP_ATTN    v = the attention output: the key-split partial results (m, l, o) of decode_attention_qkv_kernel combined
-template <int PRO, int VEC, int RPW>
+template <int PRO, int VEC, int RPW, int NB>
 __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict__ W, int K, int CoutP, GemvIn in, int B,
                                                          float* __restrict__ part) {
-    constexpr int NB = 8, RB = 8 * RPW;                 // RPW weight rows per wave, RB input rows per workgroup (= one partial slice)
+    constexpr int RB = 8 * RPW;                         // RPW weight rows per wave, RB input rows per workgroup (= one partial slice)
+    static_assert(NB == 8 || NB == 16, "batch rows per decode step: 8, or 16 (two requests' stage A decoded as one session)");
     static_assert(RB == 64 || RB == 128, "a row's RB values must be one or two whole waves");
     __shared__ __attribute__((aligned(16))) float xs[NB][RB];
     __shared__ __attribute__((aligned(16))) float red[8][4][64][VEC];
@@ -202,6 +217,61 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
             }
         }
     }
+    // ---- prologue.  Every global load of it is issued BEFORE the first wait: VMEM loads return in order, so a wait for any of them
+    // also waits for the weight loads above, and each further dependent batch (the split-K partials of the producing GEMV, one batch
+    // per input element in round 2) was one more L2 / fabric round trip in front of the FMAs (6.8 -> ~5 us per GEMV).
+    constexpr int NE = NB * RB / 512;                           // input elements per thread (a wave never straddles two rows)
+    const bool lead = PRO == GP_RESSUM && blockIdx.x == 0;       // this workgroup also publishes the residual rows + statistics
+    const long long pstride = (long long)B * in.in_stride;
+    int eb[NE], ebb[NE], ei[NE], ek[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = q * 512 + tid;
+        eb[q] = e / RB;
+        ei[q] = e % RB;
+        ebb[q] = eb[q] < B ? eb[q] : B - 1;
+        ek[q] = k0 + ei[q];
+    }
+    float psum[NE], aux0[NE], aux1[NE];                         // summed partials; RESSUM: residual + bias, gamma; LNPARTS: fold c, d
+#pragma unroll
+    for (int q = 0; q < NE; ++q) psum[q] = aux0[q] = aux1[q] = 0.f;
+    if (PRO == GP_RESSUM) {
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            aux0[q] = in.x[(long long)ebb[q] * in.x_stride + ek[q]];
+            if (in.in_bias) aux0[q] += in.in_bias[ek[q]];
+            aux1[q] = in.gamma[ek[q]];
+        }
+    } else if (PRO == GP_LNPARTS) {
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            aux0[q] = in.fold_c[ek[q]];
+            aux1[q] = in.fold_d[ek[q]];
+        }
+    }
+    if (PRO == GP_RESSUM || PRO == GP_LNPARTS) {
+        const float* pp[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) pp[q] = in.parts + (long long)ebb[q] * in.in_stride + ek[q];
+        // the loads of ALL elements first, then the sums (each in sum_parts_n's order: bit-identical to summing element by element)
+#define DTTS_GEMV_PARTS(N)                                                      \
+    {                                                                           \
+        float pv[NE][N];                                                        \
+        _Pragma("unroll") for (int q = 0; q < NE; ++q) load_parts_n<N>(pp[q], pstride, pv[q]); \
+        _Pragma("unroll") for (int q = 0; q < NE; ++q) psum[q] = reduce_parts_n<N>(pv[q]);     \
+    }
+        switch (in.in_slices) {
+            case 0: break;
+            case 1: DTTS_GEMV_PARTS(1) break;
+            case 6: DTTS_GEMV_PARTS(6) break;
+            case 12: DTTS_GEMV_PARTS(12) break;
+            case 24: DTTS_GEMV_PARTS(24) break;
+            default:
+#pragma unroll
+                for (int q = 0; q < NE; ++q) psum[q] = sum_parts(in.parts, in.in_slices, pstride, (long long)ebb[q] * in.in_stride + ek[q]);
+        }
+#undef DTTS_GEMV_PARTS
+    }
     if (PRO == GP_LNPARTS) {
         if (tid < NB) {
             float m = 0.f, r = 0.f;
@@ -211,15 +281,12 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
         }
         __syncthreads();
     }
-    const bool lead = PRO == GP_RESSUM && blockIdx.x == 0;       // this workgroup also publishes the residual rows + statistics
-    const long long pstride = (long long)B * in.in_stride;
 #pragma unroll
-    for (int e0 = 0; e0 < NB * RB; e0 += 512) {
-        const int e = e0 + tid, b = e / RB, i = e % RB, bb = b < B ? b : B - 1, k = k0 + i;   // a wave never straddles two rows
+    for (int q = 0; q < NE; ++q) {
+        const int b = eb[q], i = ei[q], bb = ebb[q], k = ek[q];
         float v;
         if (PRO == GP_LNPARTS) {
-            const float a = sum_parts(in.parts, in.in_slices, pstride, (long long)bb * in.in_stride + k);
-            v = act_apply(smr[bb][1] * (a - smr[bb][0] * in.fold_c[k]) + in.fold_d[k], in.in_act, 0.f);
+            v = act_apply(smr[bb][1] * (psum[q] - smr[bb][0] * aux0[q]) + aux1[q], in.in_act, 0.f);
         } else if (PRO == GP_ATTN) {
             // parts = [B][H][KS][ATT_REC]: per key split (m, l, o[0..D-1]); in_stride = D, in_slices = KS
             const int D = in.in_stride, h = k / D, c = k - h * D, H = K / D, KS = in.in_slices;
@@ -234,14 +301,14 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
             }
             v = num / den;
         } else if (PRO == GP_RESSUM) {
-            v = in.x[(long long)bb * in.x_stride + k] + (in.in_bias ? in.in_bias[k] : 0.f);
-            if (in.in_slices) v += sum_parts(in.parts, in.in_slices, pstride, (long long)bb * in.in_stride + k);
+            v = aux0[q];
+            if (in.in_slices) v += psum[q];
             if (lead) {
                 if (b < B) in.y_out[(long long)b * K + k] = v;
                 const float s1 = wsum(v), s2 = wsum(v * v);           // fixed order -> deterministic
                 if (lane == 0) { sst[b][RB == 128 ? (wave & 1) : 0][0] = s1; sst[b][RB == 128 ? (wave & 1) : 0][1] = s2; }
             }
-            v *= in.gamma[k];
+            v *= aux1[q];
         } else {
             v = in.x[(long long)bb * in.x_stride + k];
         }
@@ -271,7 +338,7 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
         }
     // combine the 8 waves (rows) through LDS, 4 batch rows per round; wave order fixed -> deterministic
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NB / 4; ++h) {
         if (h) __syncthreads();
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -297,13 +364,18 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
     }
 }
 
+template <int VEC, int RPW, int NB>
+static void gemv_block_launch_nb(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
+    const dim3 grid(cdiv(CoutP, 64 * VEC), K / (8 * RPW));
+    if (pro == GP_PLAIN) hipLaunchKernelGGL((gemv_block_kernel<GP_PLAIN, VEC, RPW, NB>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else if (pro == GP_ATTN) hipLaunchKernelGGL((gemv_block_kernel<GP_ATTN, VEC, RPW, NB>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else if (pro == GP_RESSUM) hipLaunchKernelGGL((gemv_block_kernel<GP_RESSUM, VEC, RPW, NB>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    else hipLaunchKernelGGL((gemv_block_kernel<GP_LNPARTS, VEC, RPW, NB>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+}
 template <int VEC, int RPW>
 static void gemv_block_launch_v(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
-    const dim3 grid(cdiv(CoutP, 64 * VEC), K / (8 * RPW));
-    if (pro == GP_PLAIN) hipLaunchKernelGGL((gemv_block_kernel<GP_PLAIN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else if (pro == GP_ATTN) hipLaunchKernelGGL((gemv_block_kernel<GP_ATTN, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else if (pro == GP_RESSUM) hipLaunchKernelGGL((gemv_block_kernel<GP_RESSUM, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
-    else hipLaunchKernelGGL((gemv_block_kernel<GP_LNPARTS, VEC, RPW>), grid, dim3(512), 0, s, W, K, CoutP, in, B, part);
+    if (B <= 8) gemv_block_launch_nb<VEC, RPW, 8>(pro, W, K, CoutP, in, B, part, s);
+    else gemv_block_launch_nb<VEC, RPW, 16>(pro, W, K, CoutP, in, B, part, s);
 }
 
 // Workgroup shape per GEMV: enough workgroups to put one on most CUs.  Wide (256-column, 16-byte loads) when that already yields
@@ -324,7 +396,7 @@ int gemv_block_slices(int K, int CoutP) { return gemv_wide(K, CoutP) ? K / 128 :
 void launch_gemv_block(int pro, const float* W, int K, int CoutP, const GemvIn& in, int B, float* part, hipStream_t s) {
     DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB && K % 128 == 0 && CoutP % 4 == 0, "gemv_block shape");
     const int rows = gemv_rows(K, CoutP);
-    DTTS_REQUIRE((long long)(K / rows) * CoutP * B <= (long long)GEMV_PART_FLOATS * GEMV_MAXB, "gemv partial scratch");
+    DTTS_REQUIRE((long long)(K / rows) * CoutP <= (long long)GEMV_PART_FLOATS, "gemv partial scratch (per batch row)");
     if (gemv_wide(K, CoutP)) gemv_block_launch_v<4, 16>(pro, W, K, CoutP, in, B, part, s);
     else if (rows == 64) gemv_block_launch_v<1, 8>(pro, W, K, CoutP, in, B, part, s);
     else gemv_block_launch_v<1, 16>(pro, W, K, CoutP, in, B, part, s);
@@ -767,7 +839,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         if (ctl->forced_u) u = ctl->forced_u[(long long)b * ctl->u_stride + step];
         else {
             float uu[4];
-            philox_uniform4(ctl->seed, (unsigned)ctl->sample_id[b], STAGE_GPT_SAMPLE, step, 0u, uu);
+            philox_uniform4(ctl->seed[b], (unsigned)ctl->sample_id[b], STAGE_GPT_SAMPLE, step, 0u, uu);
             u = uu[0];
         }
         const float target = u * tot;

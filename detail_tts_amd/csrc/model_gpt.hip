@@ -151,7 +151,7 @@ static void text_prefix_ids(const int* text, const int* text_lens, int B, int Lt
 void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, const int* text_host, const int* text_lens_host,
                         int Lt_max, int B, const dtts_gpt_options& o, float* latents_cm, int lat_stride, hipStream_t s) {
     DTTS_REQUIRE(bound_ && has_gpt_, "gpt weights not bound");
-    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB, "a GPT decode session holds 1..8 sequences (dtts_gpt_generate groups larger batches)");
+    DTTS_REQUIRE(B >= 1 && B <= GEMV_MAXB, "a GPT decode session holds 1..16 sequences (dtts_gpt_generate groups larger batches)");
     DTTS_REQUIRE(o.max_generate_length >= 1 && o.max_generate_length + 1 <= cfg.gpt_max_mel_pos, "max_generate_length");
     DTTS_REQUIRE(!latents_cm || lat_stride >= o.max_generate_length, "latent buffer too small");
     DTTS_REQUIRE(o.sample_ids, "sample_ids");
@@ -223,8 +223,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     // control block (host copy kept in the handle: the asynchronous upload reads it)
     GptCtl& c = ctl_host_;
     std::memset(&c, 0, sizeof(c));
-    for (int b = 0; b < B; ++b) { c.lp[b] = lp[b]; c.sample_id[b] = o.sample_ids[b]; }
-    c.seed = o.seed;
+    for (int b = 0; b < B; ++b) { c.lp[b] = lp[b]; c.sample_id[b] = o.sample_ids[b]; c.seed[b] = o.row_seeds ? o.row_seeds[b] : o.seed; }
     c.repetition_penalty = o.repetition_penalty;
     c.temperature = o.temperature;
     c.top_p = o.top_p;
@@ -468,6 +467,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
         og.sample_ids = o.sample_ids + g0;
         if (o.forced_uniforms) og.forced_uniforms = o.forced_uniforms + (size_t)g0 * G;
         if (o.forced_codes) og.forced_codes = o.forced_codes + (size_t)g0 * G;
+        if (o.row_seeds) og.row_seeds = o.row_seeds + g0;
         gpt_prefill(refer + (size_t)g0 * cfg.mel_channels * Tr, refer_lens_host ? refer_lens_host + g0 : nullptr, Tr,
                     text_host + (size_t)g0 * Lt_max, text_lens_host ? text_lens_host + g0 : nullptr, Lt_max, nb, og,
                     latents_cm ? latents_cm + (size_t)g0 * C * lat_stride : nullptr, lat_stride, s);
@@ -482,7 +482,7 @@ void Model::gpt_generate(const float* refer, const int* refer_lens_host, int Tr,
 // unit entry: the device sampler on given logits rows (HF logits processors + inverse-CDF draw), one token per row
 void Model::op_sample_logits(const float* logits, int R, int V, const int* history_host, int hist_len, const float* uniforms, int top_k,
                              float top_p, float temperature, float repetition_penalty, int* tokens_host, hipStream_t s) {
-    DTTS_REQUIRE(R >= 1 && R <= GEMV_MAXB && V >= 2 && V < 65535, "op_sample_logits: rows 1..8");
+    DTTS_REQUIRE(R >= 1 && R <= GEMV_MAXB && V >= 2 && V < 65535, "op_sample_logits: rows 1..16");
     ws().ensure((size_t)R * V + sizeof(int) * 4 * R + sizeof(GptCtl) + 16 * 256);
     unsigned char* seen = static_cast<unsigned char*>(ws().raw((size_t)R * V));
     int* finished = ws().i32(R);

@@ -162,6 +162,12 @@ class Runtime:
         si = _ints(sample_ids)
         rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
         o = _lib.DttsGptOptions()
+        row_seeds = None
+        if isinstance(seed, (list, tuple, np.ndarray)):          # one Philox seed per row: rows of different requests in one session
+            row_seeds = np.ascontiguousarray(np.asarray(seed, np.uint64))
+            assert row_seeds.shape == (B,)
+            o.row_seeds = row_seeds.ctypes.data_as(_lib.c_u64_p)
+            seed = int(row_seeds[0])
         o.seed, o.sample_ids, o.max_generate_length, o.top_k = int(seed), si[0], G, int(top_k or 0)
         o.top_p, o.temperature, o.repetition_penalty = float(top_p if top_p is not None else 1.0), float(temperature), float(repetition_penalty)
         o.suppress_eos = 1 if suppress_eos else 0
@@ -181,7 +187,7 @@ class Runtime:
                                             self._stream()))
         return codes, ncodes, lat
 
-    # decode session (include/detail_hip.h: dtts_gpt_prefill / _decode_step / _decode / _all_finished / _finish), <= 8 rows
+    # decode session (include/detail_hip.h: dtts_gpt_prefill / _decode_step / _decode / _all_finished / _finish), <= 16 rows
     def gpt_prefill(self, refer, refer_lens, texts, seed, sample_ids, max_generate_length=600, top_k=50, top_p=0.8, temperature=0.8,
                     repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None):
         """conditioning encoder + prefill + first token; returns the latents tensor [B,768,G] the steps fill column by column"""
@@ -192,6 +198,12 @@ class Runtime:
         si = _ints(sample_ids)
         rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
         o = _lib.DttsGptOptions()
+        row_seeds = None
+        if isinstance(seed, (list, tuple, np.ndarray)):          # one Philox seed per row: rows of different requests in one session
+            row_seeds = np.ascontiguousarray(np.asarray(seed, np.uint64))
+            assert row_seeds.shape == (B,)
+            o.row_seeds = row_seeds.ctypes.data_as(_lib.c_u64_p)
+            seed = int(row_seeds[0])
         o.seed, o.sample_ids, o.max_generate_length, o.top_k = int(seed), si[0], G, int(top_k or 0)
         o.top_p, o.temperature, o.repetition_penalty = float(top_p if top_p is not None else 1.0), float(temperature), float(repetition_penalty)
         o.suppress_eos = 1 if suppress_eos else 0
@@ -457,7 +469,7 @@ class Runtime:
         return (xo, x0) if return_x0 else xo
 
     def op_sample_logits(self, logits, history, uniforms, top_k=50, top_p=0.8, temperature=0.8, repetition_penalty=2.0):
-        """device sampler on logits rows [R, V] (R <= 8) with the rows' input_ids history [R, n] and one uniform per row -> token ids"""
+        """device sampler on logits rows [R, V] (R <= 16) with the rows' input_ids history [R, n] and one uniform per row -> token ids"""
         _check(logits, "logits"); _check(uniforms, "uniforms")
         R, V = logits.shape
         hist = np.ascontiguousarray(np.asarray(history, np.int32).reshape(R, -1))

@@ -156,7 +156,7 @@ class SynthesizerTrn:
 
         mark("start")
         # ---- stage A: codes + latents (:782-799)
-        session = forced_codes is None and B <= 8
+        session = forced_codes is None and B <= 16
         if forced_codes is None:
             kw = dict(max_generate_length=max_generate_length, top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
                       repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
@@ -214,11 +214,12 @@ class SynthesizerTrn:
 
     # ------------------------------------------------------------------------------------------------------------
     def infer_stream(self, requests, noise_scale=NOISE_SCALE, *, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False,
-                     vocoder_chunk=0):
+                     vocoder_chunk=0, pair_stage_a=False):
         """Batch server: `infer(..., batch=True)` over a sequence of request batches, software-pipelined over three HIP streams.
 
         requests: iterable of dicts with keys text [B,Lt], text_length [B], refer [B,128,Tr], refer_lengths [B] and optionally seed,
-        sample_ids (any B; up to 8 utterances share one decode session).  Yields (wav [B,1,1024*n_max], lengths) per request, in order; every
+        sample_ids (any B; up to 16 utterances share one decode session; with pair_stage_a two consecutive requests of <= 8 utterances
+        are decoded as ONE session - stage A of requests i + 1 and i + 2 together under stage B of requests i - 1 and i).  Yields (wav [B,1,1024*n_max], lengths) per request, in order; every
         result is bit-identical to `infer(**request, batch=True)` with the same seed and sample ids.
 
         Stage A of request i+1 (GPT prefill + decode: a chain of short latency-bound kernels that leaves the chip mostly idle) runs
@@ -239,7 +240,7 @@ class SynthesizerTrn:
         kw = dict(max_generate_length=max_generate_length, top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
                   repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
 
-        def launch_a(req):
+        def parse(req):
             text = torch.as_tensor(req["text"])
             tl = torch.as_tensor(req["text_length"]).reshape(-1).tolist()
             rl = [int(v) for v in torch.as_tensor(req["refer_lengths"]).reshape(-1).tolist()]
@@ -249,49 +250,76 @@ class SynthesizerTrn:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             sids = list(range(B)) if req.get("sample_ids") is None else list(req["sample_ids"])
             texts = [text[b, : int(tl[b])].cpu().numpy().astype(np.int32) for b in range(B)]
+            return dict(B=B, rl=rl, seed=seed, sids=sids, texts=texts, refer_in=req["refer"])
+
+        def launch_a(group):
+            """stage A of one request, or of TWO requests of <= 8 utterances each as ONE decode session (<= 16 rows, per-row Philox
+            seeds): the 308 MB of GPT weights stream once per token for both, and the chain of ~12 400 dependent launches is paid once."""
+            sts = [parse(r) for r in group]
             tr = None
             if trace is not None:
-                tr = dict(host_a0=time.perf_counter(), ev_a0=torch.cuda.Event(enable_timing=True), ev_a1=torch.cuda.Event(enable_timing=True),
-                          ev_b0=torch.cuda.Event(enable_timing=True), ev_b1=torch.cuda.Event(enable_timing=True),
-                          ev_c1=torch.cuda.Event(enable_timing=True))
-                trace.append(tr)
+                tr = dict(host_a0=time.perf_counter(), ev_a0=torch.cuda.Event(enable_timing=True), ev_a1=torch.cuda.Event(enable_timing=True))
             with torch.cuda.stream(sa):
                 if tr:
                     tr["ev_a0"].record(sa)
-                refer = torch.as_tensor(req["refer"]).to(dev, torch.float32).contiguous()
-                gen = None
-                if B <= 8:
-                    self.rt.gpt_prefill(refer, rl, texts, seed, sids, **kw)
+                for st in sts:
+                    st["refer"] = torch.as_tensor(st.pop("refer_in")).to(dev, torch.float32).contiguous()
+                    st["gen"] = None
+                    st["tr"] = None
+                    if trace is not None:
+                        st["tr"] = dict(tr, ev_b0=torch.cuda.Event(enable_timing=True), ev_b1=torch.cuda.Event(enable_timing=True),
+                                        ev_c1=torch.cuda.Event(enable_timing=True))
+                        trace.append(st["tr"])
+                rows = sum(st["B"] for st in sts)
+                if rows <= 16:
+                    if len(sts) == 1:
+                        refer, seeds = sts[0]["refer"], sts[0]["seed"]
+                    else:                                      # one padded prompt batch; every kernel takes the per-row length
+                        Tr = max(st["refer"].shape[2] for st in sts)
+                        refer = torch.zeros((rows, sts[0]["refer"].shape[1], Tr), device=dev, dtype=torch.float32)
+                        r0 = 0
+                        for st in sts:
+                            refer[r0:r0 + st["B"], :, : st["refer"].shape[2]] = st["refer"]
+                            r0 += st["B"]
+                        seeds = [st["seed"] for st in sts for _ in range(st["B"])]
+                    self.rt.gpt_prefill(refer, [v for st in sts for v in st["rl"]], [t for st in sts for t in st["texts"]], seeds,
+                                        [v for st in sts for v in st["sids"]], **kw)
                     if suppress_eos:                           # fixed length: the whole decode is enqueued without a host round trip
                         self.rt.gpt_decode(max_generate_length)
                 else:                                          # more than one decode session: group after group, on this thread / stream
-                    gen = self.rt.gpt_generate(refer, rl, texts, seed, sids, **kw)
+                    st = sts[0]
+                    st["gen"] = self.rt.gpt_generate(st["refer"], st["rl"], st["texts"], st["seed"], st["sids"], **kw)
             if tr:
-                tr["host_a1"] = time.perf_counter()
-            return dict(refer=refer, rl=rl, seed=seed, sids=sids, tr=tr, gen=gen)
+                for st in sts:
+                    st["tr"]["host_a1"] = time.perf_counter()
+            return sts
 
-        def finish_a(st):
+        def finish_a(sts):
             with torch.cuda.stream(sa):
-                if st["gen"] is not None:
-                    codes, ncodes, lat = st.pop("gen")
+                if sts[0]["gen"] is not None:
+                    codes, ncodes, lat = sts[0].pop("gen")
                 else:
                     while self.rt.gpt_steps() < max_generate_length:
                         if not suppress_eos and self.rt.gpt_all_finished():
                             break
                         self.rt.gpt_decode(16)
                     codes, ncodes, lat = self.rt.gpt_finish()      # waits for stream A only
-                n = [int(c) - 1 for c in ncodes]
-                if min(n) < 1:
-                    raise ValueError("an utterance produced no mel codes (stop token first)")
-                st["lat"] = lat[:, :, : max(n)].contiguous()
-                st["n"] = n
+                r0 = 0
+                for st in sts:
+                    n = [int(c) - 1 for c in ncodes[r0:r0 + st["B"]]]
+                    if min(n) < 1:
+                        raise ValueError("an utterance produced no mel codes (stop token first)")
+                    st["lat"] = lat[r0:r0 + st["B"], :, : max(n)].contiguous()
+                    st["n"] = n
+                    r0 += st["B"]
                 done = torch.cuda.Event()
                 done.record(sa)
-                if st["tr"]:
-                    st["tr"]["ev_a1"].record(sa)
-                    st["tr"]["host_a2"] = time.perf_counter()
-            st["a_done"] = done
-            return st
+                for st in sts:
+                    st["a_done"] = done
+                    if st["tr"]:
+                        st["tr"]["ev_a1"].record(sa)
+                        st["tr"]["host_a2"] = time.perf_counter()
+            return sts
 
         def launch_bc(st):
             cur.wait_event(st["a_done"])
@@ -325,14 +353,34 @@ class SynthesizerTrn:
         # Stage A is issued from its own host thread: a kernel-launch call blocks once its stream's hardware queue is full, so one
         # thread could not enqueue request i+1's decode (12 K launches) while it is still feeding request i's diffusion (10 K).  The
         # library supports exactly this split (include/detail_hip.h, "Threads"); ctypes releases the GIL inside the calls.
-        def stage_a(req):
+        def stage_a(group):
             torch.cuda.set_device(dev)
-            return finish_a(launch_a(req))
+            return finish_a(launch_a(group))
 
+        # requests -> stage-A groups: with pair_stage_a (or DTTS_PAIR_STAGE_A=1) two consecutive requests of <= 8 utterances share a decode
+        # session.  Off by default: a 16-row decode step costs 1.6x an 8-row one (161 vs 103 ms per 234 tokens alone), and under the
+        # three-stream pipeline the longer chain measured 505 vs 482 ms per batch of 8 (bench.py, 10 steps).
+        pair = bool(pair_stage_a) or os.environ.get("DTTS_PAIR_STAGE_A", "0") == "1"
         it = iter(requests)
-        try:
-            first = next(it)
-        except StopIteration:
+        held = []
+
+        def next_group():
+            while len(held) < 2:
+                try:
+                    held.append(next(it))
+                except StopIteration:
+                    break
+            if not held:
+                return None
+            nrows = [torch.as_tensor(r["text"]).shape[0] for r in held]
+            if pair and len(held) == 2 and nrows[0] <= 8 and nrows[1] <= 8:
+                g = [held.pop(0), held.pop(0)]
+            else:
+                g = [held.pop(0)]
+            return g
+
+        first = next_group()
+        if first is None:
             return
         if self._a_pool is None:
             self._a_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dtts-stage-a")
@@ -340,16 +388,16 @@ class SynthesizerTrn:
         pending = None
         try:
             while fut is not None:
-                st, fut = fut.result(), None    # the only wait on the GPU: this request's codes (their lengths size stage B)
-                try:
-                    fut = self._a_pool.submit(stage_a, next(it))     # next request's stage A starts now, under this request's diffusion
-                except StopIteration:
-                    pass
-                out = launch_bc(st)             # stage B / C of this request: enqueued, not waited for
-                if pending is not None:
-                    pending[2].synchronize()
-                    yield pending[0], pending[1]
-                pending = out
+                sts, fut = fut.result(), None   # the only wait on the GPU: this group's codes (their lengths size stage B)
+                g = next_group()
+                if g is not None:
+                    fut = self._a_pool.submit(stage_a, g)            # the next group's stage A starts now, under this group's diffusion
+                for st in sts:
+                    out = launch_bc(st)         # stage B / C of this request: enqueued, not waited for
+                    if pending is not None:
+                        pending[2].synchronize()
+                        yield pending[0], pending[1]
+                    pending = out
             pending[2].synchronize()
             yield pending[0], pending[1]
         finally:

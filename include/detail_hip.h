@@ -102,6 +102,7 @@ typedef struct dtts_gpt_options {
     int suppress_eos;               /* != 0: the stop token can never be drawn (benchmarks with random weights) */
     const float* forced_uniforms;   /* DEVICE [B][max_generate_length] uniforms replacing the Philox draw (tests), or NULL */
     const int* forced_codes;        /* HOST [B][max_generate_length] teacher-forced tokens (no sampling), or NULL */
+    const unsigned long long* row_seeds;   /* HOST [B] per-row Philox seed (rows of different requests in one session), or NULL: `seed` */
 } dtts_gpt_options;
 
 /* UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF GenerationMixin._sample, with a real KV cache
@@ -110,7 +111,7 @@ typedef struct dtts_gpt_options {
  * Outputs: codes HOST int32 [B][max_generate_length] (stop token included, rows padded with 8193), ncodes HOST [B],
  * latents_cm DEVICE [B,768,lat_stride]: column k = final_norm(ln_f(h)) at decode step k, i.e. the same values the
  * reference recomputes with UnifiedVoice.forward(return_latent=True).
- * = dtts_gpt_prefill + dtts_gpt_decode in 16-token hipGraph replays + dtts_gpt_finish; any B (groups of 8 rows run one
+ * = dtts_gpt_prefill + dtts_gpt_decode in 16-token hipGraph replays + dtts_gpt_finish; any B (groups of 16 rows run one
  * after the other).  Synchronises once per 16 tokens (finish flags; never when suppress_eos) and at the end (codes). */
 int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
                       int Lt_max, int B, const dtts_gpt_options* opts, int* codes_out, int* ncodes_out, float* latents_cm,
@@ -122,7 +123,7 @@ int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens,
  * read from a device control block, so one step has constant arguments and is graph-capturable.
  *
  * dtts_gpt_prefill: conditioning encoder (gpt/model.py:521-524), prefix embeddings, GPT-2 prefill over
- *   [cond | text | start_mel] filling the KV cache, and the FIRST sampled token.  B <= 8 rows per session.
+ *   [cond | text | start_mel] filling the KV cache, and the FIRST sampled token.  B <= 16 rows per session (two requests of <= 8 utterances can share one: the weights stream once per token for both).
  *   latents_cm DEVICE [B,768,lat_stride] (may be NULL) receives one column per generated token as the steps run. */
 int dtts_gpt_prefill(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
                      int Lt_max, int B, const dtts_gpt_options* opts, float* latents_cm, int lat_stride, void* stream);
@@ -281,7 +282,7 @@ int dtts_op_conv1d(dtts_handle* h, const char* name, const float* x, const int* 
                    int KW, int stride, int dil, int pad, int pro_act, int epi_act, int gate, int phases, const float* res,
                    float* y, int Tout_alloc, void* stream);
 /* The device sampler on given logits rows: HF RepetitionPenalty / Temperature / TopK / TopP processors as the reference's
- * generate() applies them (vqvae/model_24k.py:786-792) + the inverse-CDF draw on uniforms[r].  logits DEVICE [R][V] (R <= 8),
+ * generate() applies them (vqvae/model_24k.py:786-792) + the inverse-CDF draw on uniforms[r].  logits DEVICE [R][V] (R <= 16),
  * history HOST [R][hist_len] ids present in the row's input_ids, uniforms DEVICE [R] -> tokens HOST [R].  Synchronises. */
 int dtts_op_sample_logits(dtts_handle* h, const float* logits, int R, int V, const int* history, int hist_len,
                           const float* uniforms, int top_k, float top_p, float temperature, float repetition_penalty,

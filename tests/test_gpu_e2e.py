@@ -260,6 +260,10 @@ def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
     G = 24
     outs = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos))
     assert len(outs) == len(reqs)
+    # ... and with two consecutive requests of <= 8 utterances decoded as ONE <= 16-row session (per-row seeds): the same waveforms
+    paired = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos, pair_stage_a=True))
+    for (w0, l0), (w1, l1) in zip(outs, paired):
+        assert l0 == l1 and torch.equal(w0, w1)
     for r, (wav, lens) in zip(reqs, outs):
         ref, rlens = model.infer(r["text"], r["text_length"], r["refer"], r["refer_lengths"], batch=True, seed=r["seed"],
                                  sample_ids=r["sample_ids"], max_generate_length=G, suppress_eos=suppress_eos, return_lengths=True)

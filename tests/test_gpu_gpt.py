@@ -100,3 +100,26 @@ def test_single_token_and_limits(rt, golden):
         rt.gpt_generate(dev(g["refer"]), None, [g["text"][0]], 3, [9], max_generate_length=3, forced_codes=[np.array([5, 9000, 7])])
     with pytest.raises(DttsError):
         rt.gpt_latents(dev(g["refer"]), None, [g["text"][0]], [np.array([5, 8194])])
+
+
+def test_sixteen_row_session_with_row_seeds_equals_two_eight_row_sessions(rt):
+    """Two requests of 8 utterances decoded as ONE 16-row session (per-row Philox seeds, different prompt lengths, the 16-row GEMV
+    instantiation) give bit-identical codes and latents to the two 8-row sessions: what SynthesizerTrn.infer_stream relies on."""
+    rs = np.random.RandomState(61)
+    G = 20
+    reqs = []
+    for i, Tr in enumerate((90, 140)):
+        refer = (rs.randn(8, 128, Tr) * 2 - 5).astype(np.float32)
+        rl = [Tr - 3 * b for b in range(8)]
+        texts = [np.concatenate([rs.randint(3, 255, 6 + (b % 4)), [0]]).astype(np.int32) for b in range(8)]
+        reqs.append((refer, rl, texts, 1000 + i, [50 * i + b for b in range(8)]))
+    alone = [rt.gpt_generate(dev(r[0]), r[1], r[2], r[3], r[4], max_generate_length=G, suppress_eos=True) for r in reqs]
+    refer = np.zeros((16, 128, 140), np.float32)
+    refer[:8, :, :90] = reqs[0][0]
+    refer[8:] = reqs[1][0]
+    seeds = [reqs[0][3]] * 8 + [reqs[1][3]] * 8
+    codes, ncodes, lat = rt.gpt_generate(dev(refer), reqs[0][1] + reqs[1][1], reqs[0][2] + reqs[1][2], seeds, reqs[0][4] + reqs[1][4],
+                                         max_generate_length=G, suppress_eos=True)
+    for i in range(2):
+        assert np.array_equal(codes[8 * i:8 * i + 8], alone[i][0]), i
+        assert torch.equal(lat[8 * i:8 * i + 8], alone[i][2]), i

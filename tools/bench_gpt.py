@@ -19,3 +19,9 @@ for G in (2, 235):
     for _ in range(2): rt.gpt_generate(refer, None, texts, 1, list(range(B)), max_generate_length=G, suppress_eos=True)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 2
     print(f"B={B} G={G}: {dt*1e3:.1f} ms")
+if os.environ.get("PROF") == "1":
+    rt.profile_enable(2)
+    rt.gpt_generate(refer, None, texts, 1, list(range(B)), max_generate_length=65, suppress_eos=True)
+    torch.cuda.synchronize()
+    for p in sorted(rt.profile_report(), key=lambda p: -p["total_ms"])[:10]:
+        print("%-44s %5d launches %8.2f ms  %7.1f us" % (p["name"], p["launches"], p["total_ms"], p["total_ms"] / p["launches"] * 1e3))
