@@ -78,8 +78,22 @@ def rel_bucket(rel, num_buckets=32, max_distance=64):
     return ret + np.where(is_small, n, val_large)
 
 
+_REL_BIAS_CACHE = {}
+
+
 def rel_bias(table, T, scale):
-    """[H,T,T] additive bias: table[bucket(j-i), h] * scale. table [32,H]."""
+    """[H,T,T] additive bias: table[bucket(j-i), h] * scale. table [32,H].  Memoised per (table, T): the weights are fixed and the
+    reference recomputes the same tensor in every forward."""
+    key = (table.ctypes.data, table.shape, T, float(scale))
+    if key in _REL_BIAS_CACHE:
+        return _REL_BIAS_CACHE[key]
+    out = _REL_BIAS_CACHE[key] = _rel_bias(table, T, scale)
+    if len(_REL_BIAS_CACHE) > 64:
+        _REL_BIAS_CACHE.pop(next(iter(_REL_BIAS_CACHE)))
+    return out
+
+
+def _rel_bias(table, T, scale):
     pos = np.arange(T)
     bucket = rel_bucket(pos[None, :] - pos[:, None])
     return (table[bucket].transpose(2, 0, 1) * F32(scale)).astype(F32)
@@ -97,11 +111,9 @@ def attention_block(P, p, x, heads):
     qkv = qkv.reshape(B * heads, 3 * ch, T)
     q, k, v = qkv[:, :ch], qkv[:, ch:2 * ch], qkv[:, 2 * ch:]
     scale = F32(1.0 / math.sqrt(math.sqrt(ch)))
-    w = np.matmul((q * scale).transpose(0, 2, 1), k * scale).astype(F32)            # "bct,bcs->bts"
     bias = rel_bias(P[p + ".relative_pos_embeddings.relative_attention_bias.weight"], T, ch ** 0.5)
-    w = (w.reshape(B, heads, T, T) + bias[None]).reshape(B * heads, T, T)
-    w = ops.softmax(w, -1)
-    a = np.matmul(v, w.transpose(0, 2, 1)).astype(F32).reshape(B, C, T)               # "bts,bcs->bct"
+    # "bct,bcs->bts", + bias, softmax, "bts,bcs->bct"
+    a = ops.attention_weights_apply(q * scale, k * scale, v, bias, heads).reshape(B, C, T)
     return x + ops.conv1d(a, P[p + ".proj_out.weight"], P[p + ".proj_out.bias"])
 
 

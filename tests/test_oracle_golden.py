@@ -214,3 +214,27 @@ def test_vq_encode_path(weights, golden):
     codes, x_vq = vq.encode(weights, g["mel"])
     assert maxabs(x_vq, g["x_vq"]) < 1e-5
     assert np.array_equal(codes, g["codes"])
+
+
+def test_torch_backend_of_the_oracle_meets_the_same_fixtures(weights, golden):
+    """oracle/ops.py::use_torch - the multi-threaded fp32 torch-CPU building blocks bench.py's cpu_baseline leg times - run through the
+    same oracle code as the numpy forms: GPT latents, HF sampling loop, one DiffusionTts.forward, flow-VAE + HiFiGAN against the
+    REFERENCE's fixtures.  What is timed as the CPU baseline is therefore a checked restatement too."""
+    from oracle import diffusion as D, gpt as G, ops, vocoder as V
+    prev = ops.use_torch(True)
+    try:
+        g = golden("gpt_forced")
+        lat = G.latents_teacher_forced(weights, g["refer"], [g["refer"].shape[2]], g["text"].astype(np.int64), g["codes"])
+        assert np.abs(lat - g["latent"]).max() < 2e-4
+        g = golden("gpt_generate")
+        codes = G.generate(weights, g["refer"], [g["refer"].shape[2]], g["text"].astype(np.int64), int(g["seed"]), [int(g["sample_id"])],
+                           max_generate_length=10)
+        assert np.array_equal(codes, g["codes"])
+        g = golden("diff_forward")
+        out = D.diffusion_forward(weights, g["x"], g["ts"], g["code_emb"])
+        assert np.abs(out - g["out_cond"]).max() < 5e-5
+        g = golden("vocoder")
+        wav = V.infer_flowvae(weights, g["mel"], [g["mel"].shape[2]], int(g["seed"]), [int(g["sample_id"])])
+        assert np.sqrt(np.mean((wav - g["wav"]) ** 2)) < 1e-4
+    finally:
+        ops.use_torch(prev)

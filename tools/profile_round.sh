@@ -18,4 +18,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $(find /tmp/${TAG}_pmc_$c -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_$c/layer_counter_collection.csv
   rm -rf /tmp/${TAG}_pmc_$c
 done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d /tmp/${TAG}_pmcvoc_$c -o voc --output-format csv -- python $R/tools/bench_vocoder.py > $OUT/${TAG}_pmcvoc_$c.log 2>&1
+  mkdir -p $OUT/${TAG}_pmcvoc_$c
+  python - <<PY
+import csv, glob
+f = glob.glob("/tmp/${TAG}_pmcvoc_$c/**/*counter_collection.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if "resblock1x3_fused" in r["Kernel_Name"]]
+w = csv.DictWriter(open("$OUT/${TAG}_pmcvoc_$c/voc_counter_collection.csv", "w"), fieldnames=list(rows[0].keys()))
+w.writeheader(); w.writerows(rows)
+PY
+  rm -rf /tmp/${TAG}_pmcvoc_$c
+done
 du -sh $OUT
