@@ -51,7 +51,19 @@ def cpu_baseline(W, seed=1234):
         torch_threads = torch.get_num_threads()
     except Exception:
         torch_threads = 0
-    cores = max(blas, torch_threads) or os.cpu_count()
+    # 16 threads: on the GPU box (2 x 64-core EPYC 9575F, 256 logical CPUs) torch's default of 128 threads runs this workload 4.8x SLOWER
+    # than 16 (tools/cpu_sweep.py: one DiffusionTts.forward 0.60 s at 16 threads, 0.76 at 32, 1.34 at 64, 2.89 at 128): the baseline
+    # uses the count that is fastest there and reports it as `cores`
+    NT = min(16, os.cpu_count() or 16)
+    limits = None
+    try:
+        import torch
+        torch.set_num_threads(NT)
+        from threadpoolctl import threadpool_limits
+        limits = threadpool_limits(limits=NT)
+    except Exception:
+        pass
+    cores = NT
     prev = ops.use_torch(True)
     try:
         rs = np.random.RandomState(1)
@@ -80,11 +92,13 @@ def cpu_baseline(W, seed=1234):
         t_voc = time.time() - t0
     finally:
         ops.use_torch(prev)
+        if limits is not None:
+            limits.restore_original_limits()
     rest = t_steps * (50.0 / n_meas) + t_voc
     total = t_gpt + rest
     audio = N_CODES * 1024 / 24000.0
     return {"value": audio / total, "unit": "audio_s/s", "cores": int(cores), "kind": "port",
-            "threads": {"os_cpu_count": os.cpu_count(), "blas_threads": int(blas), "torch_get_num_threads": int(torch_threads)},
+            "threads": {"os_cpu_count": os.cpu_count(), "used": NT, "blas_default": int(blas), "torch_default": int(torch_threads)},
             "reference_in_build_container": {"value": round(audio / 86.3, 3), "unit": "audio_s/s", "cores": 8,
                                              "note": "the reference's OWN code on this utterance shape in the build container (8 vCPUs): its uncached HF sampling loop over 235 tokens 27.0 s + SynthesizerTrn.infer from the codes on 59.2 s (tests/golden/make_golden_e2e_fullsize.py log) = 86 s; not re-measured here: the reference cannot travel to the GPU box"},
             "sample": (f"1 utterance, T=936: GPT prefill + all 234 KV-cache decode steps {t_gpt:.1f}s ({(t_gpt - t_prefill) / N_CODES * 1e3:.0f} ms/token), "
