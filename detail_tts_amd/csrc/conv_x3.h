@@ -40,8 +40,9 @@ constexpr int X3D_HALO = 32;                          // left zero columns of it
 static inline int x3d_tp(int T) { return round_up(T, X3_BN) + 64 + X3D_HALO; }
 static inline size_t x3d_bytes(int B, int CP, int T) { return (size_t)B * (CP / 8) * 2 * x3d_tp(T) * 16; }
 // x [B][C][T] fp32 -> planes [B][CP/8][2][Tp][8 fp16], `halo` zero columns on the left, zero chunks for channels C .. CP - 1
+// sat (may be null): device flag set to 1 when a scaled value lies beyond fp16's range (the planes saturate there)
 void launch_split_planes_ex(const float* x, long long x_bs, int x_cs, int act, float slope, const int* lens, int T, int B, int C, int CP,
-                            int halo, int Tp, void* out, hipStream_t s);
+                            int halo, int Tp, void* out, hipStream_t s, int* sat = nullptr);
 // p.w3 / p.x3 / p.x3_tp / p.x3_halo, p.Cin = padded input channels; stride 1, no gate / phases / badd
 void launch_conv_x3d(const ConvParams& p, hipStream_t s);
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
 template <int ACT>
 __global__ __launch_bounds__(256) void split_planes_ex_kernel(const float* __restrict__ x, long long x_bs, int x_cs, float slope,
                                                              const int* __restrict__ lens, int T, int C, int C8P, int halo, int Tp,
-                                                             uint4* __restrict__ out) {
+                                                             uint4* __restrict__ out, int* __restrict__ sat) {
     const int tp = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, b = blockIdx.z;
     if (tp >= Tp) return;
     const int t = tp - halo, len = lens ? lens[b] : T;
@@ -175,6 +175,12 @@ __global__ __launch_bounds__(256) void split_planes_ex_kernel(const float* __res
             if (ACT == ACT_SILU) u = u * __frcp_rn(1.f + __expf(-u));
             v[e] = u * XS_SCALE_X;
         }
+        if (sat) {               // range check (option x3_range_check): split8 clamps beyond +-65504, silently wrong from there on
+            float m = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+            if (!(m <= 65504.f)) *sat = 1;
+        }
         split8(v, q0, q1);
     }
     uint4* o = out + ((long long)(b * C8P + c8) * NPL) * Tp + tp;
@@ -184,15 +190,15 @@ __global__ __launch_bounds__(256) void split_planes_ex_kernel(const float* __res
 }  // namespace
 
 void launch_split_planes_ex(const float* x, long long x_bs, int x_cs, int act, float slope, const int* lens, int T, int B, int C, int CP,
-                            int halo, int Tp, void* out, hipStream_t s) {
+                            int halo, int Tp, void* out, hipStream_t s, int* sat) {
     DTTS_REQUIRE(CP % 16 == 0 && CP >= C && halo >= 0 && Tp >= T + halo, "split_planes_ex: padding");
     DTTS_REQUIRE(act == ACT_NONE || act == ACT_LRELU || act == ACT_SILU, "split_planes_ex: activation");
     const dim3 grid(cdiv(Tp, 256), CP / 8, B);
     uint4* o = static_cast<uint4*>(out);
     ProfScope ps("split_planes_kernel", 0.0, (double)B * C * T * 8.0, s);
-    if (act == ACT_LRELU) hipLaunchKernelGGL(split_planes_ex_kernel<ACT_LRELU>, grid, dim3(256), 0, s, x, x_bs, x_cs, slope, lens, T, C, CP / 8, halo, Tp, o);
-    else if (act == ACT_SILU) hipLaunchKernelGGL(split_planes_ex_kernel<ACT_SILU>, grid, dim3(256), 0, s, x, x_bs, x_cs, slope, lens, T, C, CP / 8, halo, Tp, o);
-    else hipLaunchKernelGGL(split_planes_ex_kernel<ACT_NONE>, grid, dim3(256), 0, s, x, x_bs, x_cs, slope, lens, T, C, CP / 8, halo, Tp, o);
+    if (act == ACT_LRELU) hipLaunchKernelGGL(split_planes_ex_kernel<ACT_LRELU>, grid, dim3(256), 0, s, x, x_bs, x_cs, slope, lens, T, C, CP / 8, halo, Tp, o, sat);
+    else if (act == ACT_SILU) hipLaunchKernelGGL(split_planes_ex_kernel<ACT_SILU>, grid, dim3(256), 0, s, x, x_bs, x_cs, slope, lens, T, C, CP / 8, halo, Tp, o, sat);
+    else hipLaunchKernelGGL(split_planes_ex_kernel<ACT_NONE>, grid, dim3(256), 0, s, x, x_bs, x_cs, slope, lens, T, C, CP / 8, halo, Tp, o, sat);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

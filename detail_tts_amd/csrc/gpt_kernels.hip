@@ -543,7 +543,8 @@ void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const
                                  const float* fold_d, float* cache, long long cache_bs, int cache_cs, const GptCtl* ctl, int B, int H, int D,
                                  float* out, hipStream_t s) {
     DTTS_REQUIRE(D == 48, "decode attention head dim");
-    DTTS_REQUIRE(sizeof(float) * (size_t)cache_cs <= 60 * 1024, "decode attention: KV cache too long for the LDS score buffer");
+    // 64 KiB of LDS per workgroup by default: the dynamic score buffer + 5.1 KiB of static arrays (pvs 4 032 B, qkv_s 576 B, red)
+    DTTS_REQUIRE(sizeof(float) * (size_t)cache_cs + 5376 <= 64 * 1024, "decode attention: KV cache too long for the LDS score buffer");
     hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B, decode_attention_splits()), dim3(256), sizeof(float) * cache_cs, s, part,
                        slices, B, CoutP, stats, stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out);
     DTTS_CHECK_HIP(hipGetLastError());

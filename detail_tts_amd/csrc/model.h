@@ -199,6 +199,7 @@ public:
         if (key == "two_streams") opt_two_streams_ = value != 0;
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
+        else if (key == "x3_range_check") opt_range_check_ = value != 0;
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else throw Error(-1, "unknown option '" + key + "'");
     }
@@ -292,6 +293,10 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
+    bool opt_range_check_ = false;      // vocoder: detect activations beyond the split-precision planes' range (synchronises)
+    int* x3_sat_ = nullptr;             // device flag of the range check
+    int* x3_sat_flag(hipStream_t s);    // null unless the check is on; zeroed on s
+    void x3_sat_check(hipStream_t s);   // throws when the flag was raised
     int opt_cfg_streams_ = 0;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into; 0 = by batch size
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies

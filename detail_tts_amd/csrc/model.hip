@@ -46,6 +46,7 @@ Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) { DTTS_CHECK_H
 
 Model::~Model() {
     gpt_drop_graphs();
+    if (x3_sat_) (void)hipFree(x3_sat_);
     for (auto& kv : int_rings_) {
         IntRing& r = *kv.second;
         if (r.dev) (void)hipFree(r.dev);
@@ -789,8 +790,13 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     if (n_steps <= 0 || n_steps > n_steps_) n_steps = n_steps_;
     const size_t per_call = pair_ws_bytes(B, C, T);
     // the integrator outputs of all steps are evaluated up front (opt-out: DTTS_INTEG_PRECOMPUTE=0); Nu <= B distinct lengths
-    static const bool env_pre = []() { const char* v = getenv("DTTS_INTEG_PRECOMPUTE"); return !(v && v[0] == '0'); }();
-    const size_t integ_bytes = env_pre ? sizeof(float) * (size_t)n_steps * 2 * B * C * T + integ_ws_bytes(integ_chunk(B + 1) * 2 * B, C, T) : 0;
+    static const bool env_pre_on = []() { const char* v = getenv("DTTS_INTEG_PRECOMPUTE"); return !(v && v[0] == '0'); }();
+    // the precomputed integrator outputs of all steps cost n_steps * 2B * C * T floats (3 GB at batch 8 x 10 s, 11 GB at batch 4 x 60 s):
+    // beyond DTTS_INTEG_MAX_GB (default 24) the integrator is evaluated inside every step instead (same values, no table)
+    static const double max_gb = []() { const char* v = getenv("DTTS_INTEG_MAX_GB"); return v ? atof(v) : 24.0; }();
+    const size_t integ_table = sizeof(float) * (size_t)n_steps * 2 * B * C * T;
+    const bool env_pre = env_pre_on && (double)integ_table <= max_gb * 1073741824.0;
+    const size_t integ_bytes = env_pre ? integ_table + integ_ws_bytes(integ_chunk(B + 1) * 2 * B, C, T) : 0;
     ws().ensure(per_call + integ_bytes + sizeof(float) * ((size_t)2 * B * C * T + (size_t)2 * B * OC * T) + 8192);
     const PairPlan pl = plan_pair(lens_host, B, T, s);
     const int* lens2 = pl.lens2;

@@ -225,7 +225,7 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
     const bool x3 = xs && rb.c1[0].w3 && vocoder_x3();
     auto conv3 = [&](const PackedConv& pc, ConvParams p, const float* in) {
         const int Tp = x3d_tp(T);
-        launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s);
+        launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s, opt_range_check_ ? x3_sat_ : nullptr);
         p.w3 = pc.w3;
         p.x3 = xs;
         p.x3_tp = Tp;
@@ -295,6 +295,28 @@ void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, cons
     launch_resblock1x3_fused(p, s);
 }
 
+// Range check of the split-precision operands of the generator's wide ResBlock1 convs (their inputs are UNNORMALISED activations: beyond
+// +-65504 / 16 = 4094 the fp16 planes saturate and the conv is silently wrong).  Opt-in (dtts_set_option "x3_range_check" or
+// DTTS_X3_RANGE_CHECK=1): the verdict is read back at the end of the generator, which synchronises the stream.
+int* Model::x3_sat_flag(hipStream_t s) {
+    static const bool env_on = []() { const char* v = getenv("DTTS_X3_RANGE_CHECK"); return v && v[0] == '1'; }();
+    if (env_on) opt_range_check_ = true;
+    if (!opt_range_check_) return nullptr;
+    if (!x3_sat_) DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&x3_sat_), sizeof(int)));
+    DTTS_CHECK_HIP(hipMemsetAsync(x3_sat_, 0, sizeof(int), s));
+    return x3_sat_;
+}
+
+void Model::x3_sat_check(hipStream_t s) {
+    if (!opt_range_check_ || !x3_sat_) return;
+    int flag = 0;
+    DTTS_CHECK_HIP(hipMemcpyAsync(&flag, x3_sat_, sizeof(int), hipMemcpyDeviceToHost, s));
+    DTTS_CHECK_HIP(hipStreamSynchronize(s));
+    if (flag)
+        throw Error(-5, "vocoder: an activation exceeds the range of the split-precision planes (|x| > 4094): the wide ResBlock1 convs "
+                        "saturated - rerun with dtts_set_option(\"conv_x3\", 0) or DTTS_VOC_X3=0 (exact fp32 kernels)");
+}
+
 bool Model::vocoder_x3() const {
     static const bool env_on = []() { const char* v = getenv("DTTS_VOC_X3"); return !(v && v[0] == '0'); }();
     return env_on && use_x3();
@@ -316,7 +338,9 @@ void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_
     }
     float* tmp = ws().f32((size_t)B * ch * T);
     void* xs = ws().raw(x3d_bytes(B, round_up(ch, 16), T));
+    x3_sat_flag(s);
     resblock1_fwd(gen_[stage].rb[branch], x, tmp, y, ch, dl, B, T, s, xs);
+    x3_sat_check(s);
 }
 
 void Model::generator(const float* z, const float* g, const int* lens_host, int B, int T, float* wav, hipStream_t s, long long z_bs,
@@ -340,6 +364,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     float* T1 = ws().f32(buf);
     float* T2 = ws().f32(buf);
     float* gc = ws().f32((size_t)B * dec_cond_.CoutP);
+    x3_sat_flag(s);
     void* planes = nullptr;                            // fp16 operand planes of the wide stages' ResBlock1 convs
     if (size_t pb = generator_planes_bytes(cfg, B, T)) planes = ws().raw(pb);
     std::vector<int> l(B);
@@ -410,6 +435,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     o.epi_act = ACT_TANH;
     run_conv(dec_post_, o, s);
     ws().rewind(mark);
+    x3_sat_check(s);
 }
 
 static size_t generator_ws(const dtts_config& cfg, int B, int T) {

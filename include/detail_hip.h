@@ -236,6 +236,9 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *   "gpt_graph"   (default 0): 1 = dtts_gpt_decode replays captured hipGraphs (16-step chunks); 0 = the same launches issued
  *                 eagerly, 16 steps per call (measured faster on ROCm 7.2: a replayed kernel node costs ~0.8 us more than an eager
  *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
+ *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
+ *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
+ *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1;
  *   "conv_x3"     (default 1): diffusion-trunk convs and attention, and the generator's wide ResBlock1 convs, on the split-precision path (every fp32 operand as two
  *                 scaled fp16 planes, three fp16 MFMA products per fp32 product, fp32 accumulate: fp32-GEMM-class error);
  *                 0 = the exact fp32-MFMA kernels. */

@@ -249,6 +249,23 @@ def test_fused_resblock1_across_time_tiles_vs_oracle(rt, weights, stage, branch)
         assert maxabs(y[b, :, :L], ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), (stage, branch, b, maxabs(y[b, :, :L], ref))
 
 
+def test_split_precision_range_check_catches_saturation(weights):
+    """Option x3_range_check: an activation beyond the fp16 planes' range (|x| > 65504 / 16) in a wide ResBlock1 fails the call with a
+    message naming the exact-fp32 switch, instead of a silently saturated conv; in-range inputs pass and equal the unchecked result."""
+    from detail_tts_amd.runtime import DttsError, Runtime
+    rt2 = Runtime(weights, folded=True, parts=("vocoder",))
+    rs = np.random.RandomState(70)
+    x = (rs.randn(1, 200, 160) * 0.5).astype(np.float32)
+    base = host(rt2.op_resblock1(0, 1, dev(x)))
+    rt2.set_option("x3_range_check", 1)
+    assert np.array_equal(host(rt2.op_resblock1(0, 1, dev(x))), base)
+    x[0, 17, 40] = 5000.0
+    with pytest.raises(DttsError, match="conv_x3"):
+        rt2.op_resblock1(0, 1, dev(x))
+    rt2.set_option("conv_x3", 0)                       # the exact fp32 kernels take any finite input
+    assert np.isfinite(host(rt2.op_resblock1(0, 1, dev(x)))).all()
+
+
 @pytest.mark.parametrize("flow", [0, 3])
 def test_unit_wn_vs_oracle(rt, weights, flow):
     """dtts_op_wn: the WaveNet of one residual coupling layer (gated tanh * sigmoid, res / skip convs, global conditioning)."""
