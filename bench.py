@@ -410,7 +410,7 @@ def main():
                             "busy_ms": round(p["union_ms"], 2),
                             "tflops": round(p["flops"] / max(p["union_ms"], 1e-9) / 1e9, 2)} for p in prof], key=lambda k: -k["ms"])[:8],
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU baseline is a 1-GPU line item (rank 0 at N = 1 only)
         out["cpu_baseline"] = cpu_baseline(W)
     print(json.dumps(out))
     if multi:
