@@ -94,13 +94,25 @@ void Model::build_vocoder(hipStream_t stream) {
             for (int j = 0; j < cfg.n_resblock_kernels; ++j)
                 if (g.rb[j].k == 3 || g.rb[j].k == 7 || g.rb[j].k == 11)
                     for (int l = 0; l < 3; ++l) { wide.push_back(&g.rb[j].c1[l]); wide.push_back(&g.rb[j].c2[l]); }
+    // ... and, in A-fragment order, of the NARROW stages' (<= 32 channels: the LDS-resident fused kernel, resblock1_fused.hip)
+    std::vector<PackedConv*> narrow;
+    for (auto& g : gen_)
+        if (g.cout <= 32 && g.rb[0].c1[0].CoutP == 32)
+            for (int j = 0; j < cfg.n_resblock_kernels; ++j)
+                for (int l = 0; l < 3; ++l) { narrow.push_back(&g.rb[j].c1[l]); narrow.push_back(&g.rb[j].c2[l]); }
     size_t total = 0;
     for (PackedConv* pc : wide) total += (size_t)pc->KW * pc->CinP * pc->CoutP * 4 + 256;
+    for (PackedConv* pc : narrow) total += rb_fused_w3_bytes(pc->KW, pc->CinP) + 256;
     w3_voc_.ensure(total + 4096);
     for (PackedConv* pc : wide) {
         if (pc->CinP % 16 || pc->CoutP % 64) continue;
         void* dst = w3_voc_.raw((size_t)pc->KW * pc->CinP * pc->CoutP * 4);
         launch_split_weights(pc->w, pc->KW, pc->CinP, pc->CoutP, dst, stream);
+        pc->w3 = dst;
+    }
+    for (PackedConv* pc : narrow) {
+        void* dst = w3_voc_.raw(rb_fused_w3_bytes(pc->KW, pc->CinP));
+        launch_rb_pack_weights(pc->w, pc->KW, pc->CinP, pc->CoutP, pc->CinP, dst, stream);
         pc->w3 = dst;
     }
 }
@@ -222,7 +234,7 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
         return p;
     };
     // wide stages: leaky-relu + split into fp16 planes as one pass, then the dilated split-precision conv (conv_x3d.hip)
-    const bool x3 = xs && rb.c1[0].w3 && vocoder_x3();
+    const bool x3 = xs && rb.c1[0].w3 && rb.c1[0].CoutP % 64 == 0 && vocoder_x3();     // (narrow stages carry w3 in the fused kernel's fragment order)
     auto conv3 = [&](const PackedConv& pc, ConvParams p, const float* in) {
         const int Tp = x3d_tp(T);
         launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s, opt_range_check_ ? x3_sat_ : nullptr);
@@ -287,6 +299,10 @@ void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, cons
             p.b[(j * 3 + l) * 2] = st.rb[j].c1[l].b;
             p.w[(j * 3 + l) * 2 + 1] = st.rb[j].c2[l].w;
             p.b[(j * 3 + l) * 2 + 1] = st.rb[j].c2[l].b;
+            if (vocoder_x3()) {                          // split-precision form; conv_x3 = 0 / DTTS_VOC_X3=0: exact fp32 MFMA form
+                p.w3[(j * 3 + l) * 2] = st.rb[j].c1[l].w3;
+                p.w3[(j * 3 + l) * 2 + 1] = st.rb[j].c2[l].w3;
+            }
         }
     }
     for (int l = 0; l < 3; ++l) p.dil[l] = cfg.resblock_dilations[l];

@@ -72,12 +72,16 @@ struct RbFusedParams {
     int k[3] = {3, 7, 11}, dil[3] = {1, 3, 5};
     const float* w[18] = {};
     const float* b[18] = {};
+    const void* w3[18] = {};       // split-precision weights in A-fragment order (launch_rb_pack_weights); all set -> the fp16-pipe kernel
     int branch_mask = 7;
     float scale = 1.f / 3.f;
     int vec_ok = 0;                // set by the launcher
 };
 void launch_resblock1x3_fused(const RbFusedParams& p, hipStream_t s);
 int rb_fused_tile(int CP);         // interior samples per workgroup (CP = 16 | 32 padded channels)
+size_t rb_fused_w3_bytes(int KW, int CP);
+// wp: packed fp32 weights [KW][CinP][CoutP] -> [K-step = (tap, 16-channel half)][plane][lane][8 fp16] for v_mfma_f32_32x32x16_f16
+void launch_rb_pack_weights(const float* wp, int KW, int CinP, int CoutP, int CP, void* out, hipStream_t s);
 void launch_add3_scale(const float* x0, const float* x1, const float* x2, float alpha, float* y, long long n, hipStream_t s);
 
 }  // namespace dtts

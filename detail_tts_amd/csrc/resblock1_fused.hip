@@ -22,6 +22,7 @@
 
 #include "ops.h"
 #include "prof.h"
+#include "split3.h"
 
 namespace dtts {
 
@@ -211,9 +212,218 @@ __global__ __launch_bounds__(256, 1) void resblock1x3_fused_kernel(const RbFused
             for (int e = 0; e < 4 && t + e < len; ++e) dst[e] = sp[e];
     }
 }
+
+// =============================================================================================================================
+// Split-precision variant (the default): the same tile, the same dataflow, on v_mfma_f32_32x32x16_f16 with every operand as two
+// fp16 planes and three cross products (split3.h, conv_x3.h) - the fp32 instruction above is 16 x slower per flop and was the bound
+// of the fp32 form (462 GFLOP in 5.9 ms).  Activations live in the LDS as operand planes [plane][8-channel chunk][column][8 fp16]
+// (x XS_SCALE_X, leaky-relu applied by the producer), so a B fragment (8 channels of one column per lane) is one ds_read_b128 per
+// plane and a tap is a column offset; a conv's epilogue re-splits its output (each lane holds 4 consecutive channels of a column:
+// half a chunk) straight into the other buffer.  Weights are pre-split at bind time into A-fragment order
+// [K-step = (tap, 16-channel half)][plane][lane][8 fp16] (x XS_SCALE_W).  M = 32 output rows per instruction: 25 -> 32 (78 % used),
+// 12 -> 32 (37 %: still 2.7 x the fp32 form).
+typedef float f32x16r __attribute__((ext_vector_type(16)));
+
+template <int CP>
+struct RbxGeo {
+    static constexpr int W = CP == 16 ? 1024 : 512;          // staged columns, a multiple of 128 (4 waves x 32-column tiles)
+    static constexpr int G = 32;                             // guard columns per side (>= the largest conv padding, 25)
+    static constexpr int WP = W + 2 * G;
+    static constexpr int TT = W - 2 * RBF_H;
+    static constexpr int NT = W / 128;                       // 32-column tiles per wave
+    static constexpr int C8 = CP / 8;                        // 8-channel chunks
+    static constexpr int NH = CP / 16;                       // 16-channel K halves per tap
+    static constexpr int RG = CP / 8;                        // 4-row register groups of the accumulator that hold real channels... per half
+    static constexpr int BUF = 2 * C8 * WP * 16;             // bytes of one activation buffer (both planes)
+    static_assert(TT % 4 == 0, "interior must keep 16-byte stores aligned");
+    static_assert(BUF >= W * CP * 4, "the fp32 staging of a branch start must fit one buffer");
+};
+
+__global__ __launch_bounds__(256) void rbx_pack_weights_kernel(const float* __restrict__ wp, int KW, int CinP, int CoutP, int NH, uint4* __restrict__ out) {
+    // out[(kstep * 2 + plane) * 64 + lane], kstep = tap * NH + h16; lane: co = lane & 31, ci = 16 h16 + 8 (lane >> 5) + e
+    const int ks = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 64) return;
+    const int tap = ks / NH, h16 = ks - tap * NH, co = lane & 31, ci0 = 16 * h16 + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (co < CoutP && ci0 + e < CinP) ? wp[((long long)tap * CinP + ci0 + e) * CoutP + co] * XS_SCALE_W : 0.f;
+    uint4 q0, q1;
+    split8(v, q0, q1);
+    out[(ks * 2 + 0) * 64 + lane] = q0;
+    out[(ks * 2 + 1) * 64 + lane] = q1;
+}
+
+template <int CP, int K, int MODE>
+__device__ __forceinline__ void rbx_conv(const uint4* __restrict__ wf, const float* __restrict__ bias, int dil, const unsigned char* src,
+                                         unsigned char* dst, float (&res)[RbxGeo<CP>::NT][CP / 2], int lane, int wcol0, int tglob0, int len) {
+    using Gm = RbxGeo<CP>;
+    constexpr int NT = Gm::NT, WP = Gm::WP, C8 = Gm::C8, NH = Gm::NH, NKS = K * NH, NR = CP / 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int pad = (K - 1) * dil / 2;
+    f32x16r acc[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    // B fragment of (tap, h16): chunk c8 = 2 h16 + lhi, column wcol0 + 32 ct + l31 + tap dil - pad
+    const unsigned char* sl = src + ((long long)lhi * WP + Gm::G + wcol0 + l31 - pad) * 16;
+    hf8 a_cur[2], a_nxt[2];
+    a_cur[0] = __builtin_bit_cast(hf8, wf[lane]);
+    a_cur[1] = __builtin_bit_cast(hf8, wf[64 + lane]);
+    int tap = 0, h16 = 0;
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) {
+            a_nxt[0] = __builtin_bit_cast(hf8, wf[(ks + 1) * 128 + lane]);
+            a_nxt[1] = __builtin_bit_cast(hf8, wf[(ks + 1) * 128 + 64 + lane]);
+        }
+        const unsigned char* sp = sl + ((long long)(2 * h16) * WP + tap * dil) * 16;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const hf8 b0 = *reinterpret_cast<const hf8*>(sp + ct * 512);
+            const hf8 b1 = *reinterpret_cast<const hf8*>(sp + ct * 512 + C8 * WP * 16);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b0, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b1, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b0, acc[ct], 0, 0, 0);
+        }
+        a_cur[0] = a_nxt[0];
+        a_cur[1] = a_nxt[1];
+        if (++h16 == NH) { h16 = 0; ++tap; }
+    }
+    // epilogue: lane (column l31, half lhi) holds rows 8 rg + 4 lhi + (0..3) in registers 4 rg .. 4 rg + 3: half of chunk rg
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const int col = wcol0 + ct * 32 + l31, t = tglob0 + col;
+        const bool valid = t >= 0 && t < len;
+#pragma unroll
+        for (int rg = 0; rg < C8; ++rg) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u = acc[ct][4 * rg + e] * XS_ACC_SCALE + bias[8 * rg + 4 * lhi + e];
+                if (MODE == 1) u += res[ct][4 * rg + e];
+                u = valid ? u : 0.f;
+                if (MODE == 1) res[ct][4 * rg + e] = u;
+                v[e] = fmaxf(u * XS_SCALE_X, u * (0.1f * XS_SCALE_X));      // lrelu(u) * scale (both factors positive)
+            }
+            unsigned w0[2], w1[2];
+            split_pair(v[0], v[1], w0[0], w1[0]);
+            split_pair(v[2], v[3], w0[1], w1[1]);
+            unsigned char* o = dst + ((long long)rg * WP + Gm::G + col) * 16 + lhi * 8;
+            *reinterpret_cast<uint2*>(o) = make_uint2(w0[0], w0[1]);
+            *reinterpret_cast<uint2*>(o + C8 * WP * 16) = make_uint2(w1[0], w1[1]);
+        }
+    }
+}
+
+template <int CP, int K>
+__device__ __forceinline__ void rbx_branch(const RbFusedParams& p, int br, unsigned char* bufL, unsigned char* bufB,
+                                           float (&res)[RbxGeo<CP>::NT][CP / 2], int lane, int wcol0, int tglob0, int len) {
+#pragma unroll 1
+    for (int li = 0; li < 3; ++li) {
+        const int q = (br * 3 + li) * 2;
+        rbx_conv<CP, K, 0>(static_cast<const uint4*>(p.w3[q]), p.b[q], p.dil[li], bufL, bufB, res, lane, wcol0, tglob0, len);
+        __syncthreads();
+        rbx_conv<CP, K, 1>(static_cast<const uint4*>(p.w3[q + 1]), p.b[q + 1], 1, bufB, bufL, res, lane, wcol0, tglob0, len);
+        __syncthreads();
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(256, 1) void resblock1x3_fused_x3_kernel(const RbFusedParams p) {
+    using Gm = RbxGeo<CP>;
+    constexpr int W = Gm::W, WP = Gm::WP, TT = Gm::TT, NT = Gm::NT, C8 = Gm::C8, NR = CP / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* bufL = ldsb;
+    unsigned char* bufB = ldsb + Gm::BUF;
+    float* stage = reinterpret_cast<float*>(bufB);          // fp32 [CP][W] view of bufB at a branch start / for the final mean
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int len = p.lens ? p.lens[b] : p.T;
+    if (t0 >= len) return;
+    const int tglob0 = t0 - RBF_H;
+    const int wcol0 = wave * (W / 4);
+    const float* xb = p.x + (long long)b * p.x_bs;
+    for (int i = tid; i < 2 * Gm::BUF / 16; i += 256) reinterpret_cast<uint4*>(ldsb)[i] = make_uint4(0, 0, 0, 0);      // guards: finite
+    __syncthreads();
+
+    float res[NT][NR], mean[NT][NR];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) mean[ct][r] = 0.f;
+
+#pragma unroll 1
+    for (int br = 0; br < 3; ++br) {
+        if (!((p.branch_mask >> br) & 1)) continue;
+        // stage the tile: thread = (8-channel chunk, column): raw fp32 -> `stage` (source of the residual registers), lrelu + split -> bufL
+        for (int i = tid; i < C8 * W; i += 256) {
+            const int c8 = i / W, col = i - c8 * W, t = tglob0 + col;
+            float v[8], a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = 8 * c8 + e;
+                v[e] = (ch < p.C && t >= 0 && t < len) ? xb[(long long)ch * p.x_cs + t] : 0.f;
+                stage[ch * W + col] = v[e];
+                a[e] = lrelu01(v[e]) * XS_SCALE_X;
+            }
+            uint4 q0, q1;
+            split8(a, q0, q1);
+            unsigned char* o = bufL + ((long long)c8 * WP + Gm::G + col) * 16;
+            *reinterpret_cast<uint4*>(o) = q0;
+            *reinterpret_cast<uint4*>(o + C8 * WP * 16) = q1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int rg = 0; rg < C8; ++rg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[ct][4 * rg + e] = stage[(8 * rg + 4 * lhi + e) * W + wcol0 + ct * 32 + l31];
+        __syncthreads();
+        // bufB was used as fp32 staging: its guard columns must be zero again before it serves as an operand buffer (every other
+        // column is rewritten by the first convs1 epilogue before anything reads it)
+        for (int i = tid; i < 2 * C8 * 2 * Gm::G; i += 256) {
+            const int row = i / (2 * Gm::G), g = i - row * (2 * Gm::G);
+            reinterpret_cast<uint4*>(bufB)[row * WP + (g < Gm::G ? g : W + g)] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        if (br == 0) rbx_branch<CP, 3>(p, 0, bufL, bufB, res, lane, wcol0, tglob0, len);
+        else if (br == 1) rbx_branch<CP, 7>(p, 1, bufL, bufB, res, lane, wcol0, tglob0, len);
+        else rbx_branch<CP, 11>(p, 2, bufL, bufB, res, lane, wcol0, tglob0, len);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) mean[ct][r] += res[ct][r];
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int rg = 0; rg < C8; ++rg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stage[(8 * rg + 4 * lhi + e) * W + wcol0 + ct * 32 + l31] = mean[ct][4 * rg + e] * p.scale;
+    __syncthreads();
+    float* yb = p.y + (long long)b * p.y_bs;
+    for (int i = tid; i < p.C * (TT / 4); i += 256) {
+        const int row = i / (TT / 4), c4 = i - row * (TT / 4), t = t0 + c4 * 4;
+        if (t >= len) continue;
+        const float* sp = stage + row * W + RBF_H + c4 * 4;
+        float* dstp = yb + (long long)row * p.y_cs + t;
+        if (t + 3 < len && p.vec_ok) *reinterpret_cast<float4*>(dstp) = *reinterpret_cast<const float4*>(sp);
+        else
+            for (int e = 0; e < 4 && t + e < len; ++e) dstp[e] = sp[e];
+    }
+}
 }  // namespace
 
 int rb_fused_tile(int CP) { return CP == 16 ? RbfGeo<16>::TT : RbfGeo<32>::TT; }
+
+size_t rb_fused_w3_bytes(int KW, int CP) { return (size_t)KW * (CP / 16) * 2 * 64 * 16; }
+
+void launch_rb_pack_weights(const float* wp, int KW, int CinP, int CoutP, int CP, void* out, hipStream_t s) {
+    DTTS_REQUIRE(CP == 16 || CP == 32, "fused ResBlock1 weight packing: padded channels 16 / 32");
+    hipLaunchKernelGGL(rbx_pack_weights_kernel, dim3(KW * (CP / 16)), dim3(64), 0, s, wp, KW, CinP, CoutP, CP / 16, static_cast<uint4*>(out));
+    DTTS_CHECK_HIP(hipGetLastError());
+}
 
 void launch_resblock1x3_fused(const RbFusedParams& p_in, hipStream_t s) {
     RbFusedParams p = p_in;
@@ -240,6 +450,19 @@ void launch_resblock1x3_fused(const RbFusedParams& p_in, hipStream_t s) {
     for (int j = 0; j < 3; ++j) taps += ((p.branch_mask >> j) & 1) ? p.k[j] : 0;
     const double n = (double)p.B * p.T;
     ProfScope ps("resblock1x3_fused_kernel", 2.0 * 6.0 * taps * p.C * p.C * n, 8.0 * p.C * n, s);
+    if (p.w3[0]) {                  // split-precision form (weights pre-split into fragment order)
+        for (int q = 0; q < 18; ++q) DTTS_REQUIRE(p.w3[q] && p.b[q], "fused ResBlock1 (split precision): weights / biases");
+        static bool attr3 = false;
+        if (!attr3) {
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<16>::BUF));
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<32>::BUF));
+            attr3 = true;
+        }
+        if (CP == 16) hipLaunchKernelGGL(resblock1x3_fused_x3_kernel<16>, dim3(cdiv(p.T, RbxGeo<16>::TT), p.B), dim3(256), 2 * RbxGeo<16>::BUF, s, p);
+        else hipLaunchKernelGGL(resblock1x3_fused_x3_kernel<32>, dim3(cdiv(p.T, RbxGeo<32>::TT), p.B), dim3(256), 2 * RbxGeo<32>::BUF, s, p);
+        DTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     if (CP == 16) hipLaunchKernelGGL(resblock1x3_fused_kernel<16>, dim3(cdiv(p.T, RbfGeo<16>::TT), p.B), dim3(256), l16, s, p);
     else hipLaunchKernelGGL(resblock1x3_fused_kernel<32>, dim3(cdiv(p.T, RbfGeo<32>::TT), p.B), dim3(256), l32, s, p);
     DTTS_CHECK_HIP(hipGetLastError());
