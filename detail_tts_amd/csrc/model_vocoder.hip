@@ -308,6 +308,7 @@ void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, cons
     for (int l = 0; l < 3; ++l) p.dil[l] = cfg.resblock_dilations[l];
     p.branch_mask = branch_mask;
     p.scale = scale;
+    p.sat = opt_range_check_ ? x3_sat_ : nullptr;
     launch_resblock1x3_fused(p, s);
 }
 
@@ -349,7 +350,9 @@ void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
     if (rb_fused_ok(gen_[stage], ch)) {           // narrow stages: the same fused kernel the generator runs, one branch, no mean
+        x3_sat_flag(s);
         rb_fused(gen_[stage], x, y, ch, dl, B, T, 1 << branch, 1.f, s);
+        x3_sat_check(s);
         return;
     }
     float* tmp = ws().f32((size_t)B * ch * T);

@@ -76,6 +76,7 @@ struct RbFusedParams {
     int branch_mask = 7;
     float scale = 1.f / 3.f;
     int vec_ok = 0;                // set by the launcher
+    int* sat = nullptr;            // optional device flag: set to 1 when an activation exceeds the fp16 planes' range (x3_range_check)
 };
 void launch_resblock1x3_fused(const RbFusedParams& p, hipStream_t s);
 int rb_fused_tile(int CP);         // interior samples per workgroup (CP = 16 | 32 padded channels)

@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void rbx_pack_weights_kernel(const float* __re
     out[(ks * 2 + 1) * 64 + lane] = q1;
 }
 
-template <int CP, int K, int MODE>
+template <int CP, int K, int MODE, bool SAT>
 __device__ __forceinline__ void rbx_conv(const uint4* __restrict__ wf, const float* __restrict__ bias, int dil, const unsigned char* src,
-                                         unsigned char* dst, float (&res)[RbxGeo<CP>::NT][CP / 2], int lane, int wcol0, int tglob0, int len) {
+                                         unsigned char* dst, float (&res)[RbxGeo<CP>::NT][CP / 2], int lane, int wcol0, int tglob0, int len,
+                                         int* sat) {
     using Gm = RbxGeo<CP>;
     constexpr int NT = Gm::NT, WP = Gm::WP, C8 = Gm::C8, NH = Gm::NH, NKS = K * NH, NR = CP / 2;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -305,6 +306,7 @@ __device__ __forceinline__ void rbx_conv(const uint4* __restrict__ wf, const flo
                 if (MODE == 1) res[ct][4 * rg + e] = u;
                 v[e] = fmaxf(u * XS_SCALE_X, u * (0.1f * XS_SCALE_X));      // lrelu(u) * scale (both factors positive)
             }
+            if (SAT && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) <= 65504.f)) *sat = 1;
             unsigned w0[2], w1[2];
             split_pair(v[0], v[1], w0[0], w1[0]);
             split_pair(v[2], v[3], w0[1], w1[1]);
@@ -315,20 +317,20 @@ __device__ __forceinline__ void rbx_conv(const uint4* __restrict__ wf, const flo
     }
 }
 
-template <int CP, int K>
+template <int CP, int K, bool SAT>
 __device__ __forceinline__ void rbx_branch(const RbFusedParams& p, int br, unsigned char* bufL, unsigned char* bufB,
                                            float (&res)[RbxGeo<CP>::NT][CP / 2], int lane, int wcol0, int tglob0, int len) {
 #pragma unroll 1
     for (int li = 0; li < 3; ++li) {
         const int q = (br * 3 + li) * 2;
-        rbx_conv<CP, K, 0>(static_cast<const uint4*>(p.w3[q]), p.b[q], p.dil[li], bufL, bufB, res, lane, wcol0, tglob0, len);
+        rbx_conv<CP, K, 0, SAT>(static_cast<const uint4*>(p.w3[q]), p.b[q], p.dil[li], bufL, bufB, res, lane, wcol0, tglob0, len, p.sat);
         __syncthreads();
-        rbx_conv<CP, K, 1>(static_cast<const uint4*>(p.w3[q + 1]), p.b[q + 1], 1, bufB, bufL, res, lane, wcol0, tglob0, len);
+        rbx_conv<CP, K, 1, SAT>(static_cast<const uint4*>(p.w3[q + 1]), p.b[q + 1], 1, bufB, bufL, res, lane, wcol0, tglob0, len, p.sat);
         __syncthreads();
     }
 }
 
-template <int CP>
+template <int CP, bool SAT>
 __global__ __launch_bounds__(256, 1) void resblock1x3_fused_x3_kernel(const RbFusedParams p) {
     using Gm = RbxGeo<CP>;
     constexpr int W = Gm::W, WP = Gm::WP, TT = Gm::TT, NT = Gm::NT, C8 = Gm::C8, NR = CP / 2;
@@ -366,6 +368,12 @@ __global__ __launch_bounds__(256, 1) void resblock1x3_fused_x3_kernel(const RbFu
                 stage[ch * W + col] = v[e];
                 a[e] = lrelu01(v[e]) * XS_SCALE_X;
             }
+            if (SAT) {
+                float m = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(a[e]));
+                if (!(m <= 65504.f)) *p.sat = 1;
+            }
             uint4 q0, q1;
             split8(a, q0, q1);
             unsigned char* o = bufL + ((long long)c8 * WP + Gm::G + col) * 16;
@@ -387,9 +395,9 @@ __global__ __launch_bounds__(256, 1) void resblock1x3_fused_x3_kernel(const RbFu
             reinterpret_cast<uint4*>(bufB)[row * WP + (g < Gm::G ? g : W + g)] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        if (br == 0) rbx_branch<CP, 3>(p, 0, bufL, bufB, res, lane, wcol0, tglob0, len);
-        else if (br == 1) rbx_branch<CP, 7>(p, 1, bufL, bufB, res, lane, wcol0, tglob0, len);
-        else rbx_branch<CP, 11>(p, 2, bufL, bufB, res, lane, wcol0, tglob0, len);
+        if (br == 0) rbx_branch<CP, 3, SAT>(p, 0, bufL, bufB, res, lane, wcol0, tglob0, len);
+        else if (br == 1) rbx_branch<CP, 7, SAT>(p, 1, bufL, bufB, res, lane, wcol0, tglob0, len);
+        else rbx_branch<CP, 11, SAT>(p, 2, bufL, bufB, res, lane, wcol0, tglob0, len);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -454,12 +462,17 @@ void launch_resblock1x3_fused(const RbFusedParams& p_in, hipStream_t s) {
         for (int q = 0; q < 18; ++q) DTTS_REQUIRE(p.w3[q] && p.b[q], "fused ResBlock1 (split precision): weights / biases");
         static bool attr3 = false;
         if (!attr3) {
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<16>::BUF));
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<32>::BUF));
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<16>::BUF));
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<32>::BUF));
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<16>::BUF));
+            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<32>::BUF));
             attr3 = true;
         }
-        if (CP == 16) hipLaunchKernelGGL(resblock1x3_fused_x3_kernel<16>, dim3(cdiv(p.T, RbxGeo<16>::TT), p.B), dim3(256), 2 * RbxGeo<16>::BUF, s, p);
-        else hipLaunchKernelGGL(resblock1x3_fused_x3_kernel<32>, dim3(cdiv(p.T, RbxGeo<32>::TT), p.B), dim3(256), 2 * RbxGeo<32>::BUF, s, p);
+        const dim3 g16(cdiv(p.T, RbxGeo<16>::TT), p.B), g32(cdiv(p.T, RbxGeo<32>::TT), p.B);
+        if (CP == 16 && !p.sat) hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<16, false>), g16, dim3(256), 2 * RbxGeo<16>::BUF, s, p);
+        else if (CP == 16) hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<16, true>), g16, dim3(256), 2 * RbxGeo<16>::BUF, s, p);
+        else if (!p.sat) hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<32, false>), g32, dim3(256), 2 * RbxGeo<32>::BUF, s, p);
+        else hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<32, true>), g32, dim3(256), 2 * RbxGeo<32>::BUF, s, p);
         DTTS_CHECK_HIP(hipGetLastError());
         return;
     }

@@ -264,6 +264,12 @@ def test_split_precision_range_check_catches_saturation(weights):
         rt2.op_resblock1(0, 1, dev(x))
     rt2.set_option("conv_x3", 0)                       # the exact fp32 kernels take any finite input
     assert np.isfinite(host(rt2.op_resblock1(0, 1, dev(x)))).all()
+    rt2.set_option("conv_x3", 1)                       # the fused narrow-stage kernel splits inside the workgroup: same check
+    y = (rs.randn(1, 12, 300) * 0.5).astype(np.float32)
+    host(rt2.op_resblock1(4, 2, dev(y)))
+    y[0, 3, 150] = -60000.0                            # lrelu -> -6000: beyond +-4094
+    with pytest.raises(DttsError, match="conv_x3"):
+        rt2.op_resblock1(4, 2, dev(y))
 
 
 @pytest.mark.parametrize("flow", [0, 3])
