@@ -37,3 +37,14 @@ def e2e_inputs(seed=21):
     d["text"] = np.concatenate([rs.randint(3, 255, (1, L_TEXT)), [[0]]], 1).astype(np.int32)
     d["codes"] = rs.randint(0, 8192, (1, N_CODES)).astype(np.int64)
     return d
+
+
+def e2e_inputs_b(seed=22):
+    """A second, SHORTER utterance (7.5 s prompt = 700 frames, 40 text ids, 150 codes -> T = 600): with e2e_inputs() it makes a ragged batch
+    whose rows are both pinned by the reference's own waveforms (tests/golden/e2e_fullsize_b.npz)."""
+    rs = np.random.RandomState(seed)
+    d = {"seed_inputs": seed}
+    d["refer"] = (rs.randn(1, 128, 700) * 2 - 5).astype(np.float32)
+    d["text"] = np.concatenate([rs.randint(3, 255, (1, 40)), [[0]]], 1).astype(np.int32)
+    d["codes"] = rs.randint(0, 8192, (1, 150)).astype(np.int64)
+    return d

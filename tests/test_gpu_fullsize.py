@@ -365,6 +365,34 @@ def test_e2e_234_codes_row5_of_ragged_B8_vs_reference_waveform(synth, E, EI, x3)
     assert float(E["wav_rms"]) > 20 * r
 
 
+def test_e2e_two_rows_of_a_ragged_B8_batch_both_vs_reference_waveforms(synth, E, EI, golden):
+    """A ragged batch of 8 in which TWO rows are pinned by the reference's own waveforms: row 5 = the 234-code / 936-frame utterance
+    (e2e_fullsize.npz), row 2 = a SHORTER one (150 codes, 700-frame prompt, 40 text ids: e2e_fullsize_b.npz) - padded prompt, padded
+    text, padded codes, a different sequence length in every kernel of stages A, B and C - each against the run the reference made of
+    that utterance ALONE (vqvae/model_24k.py:774-810 is batch 1)."""
+    from fullsize_inputs import e2e_inputs_b
+    EB, J = golden("e2e_fullsize_b"), e2e_inputs_b()
+    refer, rl, text, tl, codes, n = _ragged_batch8(EI)
+    refer[2] = 0.0
+    refer[2, :, :700] = J["refer"][0]
+    rl[2] = 700
+    text[2] = 0
+    text[2, :41] = J["text"][0]
+    tl[2] = 41
+    codes[2] = J["codes"][0]
+    n[2] = 150
+    sids = [100, 101, int(EB["sample_id"]), 103, 104, int(E["sample_id"]), 106, 107]
+    wav, lens = synth.infer(torch.from_numpy(text), torch.tensor(tl), torch.from_numpy(refer), torch.tensor(rl), batch=True,
+                            seed=int(E["seed"]), sample_ids=sids, forced_codes=codes, return_lengths=True)
+    assert lens == [1024 * v for v in n]
+    for row, ref in ((5, E), (2, EB)):
+        w = host(wav)[row, 0, : lens[row]]
+        r = rms(w, ref["wav"])
+        print(f"\n[ragged B=8, row {row}: {lens[row] // 1024} codes] waveform RMS error {r:.3e} (reference RMS {float(ref['wav_rms']):.3e})")
+        assert r < 1e-3 and float(ref["wav_rms"]) > 20 * r, (row, r)
+        assert np.all(host(wav)[row, 0, lens[row]:] == 0)
+
+
 @pytest.mark.parametrize("x3", [1, 0])
 def test_e2e_sampler_drift_along_the_50_step_chain(synth, E, EI, x3):
     """Where along the chain does the error grow?  The sampler state after p_sample 49 / 40 / 25 / 0 and the de-normalised mel vs the
