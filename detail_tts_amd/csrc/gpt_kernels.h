@@ -65,7 +65,9 @@ void launch_gemv_block(int pro, const float* W, int K, int CoutP, const GemvIn& 
 int decode_attention_splits();
 void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* stats, int stats_slices, const float* fold_c,
                                  const float* fold_d, float* cache, long long cache_bs, int cache_cs, const GptCtl* ctl, int B, int H, int D,
-                                 float* out, hipStream_t s);
+                                 float* out, hipStream_t s, const float* wproj = nullptr, int wpCoutP = 0);
+// wproj (K-major packed [C][wpCoutP] weight of the attention's output projection) given: the projection is applied in the same
+// kernel; out = per-head partials [H][B][wpCoutP] for a GP_RESSUM GEMV with in_slices = H (no key split, no GP_ATTN GEMV)
 
 // copy k,v rows of a prefill qkv buffer [B, 3C, L] into the cache (columns 0..len-1)
 void launch_kv_to_cache(const float* qkv, long long bs, int cs, const int* lens, int L, int B, int C, float* cache, long long cache_bs,
@@ -101,5 +103,41 @@ struct SamplerParams {
     int C;
 };
 void launch_sampler(const SamplerParams& p, hipStream_t s);
+
+// ---- one decode token as ONE persistent kernel (gpt_token.hip): 128 resident workgroups, activations exchanged through memory as
+// {value, tag} words.  Replaces the 5-launches-per-layer chain for sessions of <= 8 rows on the GPT-2 shape of the reference config.
+constexpr int GPT_TOKEN_WGS = 128;
+constexpr int GPT_TOKEN_MAX_LAYERS = 12;
+constexpr int GPT_TOKEN_VS = 66 * GPT_TOKEN_WGS;                     // logits row stride (mel_head columns padded to 66 per workgroup)
+constexpr int GPT_TOKEN_XCH_WORDS = 8 * 768 * 6 + 128 * 128 * 48;    // exchange arena, 8-byte words
+struct GptTokenLayer {
+    const float4 *wq, *wp, *wf;      // c_attn / attention c_proj / c_fc repacked in register order (launch_gpt_token_pack 0 / 1 / 2)
+    const float* w2;                 // mlp c_proj, K-major [3072][768] as bound
+    const float *bq, *bp, *bf, *b2, *g1, *be1, *g2, *be2;
+};
+struct GptTokenParams {
+    const GptTokenLayer* L;          // [NL] in DEVICE memory (indexed by the layer loop: a by-value table would be copied to scratch)
+    int NL;
+    const float4* wh;                // mel_head repacked (which = 3)
+    const float* bh;                 // its bias, zero-padded to GPT_TOKEN_VS
+    int Vs;
+    const float *lnf_g, *lnf_b, *fin_g, *fin_b;
+    const float* x_in;               // [B][768] input embeddings of this token (the sampler's x_next)
+    float* kv;                       // KV cache: per layer kv_layer floats, per row kv_bs, K [768][cap] | V [cap][768]
+    long long kv_layer, kv_bs;
+    int cap;
+    const GptCtl* ctl;
+    int B;
+    unsigned long long* xch;         // GPT_TOKEN_XCH_WORDS words, zeroed when allocated
+    float* lat;                      // [B][768] final_norm(ln_f(h))
+    float* logits;                   // [B][Vs]
+    int* err;                        // raised when an exchange poll times out
+    unsigned* epoch;                 // launch counter (>= 1), bumped by the kernel
+    long long* trace;                // debug: wall-clock stamps (DTTS_GPT_TOKEN_TRACE), normally null
+};
+bool gpt_token_supported(int C, int H, int F, int NL, int V);
+size_t gpt_token_pack_floats(int which);
+void launch_gpt_token_pack(int which, const float* W, int N, int CoutP, float* out, hipStream_t s);
+void launch_gpt_token(const GptTokenParams& p, hipStream_t s);
 
 }  // namespace dtts

@@ -103,6 +103,7 @@ __device__ __forceinline__ float sum_parts(const float* __restrict__ parts, int 
         case 1: return p[0];
         case 6: return sum_parts_n<6>(p, slice_stride);
         case 12: return sum_parts_n<12>(p, slice_stride);
+        case 16: return sum_parts_n<16>(p, slice_stride);
         case 24: return sum_parts_n<24>(p, slice_stride);
         default: break;
     }
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(512) void gemv_block_kernel(const float* __restrict
             case 1: DTTS_GEMV_PARTS(1) break;
             case 6: DTTS_GEMV_PARTS(6) break;
             case 12: DTTS_GEMV_PARTS(12) break;
+            case 16: DTTS_GEMV_PARTS(16) break;
             case 24: DTTS_GEMV_PARTS(24) break;
             default:
 #pragma unroll
@@ -410,13 +412,26 @@ void launch_gemv_block(int pro, const float* W, int K, int CoutP, const GemvIn& 
 // and the attention projection's GEMV prologue (GP_ATTN) combines them.  c_attn's finish is folded in: every split sums the qkv GEMV
 // partials of its head and applies the LayerNorm algebra (row statistics from the producing GEMV); the LAST split appends k and v to
 // the cache and owns the new key.  The token position comes from the device-side control block.
-template <int D>
+// PROJ (grid.z = 1: no key split): the attention output projection (HF c_proj of the attention block, gpt/model.py via GPT2Attention) is
+// applied in the same kernel - a (head, row) workgroup multiplies its normalised 48-vector by the head's 48 rows of W_proj, which it
+// loaded into registers (144 per thread: 3 columns x 48 rows) BEFORE the attention, and leaves a per-HEAD partial [H][B][C] that the
+// next GEMV's residual prologue sums (16 slices).  One launch per layer less: under the diffusion trunk every dependent launch of the
+// decode chain costs ~37 us (tools/pipeline_trace.py), whatever its size.
+template <int D, bool PROJ>
 __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* __restrict__ part, int slices, int B, int CoutP,
                                                                    const float* __restrict__ stats, int stats_slices,
                                                                    const float* __restrict__ fold_c, const float* __restrict__ fold_d,
                                                                    float* cache, long long cache_bs, int cap, const GptCtl* ctl, int H,
-                                                                   float* out) {
+                                                                   float* out, const float* __restrict__ wproj, int wpCoutP) {
     extern __shared__ float sc[];            // [keys of this split] scores / probabilities
+    float wreg[PROJ ? D : 1][3];
+    if (PROJ) {
+        const float* wr = wproj + (long long)(blockIdx.x * D) * wpCoutP + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wreg[c][j] = wr[(long long)c * wpCoutP + 256 * j];
+    }
     __shared__ float red[4];
     __shared__ float qkv_s[3][D];
     const int h = blockIdx.x, b = blockIdx.y, ks = blockIdx.z, KS = gridDim.z;
@@ -523,6 +538,28 @@ __global__ __launch_bounds__(256) void decode_attention_qkv_kernel(const float* 
         }
     }
     __syncthreads();
+    if (PROJ) {
+        __shared__ float a_s[D];
+        if (tid < D) {
+            const int c4 = tid >> 2, e = tid & 3;
+            float o = 0.f;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) o += reinterpret_cast<const float*>(&pvs[q][c4])[e];
+            a_s[tid] = o / l;                  // one split: the new key is always there, l > 0
+        }
+        __syncthreads();
+        float* ps = out + ((long long)h * B + b) * wpCoutP + tid;          // per-head partial of the projection [H][B][C]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; c += 4) {
+                a0 += a_s[c] * wreg[c][j]; a1 += a_s[c + 1] * wreg[c + 1][j]; a2 += a_s[c + 2] * wreg[c + 2][j]; a3 += a_s[c + 3] * wreg[c + 3][j];
+            }
+            ps[256 * j] = (a0 + a1) + (a2 + a3);
+        }
+        return;
+    }
     float* rec = out + ((long long)(b * H + h) * KS + ks) * ATT_REC;
     if (tid < D) {
         const int c4 = tid >> 2, e = tid & 3;
@@ -541,12 +578,20 @@ int decode_attention_splits() {
 
 void launch_decode_attention_qkv(const float* part, int slices, int CoutP, const float* stats, int stats_slices, const float* fold_c,
                                  const float* fold_d, float* cache, long long cache_bs, int cache_cs, const GptCtl* ctl, int B, int H, int D,
-                                 float* out, hipStream_t s) {
+                                 float* out, hipStream_t s, const float* wproj, int wpCoutP) {
     DTTS_REQUIRE(D == 48, "decode attention head dim");
+    if (wproj) {             // attention + output projection: one (head, row) workgroup, no key split; out = per-head partials [H][B][wpCoutP]
+        DTTS_REQUIRE(wpCoutP == 3 * 256 && H * D <= wpCoutP, "fused attention projection: 768 output columns");
+        DTTS_REQUIRE(sizeof(float) * (size_t)cache_cs + 5376 + 256 <= 64 * 1024, "decode attention: KV cache too long for the LDS score buffer");
+        hipLaunchKernelGGL((decode_attention_qkv_kernel<48, true>), dim3(H, B, 1), dim3(256), sizeof(float) * cache_cs, s, part, slices, B, CoutP,
+                           stats, stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out, wproj, wpCoutP);
+        DTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     // 64 KiB of LDS per workgroup by default: the dynamic score buffer + 5.1 KiB of static arrays (pvs 4 032 B, qkv_s 576 B, red)
     DTTS_REQUIRE(sizeof(float) * (size_t)cache_cs + 5376 <= 64 * 1024, "decode attention: KV cache too long for the LDS score buffer");
-    hipLaunchKernelGGL(decode_attention_qkv_kernel<48>, dim3(H, B, decode_attention_splits()), dim3(256), sizeof(float) * cache_cs, s, part,
-                       slices, B, CoutP, stats, stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out);
+    hipLaunchKernelGGL((decode_attention_qkv_kernel<48, false>), dim3(H, B, decode_attention_splits()), dim3(256), sizeof(float) * cache_cs, s, part,
+                       slices, B, CoutP, stats, stats_slices, fold_c, fold_d, cache, cache_bs, cache_cs, ctl, H, out, nullptr, 0);
     DTTS_CHECK_HIP(hipGetLastError());
 }
 

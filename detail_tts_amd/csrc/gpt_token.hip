@@ -1,0 +1,736 @@
+// One decode token of the GPT-2 stack as ONE persistent kernel (gpt/model.py:107-185 GPT2InferenceModel.forward with the KV cache;
+// HF GPT2Block: ln_1 -> c_attn -> attention -> c_proj -> + -> ln_2 -> c_fc -> gelu_new -> c_proj -> +; then ln_f, final_norm,
+// mel_head: gpt/model.py:41, 173).
+//
+// Why: the launch-per-GEMV decode step (gpt_kernels.hip) is a chain of 53 dependent launches per token.  Alone that costs ~7.5 us per
+// launch; under the diffusion trunk of the previous request (SynthesizerTrn.infer_stream) every launch has to win CUs back from
+// resident conv workgroups and the chain stretches 4.5 x (tools/pipeline_trace.py: stage A 465 ms per request vs 103 alone), which
+// makes stage A the pipeline's critical stage.  Here the chain never leaves the chip: TG = 128 workgroups stay resident for the whole
+// token and hand activations to each other through memory with a low-latency "value + tag" protocol instead of kernel boundaries.
+//
+// Exchange protocol.  An exchanged activation is one 64-bit word {fp32 value, 32-bit tag}, stored and polled with relaxed agent-scope
+// (sc1) 8-byte atomics: coherent across the 8 XCDs' L2s, and self-validating - a consumer spins on the words it needs until their tag
+// is (epoch, layer); no barrier, no fence, no flag round trip (one store + one successful load per hop).  `epoch` is a device counter
+// the kernel bumps once per launch, so stale words of earlier tokens / sessions never match.  Every word of every buffer is written in
+// every launch (rows >= B as zeros).  A poll gives up after SPIN_LIMIT tries and raises the session's error flag (dtts_gpt_finish
+// fails loudly) instead of hanging the device.
+//
+// Work split (C = 768, H = 16, D = 48, F = 3072, rows <= 8; workgroup w of 128, 256 threads):
+//   P1  X (all rows, 768) -> ln_1 -> c_attn columns [18 w, 18 w + 18)                                       -> QKV
+//   P2  attention of (head w / 8, row w % 8): the cached K rows are in registers BEFORE q arrives, the V rows are loaded while the
+//       softmax runs; appends k / v to the cache                                                              -> AT
+//   P2b AT (all rows, 768) -> c_proj columns [6 w, 6 w + 6) + bias + X                                        -> Y
+//   P3  Y -> ln_2 -> c_fc columns [24 w, 24 w + 24) -> gelu_new -> times rows [24 w, 24 w + 24) of the mlp c_proj: a [8][768] PARTIAL
+//       of the mlp output, scattered to the 128 column owners (6 columns each)                               -> RS
+//   P5  owner: sum of the 128 partials (fixed order) + bias + Y                                               -> X of the next layer
+//   end X -> ln_f -> final_norm -> latents; mel_head columns [66 w, 66 w + 66) in 3 passes                    -> logits (plain stores)
+// = 5 exchanges per layer.  A column GEMV keeps its weight slice in REGISTERS (one float4 = 2 columns x 2 k's; k is split over the
+// workgroup's threads and combined through LDS), loaded from a bind-time repack in exactly the thread order (tok_pack_kernel) and
+// issued one phase AHEAD, before the poll of the phase's input, so the weight stream runs under the exchange latency.  One CU
+// streams ~50-70 GB/s (tools/ubench/stream_rate.hip), so the 128 workgroups together pull what the token needs (~340 MB of weights +
+// the KV rows) at several TB/s.  fp32 FMA throughout; only the order of the sums differs from the launch-per-GEMV path.
+#include <cstdio>
+#include <cstdlib>
+
+#include "gpt_kernels.h"
+
+namespace dtts {
+namespace {
+
+typedef unsigned long long u64;
+constexpr int TG = GPT_TOKEN_WGS, TC = 768, TH = 16, TD = 48, TF = 3072;
+constexpr int KP = 864;                       // rows of the LDS activation tile (>= kl + KL * (KT - 1) of every phase; [768, KP) stay 0)
+constexpr int SPIN_LIMIT = 1 << 18;
+static_assert(TG == 128, "work split");
+
+// column GEMV shapes: PN column pairs per workgroup, KL k-lanes (PN * KL <= 256), KT k's per thread (even; KL * KT >= K)
+constexpr int Q_PN = 9, Q_KL = 28, Q_KT = 28;        // c_attn   768 -> 2304 : 18 columns per workgroup
+constexpr int P_PN = 3, P_KL = 85, P_KT = 10;        // c_proj   768 ->  768 : 6
+constexpr int F_PN = 12, F_KL = 21, F_KT = 38;       // c_fc     768 -> 3072 : 24
+constexpr int H_PN = 11, H_KL = 23, H_KT = 34;       // mel_head 768 -> 8448 : 3 passes of 22
+constexpr int NQ = 2 * Q_PN, NP = 2 * P_PN, NF = 2 * F_PN, NH = 2 * H_PN;
+static_assert(NQ * TG == 3 * TC && NP * TG == TC && NF * TG == TF && 3 * NH * TG == GPT_TOKEN_VS, "column split");
+static_assert(Q_KL * Q_KT >= TC && P_KL * P_KT >= TC && F_KL * F_KT >= TC && H_KL * H_KT >= TC, "k split");
+static_assert(255 / P_PN + P_KL * (P_KT - 1) < KP && 255 / Q_PN + Q_KL * (Q_KT - 1) < KP && 255 / F_PN + F_KL * (F_KT - 1) < KP &&
+                  255 / H_PN + H_KL * (H_KT - 1) < KP, "LDS activation tile");
+
+// exchange arena (u64 words)
+constexpr int X_OFF = 0, QKV_OFF = X_OFF + 8 * TC, AT_OFF = QKV_OFF + 8 * 3 * TC, Y_OFF = AT_OFF + 8 * TC, RS_OFF = Y_OFF + 8 * TC;
+constexpr int RS_PER = 8 * NP;                // words one source sends one owner: 6 columns x 8 rows
+constexpr int XCH_WORDS = RS_OFF + TG * TG * RS_PER;
+static_assert(XCH_WORDS == GPT_TOKEN_XCH_WORDS, "exchange arena size");
+
+struct Smem {
+    float4 xs[2][KP];            // activation tile [row quad][k]: rows 0-3 | rows 4-7 of input k   (P2: the PV partials)
+    float red[6144];             // k-lane partials of a column GEMV | gathered mlp partials | attention scores
+    float qkv[3][TD];
+    float hs[NF][8];             // gelu(c_fc) of this workgroup's 24 columns, [column][row]
+    float own_x[RS_PER], own_y[RS_PER];      // residual rows of the 6 columns this workgroup owns
+    float st1[8][4], st2[8][4];  // LayerNorm: per-row wave partials
+    float part[4][RS_PER];
+    float mred[4], lred[4];
+};
+static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials alias the activation tile");
+
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        if (p.trace && tid == 0 && (w == 0 || w == 37)) p.trace[((w ? 1 : 0) * 16 + l) * 16 + (k)] = wall_clock64(); \
+    } while (0)
+
+// (the base pointer is redefined opaquely at every exchange: loop-invariant code motion would otherwise precompute the 64-bit address of
+// every word of every exchange of the layer loop - several hundred live registers)
+__device__ __forceinline__ u64* pin_x(u64* p) {
+    asm volatile("" : "+v"(p)::"memory");
+    return p;
+}
+__device__ __forceinline__ void ll_store(u64* base, int idx, float v, unsigned tag) {
+    __hip_atomic_store(pin_x(base) + idx, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ll_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct PollState {
+    int* err;
+    bool dead;
+};
+
+// N words base[idx(i)]: all loads in flight at once; while any of them is stale, all are read again
+template <int N, class F>
+__device__ __forceinline__ void ll_poll(const u64* base, F idx, unsigned tag, float (&out)[N], PollState& ps) {
+    u64 v[N];
+    int spins = 0;
+    base = pin_x(const_cast<u64*>(base));
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = ll_load(base + idx(i));
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) bad |= (unsigned)(v[i] >> 32) ^ tag;
+        if (bad == 0 || ps.dead) break;
+        if (++spins > SPIN_LIMIT) {
+            ps.dead = true;
+            *ps.err = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __uint_as_float((unsigned)v[i]);
+}
+
+// sums of 8 values per lane over the wave in 10 shuffles (halving exchange): every lane gets the total of row (lane >> 3) & 7
+__device__ __forceinline__ float wsum8(const float (&s)[8], int lane) {
+    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+    float t[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (h32 ? s[4 + i] : s[i]) + __shfl_xor(h32 ? s[i] : s[4 + i], 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (h16 ? t[2 + i] : t[i]) + __shfl_xor(h16 ? t[i] : t[2 + i], 16);
+    float w = (h8 ? u[1] : u[0]) + __shfl_xor(h8 ? u[0] : u[1], 8);
+    w += __shfl_xor(w, 4);
+    w += __shfl_xor(w, 2);
+    w += __shfl_xor(w, 1);
+    return w;
+}
+
+// LayerNorm of 8 rows of 768 (thread: k = tid + 256 m), two-pass statistics
+__device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ g, const float* __restrict__ be, Smem& sm, int tid) {
+    const int lane = tid & 63, wave = (tid >> 6) & 3;
+    float gg[3], bb[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        gg[m] = g[tid + 256 * m];
+        bb[m] = be[tid + 256 * m];
+    }
+    float s[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) s[b] = (v[b][0] + v[b][1]) + v[b][2];
+    float w = wsum8(s, lane);
+    if ((lane & 7) == 0) sm.st1[(lane >> 3) & 7][wave] = w;
+    __syncthreads();
+    float mean[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const float4 p = *reinterpret_cast<const float4*>(sm.st1[b]);
+        mean[b] = ((p.x + p.y) + (p.z + p.w)) * (1.f / TC);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const float d0 = v[b][0] - mean[b], d1 = v[b][1] - mean[b], d2 = v[b][2] - mean[b];
+        s[b] = (d0 * d0 + d1 * d1) + d2 * d2;
+    }
+    w = wsum8(s, lane);
+    if ((lane & 7) == 0) sm.st2[(lane >> 3) & 7][wave] = w;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const float4 p = *reinterpret_cast<const float4*>(sm.st2[b]);
+        const float rstd = rsqrtf(((p.x + p.y) + (p.z + p.w)) * (1.f / TC) + 1e-5f);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) v[b][m] = (v[b][m] - mean[b]) * rstd * gg[m] + bb[m];
+    }
+}
+
+// rows (thread layout k = tid + 256 m) -> LDS activation tile
+__device__ __forceinline__ void rows_to_tile(const float (&v)[8][3], Smem& sm, int tid) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int k = tid + 256 * m;
+        sm.xs[0][k] = make_float4(v[0][m], v[1][m], v[2][m], v[3][m]);
+        sm.xs[1][k] = make_float4(v[4][m], v[5][m], v[6][m], v[7][m]);
+    }
+}
+
+// The weight / cache prefetches are loads of read-only memory with addresses known at the top of the layer: the compiler would hoist
+// them all to there.  An opaque redefinition of the base pointer pins each prefetch to its place in the schedule.
+template <class T>
+__device__ __forceinline__ const T* pin_v(const T* p) {
+    asm volatile("" : "+v"(p)::"memory");
+    return p;
+}
+
+template <int KT>
+__device__ __forceinline__ void wload(float4 (&wr)[KT / 2], const float4* base, int tid) {
+    base = pin_v(base);
+#pragma unroll
+    for (int i = 0; i < KT / 2; ++i) wr[i] = base[i * 256 + tid];
+}
+
+// column GEMV on the LDS tile with the weight slice in registers (wr[i] = {W[k0][c], W[k0][c + 1], W[k1][c], W[k1][c + 1]},
+// k0 = kl + KL 2 i, k1 = k0 + KL, c = 2 q): returns out[b * NC + col] for o = b * NC + col = tid (< 8 NC)
+template <int PN, int KL, int KT>
+__device__ __forceinline__ float col_gemv(const float4 (&wr)[KT / 2], Smem& sm, int tid) {
+    constexpr int NC = 2 * PN;
+    static_assert(8 * NC <= 256 && KL * 8 * NC <= 6144 && KT % 2 == 0, "col_gemv");
+    const int q = tid % PN, kl = tid / PN;
+    float acc[8][2];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KT / 2; ++i) {
+        const int k0 = kl + KL * 2 * i, k1 = k0 + KL;
+        const float4 xa = sm.xs[0][k0], xb = sm.xs[1][k0], ya = sm.xs[0][k1], yb = sm.xs[1][k1];
+        const float4 w = wr[i];
+        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        const float y[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            acc[b][0] += x[b] * w.x;
+            acc[b][1] += x[b] * w.y;
+            acc[b][0] += y[b] * w.z;
+            acc[b][1] += y[b] * w.w;
+        }
+    }
+    if (kl < KL) {
+        float* r = sm.red + kl * (8 * NC) + q * 2;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) *reinterpret_cast<float2*>(r + b * NC) = make_float2(acc[b][0], acc[b][1]);
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (tid < 8 * NC) {
+        const float* r = sm.red + tid;
+        int i = 0;
+#pragma unroll 4
+        for (; i + 4 <= KL; i += 4) {
+            a0 += r[(i + 0) * (8 * NC)];
+            a1 += r[(i + 1) * (8 * NC)];
+            a2 += r[(i + 2) * (8 * NC)];
+            a3 += r[(i + 3) * (8 * NC)];
+        }
+        for (; i < KL; ++i) a0 += r[i * (8 * NC)];
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+__device__ __forceinline__ float gelu_new(float v) {
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    return 0.5f * v * (1.f + tanhf(u));
+}
+
+__global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams p) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+    const int tid_k = threadIdx.x, w = blockIdx.x;
+    PollState ps{p.err, false};
+    if (*p.err) return;                                   // a timed-out session stays dead (no 0.3 s of spinning per token)
+    const unsigned epoch = *p.epoch;
+    const GptCtl* ctl = p.ctl;
+    const int B = p.B;
+    u64* const XB = p.xch + X_OFF;
+    u64* const QB = p.xch + QKV_OFF;
+    u64* const AB = p.xch + AT_OFF;
+    u64* const YB = p.xch + Y_OFF;
+    u64* const RB = p.xch + RS_OFF;
+
+    for (int k = TC + tid_k; k < KP; k += 256) {
+        sm.xs[0][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sm.xs[1][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // this workgroup's attention work item
+    const int ah = w >> 3, ab = w & 7;
+    const bool arow = ab < B;
+    const int an = arow ? ctl->lp[ab] + ctl->step[ab] : 1;        // keys including the new one
+    const int ncach = an - 1;
+
+    float4 wq[Q_KT / 2];
+    wload<Q_KT>(wq, p.L[0].wq + (size_t)w * (Q_KT / 2) * 256, tid_k);
+    if (tid_k < RS_PER) {                                 // layer 0's input (the sampler's plain rows) enters the same exchange as every other layer's
+        const int b = tid_k / NP, c = NP * w + tid_k % NP;
+        ll_store(XB, b * TC + c, b < B ? p.x_in[b * TC + c] : 0.f, epoch << 4);
+    }
+
+    for (int l = 0; l < p.NL; ++l) {
+        const GptTokenLayer L = p.L[l];                        // uniform address: scalar loads
+        // thread index behind an opaque zero: nothing derived from it is loop-invariant, so the compiler cannot precompute (and keep
+        // live across the layer) the address offsets of every load and store of the body
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        const int tid = tid_k + zero, lane = tid & 63, wave = (tid >> 6) & 3;
+        const unsigned tag = (epoch << 4) | (unsigned)l;
+        // small per-thread constants of the layer, loaded BEFORE the bulk prefetches: vmcnt retires in order, so a bias load issued
+        // behind a weight prefetch would wait for all of it
+        const float c_bq = tid < 8 * NQ ? L.bq[NQ * w + tid % NQ] : 0.f;
+        const float c_bf = tid < 8 * NF ? L.bf[NF * w + tid % NF] : 0.f;
+        const float c_bp = tid < RS_PER ? L.bp[NP * w + tid % NP] : 0.f;
+        const float c_b2 = tid < RS_PER ? L.b2[NP * w + (tid >> 3)] : 0.f;      // (P5's output slot is [column][row])
+        // ------------------------------------------------------------------------------------------------ P1: ln_1 + c_attn
+        float v[8][3];
+        {
+            float f[24];
+            ll_poll<24>(XB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, tag, f, ps);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
+        }
+        STAMP(0);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {                        // the 6 columns this workgroup owns: residual for P2b
+            const int c = tid + 256 * m - NP * w;
+            if (c >= 0 && c < NP)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) sm.own_x[b * NP + c] = v[b][m];
+        }
+        ln8(v, L.g1, L.be1, sm, tid);
+        rows_to_tile(v, sm, tid);
+        __syncthreads();
+        STAMP(10);
+        const float rq = col_gemv<Q_PN, Q_KL, Q_KT>(wq, sm, tid);
+        STAMP(11);
+        if (tid < 8 * NQ) ll_store(QB, (tid / NQ) * (3 * TC) + NQ * w + tid % NQ, rq + c_bq, tag);
+        // prefetch for P2 / P2b: the cached keys of this (head, row), the c_proj slice.  K is channel-major with the keys contiguous:
+        // thread (kq = tid / 4, cgp = tid % 4) holds channels [12 cgp, 12 cgp + 12) of the 4 consecutive keys 4 (kq + 64 u) .. + 3
+        const float* cb = p.kv + (size_t)l * p.kv_layer + (size_t)ab * p.kv_bs;
+        const float* kp = pin_v(cb + (size_t)(ah * TD) * p.cap);
+        const int kq = tid >> 2, cgp = tid & 3;
+        float4 kreg[2][12];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s0 = 4 * (kq + 64 * u);
+            if (arow && s0 < ncach) {
+#pragma unroll
+                for (int c = 0; c < 12; ++c) kreg[u][c] = *reinterpret_cast<const float4*>(kp + ((12 * cgp + c) * p.cap + s0));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 12; ++c) kreg[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float4 wp[P_KT / 2];
+        wload<P_KT>(wp, L.wp + (size_t)w * (P_KT / 2) * 256, tid);
+        STAMP(1);
+        // ------------------------------------------------------------------------------------------------ P2: attention
+        {
+            float f[1];
+            const int e = tid % 144, which = e / TD, c = e - which * TD;
+            ll_poll<1>(QB, [&](int) { return ab * (3 * TC) + which * TC + ah * TD + c; }, tag, f, ps);
+            if (tid < 144) {
+                sm.qkv[which][c] = which == 0 ? f[0] * 0.14433756729740643f : f[0];      // q / sqrt(48)
+                if (arow && which > 0) {                      // KV append at the row's position
+                    float* cbw = p.kv + (size_t)l * p.kv_layer + (size_t)ab * p.kv_bs;
+                    if (which == 1) cbw[(size_t)(ah * TD + c) * p.cap + ncach] = f[0];
+                    else cbw[(size_t)TC * p.cap + (size_t)ncach * TC + ah * TD + c] = f[0];
+                }
+            }
+        }
+        STAMP(2);
+        __syncthreads();
+        float* sc = sm.red;                                   // scores of this row
+        float mx = -INFINITY;
+        if (arow) {
+            float qv[12];
+#pragma unroll
+            for (int c4 = 0; c4 < 3; ++c4) {
+                const float4 qq = *reinterpret_cast<const float4*>(&sm.qkv[0][12 * cgp + 4 * c4]);
+                qv[4 * c4] = qq.x; qv[4 * c4 + 1] = qq.y; qv[4 * c4 + 2] = qq.z; qv[4 * c4 + 3] = qq.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < 12; ++c) {
+                    a.x += qv[c] * kreg[u][c].x;
+                    a.y += qv[c] * kreg[u][c].y;
+                    a.z += qv[c] * kreg[u][c].z;
+                    a.w += qv[c] * kreg[u][c].w;
+                }
+                // the 4 channel groups sit in 4 neighbouring lanes
+                a.x += __shfl_xor(a.x, 1); a.y += __shfl_xor(a.y, 1); a.z += __shfl_xor(a.z, 1); a.w += __shfl_xor(a.w, 1);
+                a.x += __shfl_xor(a.x, 2); a.y += __shfl_xor(a.y, 2); a.z += __shfl_xor(a.z, 2); a.w += __shfl_xor(a.w, 2);
+                const int s0 = 4 * (kq + 64 * u);
+                if (cgp == 0 && s0 < ncach) {                 // keys >= ncach of the last quad: cache slots not written yet
+                    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s0 + e < ncach) {
+                            sc[s0 + e] = av[e];
+                            mx = fmaxf(mx, av[e]);
+                        }
+                }
+            }
+            for (int s = 512 + tid; s < ncach; s += 256) {     // long sessions: keys beyond the register-resident rounds
+                float d = 0.f;
+#pragma unroll 8
+                for (int c = 0; c < TD; ++c) d += sm.qkv[0][c] * kp[(size_t)c * p.cap + s];
+                sc[s] = d;
+                mx = fmaxf(mx, d);
+            }
+            if (wave == 0) {                                  // the key just produced: q . k from LDS
+                float d = lane < TD ? sm.qkv[0][lane] * sm.qkv[1][lane] : 0.f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+                if (lane == 0) sc[ncach] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
+        // V rows: thread (slot = tid / 4, cg = tid % 4) owns 12 channels of the keys s = slot + 64 u; issued now, used after the softmax
+        const int slot = tid >> 2, cg = tid & 3;
+        const float* vp = pin_v(cb + (size_t)TC * p.cap + ah * TD);
+        float4 vr[6][3];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int s = slot + 64 * u;
+            if (arow && s < ncach) {
+                const float4* src = reinterpret_cast<const float4*>(vp + (s * TC + cg * 12));
+                vr[u][0] = src[0];
+                vr[u][1] = src[1];
+                vr[u][2] = src[2];
+            } else {
+                vr[u][0] = vr[u][1] = vr[u][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) sm.mred[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(sm.mred[0], sm.mred[1]), fmaxf(sm.mred[2], sm.mred[3]));
+        float lsum = 0.f;
+        if (arow)
+            for (int s = tid; s < an; s += 256) {
+                const float pr = expf(sc[s] - mx);
+                sc[s] = pr;
+                lsum += pr;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+        if (lane == 0) sm.lred[wave] = lsum;
+        __syncthreads();
+        lsum = (sm.lred[0] + sm.lred[1]) + (sm.lred[2] + sm.lred[3]);
+        {
+            float acc[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) acc[c] = 0.f;
+            if (arow) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int s = slot + 64 * u;
+                    const float pr = s < ncach ? sc[s] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        acc[e * 4 + 0] += pr * vr[u][e].x;
+                        acc[e * 4 + 1] += pr * vr[u][e].y;
+                        acc[e * 4 + 2] += pr * vr[u][e].z;
+                        acc[e * 4 + 3] += pr * vr[u][e].w;
+                    }
+                }
+                for (int s = slot + 384; s < ncach; s += 64) {
+                    const float pr = sc[s];
+                    const float* src = vp + (s * TC + cg * 12);
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) acc[c] += pr * src[c];
+                }
+            }
+            float* pv = reinterpret_cast<float*>(&sm.xs[0][0]) + slot * TD + cg * 12;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) *reinterpret_cast<float4*>(pv + e * 4) = make_float4(acc[e * 4], acc[e * 4 + 1], acc[e * 4 + 2], acc[e * 4 + 3]);
+        }
+        __syncthreads();
+        if (tid < TD) {
+            float o = 0.f;
+            if (arow) {
+                const float* pv = reinterpret_cast<const float*>(&sm.xs[0][0]) + tid;
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 4
+                for (int q = 0; q < 64; q += 4) {
+                    o0 += pv[q * TD];
+                    o1 += pv[(q + 1) * TD];
+                    o2 += pv[(q + 2) * TD];
+                    o3 += pv[(q + 3) * TD];
+                }
+                o = ((o0 + o1) + (o2 + o3) + sc[ncach] * sm.qkv[2][tid]) / lsum;      // + the key just produced
+            }
+            ll_store(AB, ab * TC + ah * TD + tid, o, tag);
+        }
+        STAMP(3);
+        // prefetch for P3: the c_fc slice
+        float4 wf[F_KT / 2];
+        wload<F_KT>(wf, L.wf + (size_t)w * (F_KT / 2) * 256, tid);
+        // ------------------------------------------------------------------------------------------------ P2b: c_proj + residual
+        {
+            float f[24];
+            ll_poll<24>(AB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, tag, f, ps);
+            STAMP(4);
+            __syncthreads();                                   // the PV partials (aliasing the tile) have been consumed
+#pragma unroll
+            for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
+        }
+        rows_to_tile(v, sm, tid);
+        __syncthreads();
+        const float rp = col_gemv<P_PN, P_KL, P_KT>(wp, sm, tid);
+        if (tid < RS_PER) {
+            const float y = rp + c_bp + sm.own_x[tid];
+            sm.own_y[tid] = y;
+            ll_store(YB, (tid / NP) * TC + NP * w + tid % NP, y, tag);
+        }
+        STAMP(5);
+        // ------------------------------------------------------------------------------------------------ P3: ln_2 + c_fc + gelu + mlp c_proj partial
+        {
+            float f[24];
+            ll_poll<24>(YB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, tag, f, ps);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
+        }
+        STAMP(6);
+        ln8(v, L.g2, L.be2, sm, tid);                          // (its first barrier also orders col_gemv's LDS reads before the tile rewrite)
+        rows_to_tile(v, sm, tid);
+        __syncthreads();
+        STAMP(12);
+        const float rf = col_gemv<F_PN, F_KL, F_KT>(wf, sm, tid);
+        STAMP(13);
+        float w2[NF][3];                                        // rows [24 w, 24 w + 24) of the mlp c_proj, columns 3 tid .. 3 tid + 2 (12-byte loads)
+        {
+            typedef float f3 __attribute__((ext_vector_type(3)));
+            const float* src = pin_v(L.w2 + (size_t)(NF * w) * TC) + 3 * tid;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const f3 t = *reinterpret_cast<const f3*>(src + j * TC);
+                w2[j][0] = t.x; w2[j][1] = t.y; w2[j][2] = t.z;
+            }
+        }
+        if (tid < 8 * NF) sm.hs[tid % NF][tid / NF] = gelu_new(rf + c_bf);
+        __syncthreads();
+        STAMP(14);
+        {
+            float acc[8][3];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[b][0] = acc[b][1] = acc[b][2] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float4 ha = *reinterpret_cast<const float4*>(&sm.hs[j][0]), hb = *reinterpret_cast<const float4*>(&sm.hs[j][4]);
+                const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    acc[b][0] += h[b] * w2[j][0];
+                    acc[b][1] += h[b] * w2[j][1];
+                    acc[b][2] += h[b] * w2[j][2];
+                }
+            }
+            STAMP(15);
+            // The partial goes to the owners as [owner][source][column][row] words.  Through LDS first ([column 0..767][row] is exactly
+            // that order for a fixed source), so that a wave's store instruction writes 64 consecutive words: full 64-byte lines
+            // (24 scattered 8-byte stores per thread cost 17 us per layer: every one a partial-line write-through).
+            {
+                float* st = sm.red + 24 * tid;                 // columns 3 tid .. 3 tid + 2, 8 rows each
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    *reinterpret_cast<float4*>(st + 8 * m) = make_float4(acc[0][m], acc[1][m], acc[2][m], acc[3][m]);
+                    *reinterpret_cast<float4*>(st + 8 * m + 4) = make_float4(acc[4][m], acc[5][m], acc[6][m], acc[7][m]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int j = tid + 256 * i, owner = j / RS_PER;
+                ll_store(RB, (owner * TG + w) * RS_PER + (j - owner * RS_PER), sm.red[j], tag);
+            }
+            // prefetch for the next layer's P1 (unconditional: a conditional reload keeps the old slice live across the whole layer)
+            wload<Q_KT>(wq, p.L[l + 1 < p.NL ? l + 1 : l].wq + (size_t)w * (Q_KT / 2) * 256, tid);
+        }
+        STAMP(7);
+        // ------------------------------------------------------------------------------------------------ P5: owner sum -> next X
+        {
+            float f[24];
+            ll_poll<24>(RB + (size_t)w * TG * RS_PER, [&](int i) { return tid + 256 * i; }, tag, f, ps);
+            STAMP(8);
+            __syncthreads();                                   // col_gemv's reads of `red` are done
+#pragma unroll
+            for (int i = 0; i < 24; ++i) sm.red[tid + 256 * i] = f[i];
+        }
+        __syncthreads();
+        if (tid < 4 * RS_PER) {                                // 4 groups of 32 sources, then the 4 group sums: a fixed order
+            const int o = tid % RS_PER, g = tid / RS_PER;
+            const float* r = sm.red + (g * 32) * RS_PER + o;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+            for (int s = 0; s < 32; s += 4) {
+                a0 += r[s * RS_PER];
+                a1 += r[(s + 1) * RS_PER];
+                a2 += r[(s + 2) * RS_PER];
+                a3 += r[(s + 3) * RS_PER];
+            }
+            sm.part[g][o] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (tid < RS_PER) {
+            // slot layout [column][row] -> (row b, column c) = (tid % 8, tid / 8); own_y is [row][column]
+            const int c = tid >> 3, b = tid & 7;
+            const float xn = ((sm.part[0][tid] + sm.part[1][tid]) + (sm.part[2][tid] + sm.part[3][tid])) + c_b2 + sm.own_y[b * NP + c];
+            ll_store(XB, b * TC + NP * w + c, xn, ((epoch << 4) | (unsigned)(l + 1)));
+        }
+        STAMP(9);
+        __syncthreads();                                       // `red` is free again
+    }
+    // ---------------------------------------------------------------------------------------------------- ln_f, final_norm, mel_head
+    {
+        const int tid = tid_k, l = p.NL;
+        float4 wh[H_KT / 2];
+        wload<H_KT>(wh, p.wh + (size_t)(w * 3) * (H_KT / 2) * 256, tid);
+        float v[8][3], f[24];
+        ll_poll<24>(XB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, (epoch << 4) | (unsigned)p.NL, f, ps);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
+        STAMP(0);
+        ln8(v, p.lnf_g, p.lnf_b, sm, tid);
+        ln8(v, p.fin_g, p.fin_b, sm, tid);
+        if (w == 0) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b < B) {
+                    const int step = ctl->step[b];
+                    float* col = (ctl->latents && step < ctl->max_steps) ? ctl->latents + (long long)b * ctl->lat_bs + step : nullptr;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const int c = tid + 256 * m;
+                        p.lat[b * TC + c] = v[b][m];
+                        if (col) col[(long long)c * ctl->lat_cs] = v[b][m];
+                    }
+                }
+        }
+        rows_to_tile(v, sm, tid);
+        __syncthreads();
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const float rh = col_gemv<H_PN, H_KL, H_KT>(wh, sm, tid);
+            if (pass < 2) wload<H_KT>(wh, p.wh + (size_t)(w * 3 + pass + 1) * (H_KT / 2) * 256, tid);
+            if (tid < 8 * NH) {
+                const int b = tid / NH, c = 3 * NH * w + NH * pass + tid % NH;
+                if (b < B) p.logits[(size_t)b * p.Vs + c] = rh + p.bh[c];
+            }
+            __syncthreads();                                   // `red` reads done before the next pass writes it
+        }
+        STAMP(1);
+    }
+    if (w == 0 && tid_k == 0) *p.epoch = epoch + 1;          // every workgroup read it before it produced anything workgroup 0 waited for
+}
+
+// bind-time repack of a K-major weight W[K][CoutP] (N valid columns) into the register order of col_gemv: virtual workgroup v owns
+// columns [2 PN v, 2 PN (v + 1)); out[(v KT/2 + i) 256 + t] = {W[k0][n], W[k0][n + 1], W[k1][n], W[k1][n + 1]},
+// q = t % PN, kl = t / PN, n = 2 PN v + 2 q, k0 = kl + KL 2 i, k1 = k0 + KL; zeros outside
+__global__ void tok_pack_kernel(const float* __restrict__ W, int K, int N, int CoutP, int PN, int KL, int KT2, int NV, float4* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)NV * KT2 * 256) return;
+    const int t = (int)(e & 255), i = (int)((e >> 8) % KT2), v = (int)((e >> 8) / KT2);
+    const int q = t % PN, kl = t / PN;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kl < KL)
+        for (int h = 0; h < 2; ++h) {
+            const int k = kl + KL * (2 * i + h);
+            for (int c = 0; c < 2; ++c) {
+                const int n = 2 * PN * v + 2 * q + c;
+                if (k < K && n < N) r[2 * h + c] = W[(long long)k * CoutP + n];
+            }
+        }
+    out[e] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+void pack(const float* W, int K, int N, int CoutP, int PN, int KL, int KT, int NV, float4* out, hipStream_t s) {
+    const long long n = (long long)NV * (KT / 2) * 256;
+    hipLaunchKernelGGL(tok_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, K, N, CoutP, PN, KL, KT / 2, NV, out);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+bool gpt_token_supported(int C, int H, int F, int NL, int V) { return C == TC && H == TH && F == TF && NL >= 1 && NL <= GPT_TOKEN_MAX_LAYERS && V <= GPT_TOKEN_VS; }
+
+size_t gpt_token_pack_floats(int which) {
+    switch (which) {
+        case 0: return (size_t)TG * (Q_KT / 2) * 256 * 4;
+        case 1: return (size_t)TG * (P_KT / 2) * 256 * 4;
+        case 2: return (size_t)TG * (F_KT / 2) * 256 * 4;
+        default: return (size_t)TG * 3 * (H_KT / 2) * 256 * 4;
+    }
+}
+
+void launch_gpt_token_pack(int which, const float* W, int N, int CoutP, float* out, hipStream_t s) {
+    float4* o = reinterpret_cast<float4*>(out);
+    switch (which) {
+        case 0: pack(W, TC, N, CoutP, Q_PN, Q_KL, Q_KT, TG, o, s); break;
+        case 1: pack(W, TC, N, CoutP, P_PN, P_KL, P_KT, TG, o, s); break;
+        case 2: pack(W, TC, N, CoutP, F_PN, F_KL, F_KT, TG, o, s); break;
+        default: pack(W, TC, N, CoutP, H_PN, H_KL, H_KT, 3 * TG, o, s); break;
+    }
+}
+
+void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
+    DTTS_REQUIRE(p.B >= 1 && p.B <= 8 && p.NL >= 1 && p.NL <= GPT_TOKEN_MAX_LAYERS && p.Vs == GPT_TOKEN_VS, "persistent decode token: shape");
+    DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
+    static bool once = false;
+    if (!once) {
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gpt_token_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        once = true;
+    }
+    // DTTS_GPT_TOKEN_TRACE = n: the n-th launch records wall-clock stamps of workgroups 0 and 37 at every exchange and prints them
+    static const int trace_at = []() { const char* v = getenv("DTTS_GPT_TOKEN_TRACE"); return v ? atoi(v) : 0; }();
+    static int launches = 0;
+    static long long* d_trace = nullptr;
+    GptTokenParams q = p;
+    q.trace = nullptr;
+    const bool tracing = trace_at > 0 && ++launches == trace_at;
+    if (tracing) {
+        if (!d_trace) DTTS_CHECK_HIP(hipMalloc(&d_trace, sizeof(long long) * 2 * 16 * 16));
+        DTTS_CHECK_HIP(hipMemsetAsync(d_trace, 0, sizeof(long long) * 2 * 16 * 16, s));
+        q.trace = d_trace;
+    }
+    hipLaunchKernelGGL(gpt_token_kernel, dim3(TG), dim3(256), sizeof(Smem), s, q);
+    DTTS_CHECK_HIP(hipGetLastError());
+    if (tracing) {
+        long long h[2 * 16 * 16];
+        DTTS_CHECK_HIP(hipMemcpyAsync(h, d_trace, sizeof(h), hipMemcpyDeviceToHost, s));
+        DTTS_CHECK_HIP(hipStreamSynchronize(s));
+        static const char* names[16] = {"X", "QKVst", "qkv", "ATst", "AT", "Yst", "Y", "RSst", "RS", "X'st", "p1tile", "p1gemv", "p3tile", "p3gemv", "gelu", "w2fma"};
+        static const int order[16] = {0, 10, 11, 1, 2, 3, 4, 5, 6, 12, 13, 14, 15, 7, 8, 9};
+        for (int g = 0; g < 2; ++g) {
+            const long long t0 = h[(g * 16) * 16];
+            fprintf(stderr, "[gpt_token trace] workgroup %d, us since its layer-0 X poll (100 MHz clock)\n", g ? 37 : 0);
+            for (int l = 0; l <= p.NL; ++l) {
+                fprintf(stderr, "  l%-2d", l);
+                for (int kk = 0; kk < (l < p.NL ? 16 : 2); ++kk) {
+                    const int k = l < p.NL ? order[kk] : kk;
+                    fprintf(stderr, " %s %.2f |", l < p.NL ? names[k] : (k ? "end" : "X"), (h[(g * 16 + l) * 16 + k] - t0) * 0.01);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+}
+
+}  // namespace dtts

@@ -79,6 +79,11 @@ struct GptSession {
     unsigned char* seen = nullptr;
     int *finished = nullptr, *codes = nullptr, *forced = nullptr;
     GptCtl* ctl = nullptr;
+    // persistent token kernel (gpt_token.hip): exchange arena, logits rows, error flag, launch counter
+    unsigned long long* xch = nullptr;
+    float* logits = nullptr;
+    int* tok_err = nullptr;
+    unsigned* tok_epoch = nullptr;
 };
 
 struct ResBlock1W {
@@ -200,6 +205,7 @@ public:
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
         else if (key == "x3_range_check") opt_range_check_ = value != 0;
+        else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; gpt_drop_graphs(); }
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else throw Error(-1, "unknown option '" + key + "'");
     }
@@ -283,6 +289,12 @@ private:
     const float *text_emb_ = nullptr, *mel_emb_ = nullptr, *text_pos_ = nullptr, *mel_pos_ = nullptr;
 
     Arena gpt_persist_;                   // LayerNorm-algebra vectors (bind time)
+    Arena gpt_tokw_;                      // weights repacked for the persistent token kernel (bind time)
+    std::vector<GptTokenLayer> tok_layers_;   // host copy of the layer table (uploaded at bind time)
+    GptTokenParams tokp_;                 // its launch parameters (weight side filled at bind time, session side at prefill)
+    bool tok_ok_ = false;                 // the model has the shape the token kernel is written for
+    bool opt_gpt_token_ = true;           // option "gpt_token_kernel"
+    bool gpt_use_token_kernel() const;
     Arena gpt_state_;                     // decode session state (fixed addresses: the captured graphs point into it)
     GptSession gs_;
     GptCtl ctl_host_;

@@ -9,6 +9,20 @@
 #include <cstdlib>
 
 namespace dtts {
+// Side streams of the diffusion trunk.  DTTS_B_CU_RESERVE = n (experiment): the stream's queue is masked off the last n CUs of the
+// 256 (the mask's bits interleave over the 8 XCDs), which stay free for the decode chain of the next request.
+static void make_side_stream(hipStream_t* st) {
+    static const int reserve = []() { const char* v = getenv("DTTS_B_CU_RESERVE"); return v ? atoi(v) : 0; }();
+    if (reserve > 0 && reserve < 256) {
+        uint32_t mask[8];
+        for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+        for (int b = 256 - reserve; b < 256; ++b) mask[b >> 5] &= ~(1u << (b & 31));
+        DTTS_CHECK_HIP(hipExtStreamCreateWithCUMask(st, 8, mask));
+        return;
+    }
+    DTTS_CHECK_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+}
+
 
 // ------------------------------------------------------------------------------------------ Arena
 static thread_local Arena* t_arena_override = nullptr;
@@ -591,7 +605,7 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
     while (NS > 1 && ((2 * B) % NS != 0 || (B % ((2 * B) / NS) != 0 && ((2 * B) / NS) % B != 0))) --NS;
     const int n = 2 * B / NS, Bi = B + Nu;
     for (int k = 1; k < NS; ++k)
-        if (!sx_[k - 1]) DTTS_CHECK_HIP(hipStreamCreateWithFlags(&sx_[k - 1], hipStreamNonBlocking));
+        if (!sx_[k - 1]) make_side_stream(&sx_[k - 1]);
     if (NS > 1 && !ev_fork_) {
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         for (auto& e : ev_joinx_) DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -699,7 +713,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     const bool x3 = use_x3();
     static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
     const bool two = env_two && opt_two_streams_;
-    if (two && !sx_[0]) DTTS_CHECK_HIP(hipStreamCreateWithFlags(&sx_[0], hipStreamNonBlocking));
+    if (two && !sx_[0]) make_side_stream(&sx_[0]);
     if (two && !ev_fork_) {
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         for (auto& e : ev_joinx_) DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -7,6 +7,7 @@
 
 #include "gpt_kernels.h"
 #include "model.h"
+#include "prof.h"
 
 namespace dtts {
 
@@ -58,8 +59,54 @@ void Model::build_gpt(hipStream_t s) {
         launch_ln_fold_vectors(w.fc.w, C, w.fc.CoutP, w.ln2_g, w.ln2_b, w.fc.b, cf, df, s);
         w.attn_c = ca; w.attn_d = da; w.fc_c = cf; w.fc_d = df;
     }
+    // the persistent token kernel's register-order weight copies (gpt_token.hip)
+    tok_ok_ = gpt_token_supported(C, cfg.gpt_heads, gpt_layers_.empty() ? 0 : gpt_layers_[0].fc.Cout, (int)gpt_layers_.size(), cfg.gpt_mel_codes);
+    for (auto& w : gpt_layers_) tok_ok_ = tok_ok_ && w.fc2.CoutP == C && w.fc.Cout == 4 * C;
+    if (tok_ok_) {
+        const size_t per_layer = gpt_token_pack_floats(0) + gpt_token_pack_floats(1) + gpt_token_pack_floats(2);
+        gpt_tokw_.ensure(sizeof(float) * (per_layer * gpt_layers_.size() + gpt_token_pack_floats(3) + GPT_TOKEN_VS) + 65536 +
+                         sizeof(GptTokenLayer) * GPT_TOKEN_MAX_LAYERS);
+        gpt_tokw_.reset();
+        tokp_ = GptTokenParams();
+        tokp_.NL = (int)gpt_layers_.size();
+        tok_layers_.assign(gpt_layers_.size(), GptTokenLayer());
+        for (size_t l = 0; l < gpt_layers_.size(); ++l) {
+            const GptLayerW& w = gpt_layers_[l];
+            GptTokenLayer& t = tok_layers_[l];
+            float* q = gpt_tokw_.f32(gpt_token_pack_floats(0));
+            float* pj = gpt_tokw_.f32(gpt_token_pack_floats(1));
+            float* f = gpt_tokw_.f32(gpt_token_pack_floats(2));
+            launch_gpt_token_pack(0, w.attn.w, 3 * C, w.attn.CoutP, q, s);
+            launch_gpt_token_pack(1, w.proj.w, C, w.proj.CoutP, pj, s);
+            launch_gpt_token_pack(2, w.fc.w, 4 * C, w.fc.CoutP, f, s);
+            t.wq = reinterpret_cast<const float4*>(q);
+            t.wp = reinterpret_cast<const float4*>(pj);
+            t.wf = reinterpret_cast<const float4*>(f);
+            t.w2 = w.fc2.w;
+            t.bq = w.attn.b; t.bp = w.proj.b; t.bf = w.fc.b; t.b2 = w.fc2.b;
+            t.g1 = w.ln1_g; t.be1 = w.ln1_b; t.g2 = w.ln2_g; t.be2 = w.ln2_b;
+        }
+        GptTokenLayer* dl = static_cast<GptTokenLayer*>(gpt_tokw_.raw(sizeof(GptTokenLayer) * tok_layers_.size()));
+        DTTS_CHECK_HIP(hipMemcpyAsync(dl, tok_layers_.data(), sizeof(GptTokenLayer) * tok_layers_.size(), hipMemcpyHostToDevice, s));
+        tokp_.L = dl;
+        float* hw = gpt_tokw_.f32(gpt_token_pack_floats(3));
+        float* hb = gpt_tokw_.f32(GPT_TOKEN_VS);
+        launch_gpt_token_pack(3, mel_head_.w, cfg.gpt_mel_codes, mel_head_.CoutP, hw, s);
+        DTTS_CHECK_HIP(hipMemsetAsync(hb, 0, sizeof(float) * GPT_TOKEN_VS, s));
+        DTTS_CHECK_HIP(hipMemcpyAsync(hb, mel_head_.b, sizeof(float) * cfg.gpt_mel_codes, hipMemcpyDeviceToDevice, s));
+        tokp_.wh = reinterpret_cast<const float4*>(hw);
+        tokp_.bh = hb;
+        tokp_.Vs = GPT_TOKEN_VS;
+        tokp_.lnf_g = lnf_g_; tokp_.lnf_b = lnf_b_; tokp_.fin_g = fin_g_; tokp_.fin_b = fin_b_;
+    }
     gpt_drop_graphs();      // captured graphs hold the old weight pointers
     gs_ = GptSession();
+}
+
+// sessions of <= 8 rows decode a token with ONE persistent kernel (DTTS_GPT_TOKEN_KERNEL=0: the launch-per-GEMV chain)
+bool Model::gpt_use_token_kernel() const {
+    static const bool env_on = []() { const char* v = getenv("DTTS_GPT_TOKEN_KERNEL"); return !(v && v[0] == '0'); }();
+    return env_on && opt_gpt_token_ && tok_ok_ && gs_.B <= 8 && gs_.xch != nullptr;
 }
 
 // HF GPT-2 stack (without ln_f) over x [B, C, L] in place; optionally fills the KV cache.
@@ -175,7 +222,8 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     const int cap = round_up(Lp + G, 128);
     const long long kv_bs = (long long)2 * C * cap, kv_layer = kv_bs * B;
     const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * (4 * C + cfg.gpt_heads * 8 * ATT_REC) + (size_t)2 * B * GEMV_PART_FLOATS + 2 * 64 * GEMV_MAXB * 2) +
-                        (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + 64) + sizeof(GptCtl) + 64 * 256;
+                        (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + 64) + sizeof(GptCtl) + 64 * 256 +
+                        (tok_ok_ && B <= 8 ? sizeof(unsigned long long) * GPT_TOKEN_XCH_WORDS + sizeof(float) * 8 * GPT_TOKEN_VS + 1024 : 0);
     if (need > gpt_state_.capacity() || gs_.B != B || gs_.cap != cap || gs_.G != G) {
         gpt_drop_graphs();
         gpt_state_.ensure(need);
@@ -197,6 +245,17 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
         n.codes = gpt_state_.i32((size_t)B * G);
         n.forced = gpt_state_.i32((size_t)B * G);
         n.ctl = static_cast<GptCtl*>(gpt_state_.raw(sizeof(GptCtl)));
+        if (tok_ok_ && B <= 8) {
+            n.xch = static_cast<unsigned long long*>(gpt_state_.raw(sizeof(unsigned long long) * GPT_TOKEN_XCH_WORDS));
+            n.logits = gpt_state_.f32((size_t)8 * GPT_TOKEN_VS);
+            n.tok_err = gpt_state_.i32(2);
+            n.tok_epoch = reinterpret_cast<unsigned*>(n.tok_err + 1);
+            // tags of a previous layout of this arena must not survive: all words 0 (no valid tag is 0), the launch counter restarts at 1
+            DTTS_CHECK_HIP(hipMemsetAsync(n.xch, 0, sizeof(unsigned long long) * GPT_TOKEN_XCH_WORDS, s));
+            const int init[2] = {0, 1};
+            DTTS_CHECK_HIP(hipMemcpyAsync(n.tok_err, init, sizeof(init), hipMemcpyHostToDevice, s));
+            DTTS_CHECK_HIP(hipStreamSynchronize(s));
+        }
         gs_ = n;
     }
     gs_.kv_bs = kv_bs;
@@ -294,6 +353,44 @@ void Model::gpt_head_and_sample(hipStream_t s) {
 // (the step index, positions and sampling state are read from the device control block) -> safe to capture in a hipGraph.
 void Model::gpt_step_launches(hipStream_t s) {
     const int C = cfg.gpt_dim, H = cfg.gpt_heads, D = C / H, B = gs_.B, NL = (int)gpt_layers_.size();
+    if (gpt_use_token_kernel()) {                       // 2 launches per token: the persistent token kernel + the sampler
+        GptTokenParams p = tokp_;
+        p.x_in = gs_.y;
+        p.kv = gs_.kv;
+        p.kv_layer = gs_.kv_layer;
+        p.kv_bs = gs_.kv_bs;
+        p.cap = gs_.cap;
+        p.ctl = gs_.ctl;
+        p.B = B;
+        p.xch = gs_.xch;
+        p.lat = gs_.lat;
+        p.logits = gs_.logits;
+        p.err = gs_.tok_err;
+        p.epoch = gs_.tok_epoch;
+        {
+            ProfScope ps("gpt_token", 0.0, 0.0, s);
+            launch_gpt_token(p, s);
+        }
+        SamplerParams sp;
+        sp.parts = gs_.logits;
+        sp.slices = 1;
+        sp.bias = nullptr;
+        sp.Vs = GPT_TOKEN_VS;
+        sp.V = cfg.gpt_mel_codes;
+        sp.B = B;
+        sp.seen = gs_.seen;
+        sp.finished = gs_.finished;
+        sp.codes = gs_.codes;
+        sp.codes_stride = gs_.G;
+        sp.eos = 8193;
+        sp.ctl = gs_.ctl;
+        sp.mel_emb = mel_emb_;
+        sp.mel_pos = mel_pos_;
+        sp.x_next = gs_.y;
+        sp.C = C;
+        launch_sampler(sp, s);
+        return;
+    }
     const int st_sl = gemv_block_slices(C, gpt_layers_[0].attn.CoutP);      // statistics slices of a K = C RESSUM GEMV
     for (int l = 0; l < NL; ++l) {
         const GptLayerW& w = gpt_layers_[l];
@@ -314,18 +411,25 @@ void Model::gpt_step_launches(hipStream_t s) {
         a.y_out = gs_.x;
         a.stats_out = gs_.st1;
         launch_gemv_block(GP_RESSUM, w.attn.w, C, w.attn.CoutP, a, B, gs_.part, s);
-        launch_decode_attention_qkv(gs_.part, sq, w.attn.CoutP, gs_.st1, st_sl, w.attn_c, w.attn_d, cache, gs_.kv_bs, gs_.cap, gs_.ctl, B, H, D,
-                                    gs_.ab, s);
-        GemvIn p;                                        // K3: attention projection (combines the key splits)
-        p.parts = gs_.ab;
-        p.in_slices = decode_attention_splits();
-        p.in_stride = D;
-        launch_gemv_block(GP_ATTN, w.proj.w, C, w.proj.CoutP, p, B, gs_.part2, s);
+        static const bool fuse_proj = []() { const char* v = getenv("DTTS_GPT_FUSE_PROJ"); return !(v && v[0] == '0'); }();
+        const bool fp = fuse_proj && w.proj.CoutP == 768 && H == 16;
+        if (fp) {                                        // K2 + K3: attention and its output projection, per-head partials in part2
+            launch_decode_attention_qkv(gs_.part, sq, w.attn.CoutP, gs_.st1, st_sl, w.attn_c, w.attn_d, cache, gs_.kv_bs, gs_.cap, gs_.ctl, B, H,
+                                        D, gs_.part2, s, w.proj.w, w.proj.CoutP);
+        } else {
+            launch_decode_attention_qkv(gs_.part, sq, w.attn.CoutP, gs_.st1, st_sl, w.attn_c, w.attn_d, cache, gs_.kv_bs, gs_.cap, gs_.ctl, B, H,
+                                        D, gs_.ab, s);
+            GemvIn p;                                    // K3: attention projection (combines the key splits)
+            p.parts = gs_.ab;
+            p.in_slices = decode_attention_splits();
+            p.in_stride = D;
+            launch_gemv_block(GP_ATTN, w.proj.w, C, w.proj.CoutP, p, B, gs_.part2, s);
+        }
         GemvIn f;                                        // K4: Y = X + proj ; c_fc(gamma2 . Y)
         f.x = gs_.x;
         f.x_stride = C;
         f.parts = gs_.part2;
-        f.in_slices = spj;
+        f.in_slices = fp ? H : spj;
         f.in_stride = w.proj.CoutP;
         f.in_bias = w.proj.b;
         f.gamma = w.ln2_g;
@@ -440,7 +544,14 @@ void Model::gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s) {
     // the DEVICE step counters are the truth: the sampler advances them, also when the steps were replayed from a caller-owned graph
     // (dtts_gpt_decode_step captured once, replayed n times: the host counter gs_.steps saw one call); steps >= G were device no-ops
     DTTS_CHECK_HIP(hipMemcpyAsync(&hctl, gs_.ctl, sizeof(GptCtl), hipMemcpyDeviceToHost, s));
+    int tok_err = 0;
+    if (gs_.tok_err) DTTS_CHECK_HIP(hipMemcpyAsync(&tok_err, gs_.tok_err, sizeof(int), hipMemcpyDeviceToHost, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
+    if (tok_err) {
+        DTTS_CHECK_HIP(hipMemsetAsync(gs_.tok_err, 0, sizeof(int), s));
+        gs_.active = false;
+        DTTS_REQUIRE(false, "persistent decode kernel: an activation exchange timed out (workgroups not co-resident?); set DTTS_GPT_TOKEN_KERNEL=0");
+    }
     for (int b = 0; b < B; ++b) {
         const int done = std::max(0, std::min(hctl.step[b], G));
         int n = done;

@@ -236,6 +236,9 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *   "gpt_graph"   (default 0): 1 = dtts_gpt_decode replays captured hipGraphs (16-step chunks); 0 = the same launches issued
  *                 eagerly, 16 steps per call (measured faster on ROCm 7.2: a replayed kernel node costs ~0.8 us more than an eager
  *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
+ *   "gpt_token_kernel" (default 1): decode sessions of <= 8 rows run a token as ONE persistent kernel (128 resident workgroups that
+ *                 exchange activations through memory, csrc/gpt_token.hip) + the sampler; 0 = the chain of 5 launches per layer
+ *                 (always used by 9..16-row sessions).  Same fp32 arithmetic, different summation order; env DTTS_GPT_TOKEN_KERNEL=0;
  *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
  *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
  *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1;

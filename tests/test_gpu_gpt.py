@@ -108,6 +108,14 @@ def test_sixteen_row_session_with_row_seeds_equals_two_eight_row_sessions(rt):
     rs = np.random.RandomState(61)
     G = 20
     reqs = []
+    rt.set_option("gpt_token_kernel", 0)      # 8-row sessions on the same launch-per-GEMV kernels as the 16-row one: bit-identical
+    try:
+        _sixteen_rows(rt, rs, G, reqs)
+    finally:
+        rt.set_option("gpt_token_kernel", 1)
+
+
+def _sixteen_rows(rt, rs, G, reqs):
     for i, Tr in enumerate((90, 140)):
         refer = (rs.randn(8, 128, Tr) * 2 - 5).astype(np.float32)
         rl = [Tr - 3 * b for b in range(8)]
@@ -123,3 +131,32 @@ def test_sixteen_row_session_with_row_seeds_equals_two_eight_row_sessions(rt):
     for i in range(2):
         assert np.array_equal(codes[8 * i:8 * i + 8], alone[i][0]), i
         assert torch.equal(lat[8 * i:8 * i + 8], alone[i][2]), i
+
+
+def test_token_kernel_equals_the_launch_per_gemv_chain(rt):
+    """The persistent token kernel (one launch per token, 128 workgroups exchanging activations through memory) against the
+    launch-per-GEMV chain on a ragged 8-row session: identical sampled codes, latents equal to fp32 summation-order noise; and a
+    second session on the same handle (exchange words of the first one still in memory, the launch counter keeps counting)."""
+    rs = np.random.RandomState(67)
+    G = 40
+    refer = (rs.randn(8, 128, 120) * 2 - 5).astype(np.float32)
+    rl = [120 - 5 * b for b in range(8)]
+    texts = [np.concatenate([rs.randint(3, 255, 5 + (b % 5)), [0]]).astype(np.int32) for b in range(8)]
+    args = (dev(refer), rl, texts, 77, list(range(20, 28)))
+    rt.set_option("gpt_token_kernel", 0)
+    try:
+        c0, n0, l0 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+    finally:
+        rt.set_option("gpt_token_kernel", 1)
+    for _ in range(2):
+        c1, n1, l1 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+        assert np.array_equal(c0, c1) and np.array_equal(n0, n1)
+        assert float((l0 - l1).abs().max()) < 2e-4
+    # fewer rows than the kernel's 8 (the padding rows are exchanged as zeros), sampling with EOS allowed
+    c2 = rt.gpt_generate(dev(refer[:3]), rl[:3], texts[:3], 5, [1, 2, 3], max_generate_length=12)
+    rt.set_option("gpt_token_kernel", 0)
+    try:
+        c3 = rt.gpt_generate(dev(refer[:3]), rl[:3], texts[:3], 5, [1, 2, 3], max_generate_length=12)
+    finally:
+        rt.set_option("gpt_token_kernel", 1)
+    assert np.array_equal(c2[0], c3[0]) and np.array_equal(c2[1], c3[1])

@@ -19,7 +19,20 @@ def main():
     ap.add_argument("--requests", type=int, default=6)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--codes", type=int, default=234)
+    ap.add_argument("--reserve", type=int, default=0, help="mask the diffusion streams off the last N CUs (left to stage A)")
     args = ap.parse_args()
+    main_stream = None
+    if args.reserve:
+        import ctypes
+        os.environ["DTTS_B_CU_RESERVE"] = str(args.reserve)
+        hip = ctypes.CDLL("libamdhip64.so")
+        mask = (ctypes.c_uint32 * 8)(*([0xffffffff] * 8))
+        for b in range(256 - args.reserve, 256):
+            mask[b >> 5] &= ~(1 << (b & 31))
+        st = ctypes.c_void_p()
+        torch.cuda.init()
+        assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, mask) == 0
+        main_stream = torch.cuda.ExternalStream(st.value)
     from detail_tts_amd.vqvae.model_24k import SynthesizerTrn
     from detail_tts_amd.weights import select_inference_params, synthetic_state_dict
     model = SynthesizerTrn(select_inference_params(synthetic_state_dict(0)), folded=True)
@@ -32,12 +45,15 @@ def main():
     def reqs(k, first):
         return (dict(text=text, text_length=tl, refer=refer, refer_lengths=rl, seed=first + i, sample_ids=list(range(B))) for i in range(k))
 
-    list(model.infer_stream(reqs(2, 0), max_generate_length=n + 1, suppress_eos=True))       # warm-up
     torch.cuda.synchronize()
-    model.stream_trace = []
-    t0 = time.perf_counter()
-    out = list(model.infer_stream(reqs(args.requests, 10), max_generate_length=n + 1, suppress_eos=True))
-    torch.cuda.synchronize()
+    ctx = torch.cuda.stream(main_stream) if main_stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+    with ctx:
+        list(model.infer_stream(reqs(2, 0), max_generate_length=n + 1, suppress_eos=True))       # warm-up
+        torch.cuda.synchronize()
+        model.stream_trace = []
+        t0 = time.perf_counter()
+        out = list(model.infer_stream(reqs(args.requests, 10), max_generate_length=n + 1, suppress_eos=True))
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tr = model.stream_trace
     model.stream_trace = None
