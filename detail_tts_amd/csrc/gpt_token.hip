@@ -8,9 +8,10 @@
 // makes stage A the pipeline's critical stage.  Here the chain never leaves the chip: TG = 128 workgroups stay resident for the whole
 // token and hand activations to each other through memory with a low-latency "value + tag" protocol instead of kernel boundaries.
 //
-// Exchange protocol.  An exchanged activation is one 64-bit word {fp32 value, 32-bit tag}, stored and polled with relaxed agent-scope
-// (sc1) 8-byte atomics: coherent across the 8 XCDs' L2s, and self-validating - a consumer spins on the words it needs until their tag
-// is (epoch, layer); no barrier, no fence, no flag round trip (one store + one successful load per hop).  `epoch` is a device counter
+// Exchange protocol.  Exchanged activations travel as 16-byte words {3 fp32 values (3 consecutive columns of a row), 32-bit tag},
+// written and polled with agent-scope (sc1) 16-byte accesses: coherent across the 8 XCDs' L2s, and self-validating - a consumer spins
+// on the words it needs until their tag is (epoch, layer); no barrier, no fence, no flag round trip (one store + one successful load
+// per hop).  A lane's aligned 16-byte store reaches memory as one piece (the same property RCCL's LL128 protocol rests on).  `epoch` is a device counter
 // the kernel bumps once per launch, so stale words of earlier tokens / sessions never match.  Every word of every buffer is written in
 // every launch (rows >= B as zeros).  A poll gives up after SPIN_LIMIT tries and raises the session's error flag (dtts_gpt_finish
 // fails loudly) instead of hanging the device.
@@ -29,8 +30,11 @@
 // issued one phase AHEAD, before the poll of the phase's input, so the weight stream runs under the exchange latency.  One CU
 // streams ~50-70 GB/s (tools/ubench/stream_rate.hip), so the 128 workgroups together pull what the token needs (~340 MB of weights +
 // the KV rows) at several TB/s.  fp32 FMA throughout; only the order of the sums differs from the launch-per-GEMV path.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "gpt_kernels.h"
 
@@ -54,11 +58,13 @@ static_assert(Q_KL * Q_KT >= TC && P_KL * P_KT >= TC && F_KL * F_KT >= TC && H_K
 static_assert(255 / P_PN + P_KL * (P_KT - 1) < KP && 255 / Q_PN + Q_KL * (Q_KT - 1) < KP && 255 / F_PN + F_KL * (F_KT - 1) < KP &&
                   255 / H_PN + H_KL * (H_KT - 1) < KP, "LDS activation tile");
 
-// exchange arena (u64 words)
-constexpr int X_OFF = 0, QKV_OFF = X_OFF + 8 * TC, AT_OFF = QKV_OFF + 8 * 3 * TC, Y_OFF = AT_OFF + 8 * TC, RS_OFF = Y_OFF + 8 * TC;
-constexpr int RS_PER = 8 * NP;                // words one source sends one owner: 6 columns x 8 rows
-constexpr int XCH_WORDS = RS_OFF + TG * TG * RS_PER;
-static_assert(XCH_WORDS == GPT_TOKEN_XCH_WORDS, "exchange arena size");
+// exchange arena, in 16-byte words ("quads": 3 consecutive columns of one row + tag)
+constexpr int XQ = TC / 3;                     // quads per row of a 768-wide buffer
+constexpr int X_OFF = 0, QKV_OFF = X_OFF + 8 * XQ, AT_OFF = QKV_OFF + 8 * 3 * XQ, Y_OFF = AT_OFF + 8 * XQ, RS_OFF = Y_OFF + 8 * XQ;
+constexpr int RS_PER = 8 * NP;                // values one source sends one owner: 6 columns x 8 rows, [column][row]
+constexpr int RS_Q = RS_PER / 3;              // = 16 quads
+constexpr int XCH_QUADS = RS_OFF + TG * TG * RS_Q;
+static_assert(2 * XCH_QUADS == GPT_TOKEN_XCH_WORDS, "exchange arena size");
 
 struct Smem {
     float4 xs[2][KP];            // activation tile [row quad][k]: rows 0-3 | rows 4-7 of input k   (P2: the PV partials)
@@ -68,6 +74,7 @@ struct Smem {
     float own_x[RS_PER], own_y[RS_PER];      // residual rows of the 6 columns this workgroup owns
     float st1[8][4], st2[8][4];  // LayerNorm: per-row wave partials
     float part[4][RS_PER];
+    float oq[8 * NQ];            // a phase's outputs, regrouped into triples before they are stored
     float mred[4], lred[4];
 };
 static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials alias the activation tile");
@@ -77,34 +84,35 @@ static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials a
         if (p.trace && tid == 0 && (w == 0 || w == 37)) p.trace[((w ? 1 : 0) * 16 + l) * 16 + (k)] = wall_clock64(); \
     } while (0)
 
-// (the base pointer is redefined opaquely at every exchange: loop-invariant code motion would otherwise precompute the 64-bit address of
-// every word of every exchange of the layer loop - several hundred live registers)
-__device__ __forceinline__ u64* pin_x(u64* p) {
-    asm volatile("" : "+v"(p)::"memory");
-    return p;
+// The 16-byte agent-scope accesses are raw buffer loads / stores with the sc1 cache-policy bit: compiler-generated (it tracks their
+// latency and their register hazards - hand-written `global_*_dwordx4 ... sc1` inline asm, which it does not, delivered stale store
+// data here), one descriptor over the whole arena, 32-bit byte offsets.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+constexpr int AUX_SC1 = 16;                    // gfx940+ cache policy: bit 0 = sc0, bit 1 = nt, bit 4 = sc1
+struct Xch {
+    __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ void q_store(const Xch& x, int q, float a, float b, float c, unsigned tag) {
+    const u4v v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(v, x.rs, q * 16, 0, AUX_SC1);
 }
-__device__ __forceinline__ void ll_store(u64* base, int idx, float v, unsigned tag) {
-    __hip_atomic_store(pin_x(base) + idx, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 ll_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct PollState {
     int* err;
     bool dead;
 };
 
-// N words base[idx(i)]: all loads in flight at once; while any of them is stale, all are read again
-template <int N, class F>
-__device__ __forceinline__ void ll_poll(const u64* base, F idx, unsigned tag, float (&out)[N], PollState& ps) {
-    u64 v[N];
+// 8 quads idx(i): all loads in flight at once; while any of them is stale, all are read again
+template <class F>
+__device__ __forceinline__ void q_poll8(const Xch& x, F idx, unsigned tag, float (&out)[8][3], PollState& ps) {
+    u4v v[8];
     int spins = 0;
-    base = pin_x(const_cast<u64*>(base));
     for (;;) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = ll_load(base + idx(i));
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(x.rs, idx(i) * 16, 0, AUX_SC1);
         unsigned bad = 0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) bad |= (unsigned)(v[i] >> 32) ^ tag;
+        for (int i = 0; i < 8; ++i) bad |= v[i].w ^ tag;
         if (bad == 0 || ps.dead) break;
         if (++spins > SPIN_LIMIT) {
             ps.dead = true;
@@ -114,7 +122,28 @@ __device__ __forceinline__ void ll_poll(const u64* base, F idx, unsigned tag, fl
         __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = __uint_as_float((unsigned)v[i]);
+    for (int i = 0; i < 8; ++i) {
+        out[i][0] = __uint_as_float(v[i].x);
+        out[i][1] = __uint_as_float(v[i].y);
+        out[i][2] = __uint_as_float(v[i].z);
+    }
+}
+__device__ __forceinline__ void q_poll1(const Xch& x, int q, unsigned tag, float (&out)[3], PollState& ps) {
+    u4v v;
+    int spins = 0;
+    for (;;) {
+        v = __builtin_amdgcn_raw_buffer_load_b128(x.rs, q * 16, 0, AUX_SC1);
+        if (v.w == tag || ps.dead) break;
+        if (++spins > SPIN_LIMIT) {
+            ps.dead = true;
+            *ps.err = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    out[0] = __uint_as_float(v.x);
+    out[1] = __uint_as_float(v.y);
+    out[2] = __uint_as_float(v.z);
 }
 
 // sums of 8 values per lane over the wave in 10 shuffles (halving exchange): every lane gets the total of row (lane >> 3) & 7
@@ -132,14 +161,14 @@ __device__ __forceinline__ float wsum8(const float (&s)[8], int lane) {
     return w;
 }
 
-// LayerNorm of 8 rows of 768 (thread: k = tid + 256 m), two-pass statistics
+// LayerNorm of 8 rows of 768 (thread: columns 3 tid .. 3 tid + 2), two-pass statistics
 __device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ g, const float* __restrict__ be, Smem& sm, int tid) {
     const int lane = tid & 63, wave = (tid >> 6) & 3;
     float gg[3], bb[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        gg[m] = g[tid + 256 * m];
-        bb[m] = be[tid + 256 * m];
+        gg[m] = g[3 * tid + m];
+        bb[m] = be[3 * tid + m];
     }
     float s[8];
 #pragma unroll
@@ -170,11 +199,11 @@ __device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ 
     }
 }
 
-// rows (thread layout k = tid + 256 m) -> LDS activation tile
+// rows (thread: columns k = 3 tid + m) -> LDS activation tile
 __device__ __forceinline__ void rows_to_tile(const float (&v)[8][3], Smem& sm, int tid) {
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const int k = tid + 256 * m;
+        const int k = 3 * tid + m;
         sm.xs[0][k] = make_float4(v[0][m], v[1][m], v[2][m], v[3][m]);
         sm.xs[1][k] = make_float4(v[4][m], v[5][m], v[6][m], v[7][m]);
     }
@@ -247,8 +276,8 @@ __device__ __forceinline__ float gelu_new(float v) {
     return 0.5f * v * (1.f + tanhf(u));
 }
 
-__global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams p) {
-    __builtin_amdgcn_s_setprio(3);
+__global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) {
+    __builtin_amdgcn_s_setprio(3);                        // under the diffusion trunk: this latency chain's waves issue ahead of the resident conv waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
     const int tid_k = threadIdx.x, w = blockIdx.x;
@@ -257,11 +286,8 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
     const unsigned epoch = *p.epoch;
     const GptCtl* ctl = p.ctl;
     const int B = p.B;
-    u64* const XB = p.xch + X_OFF;
-    u64* const QB = p.xch + QKV_OFF;
-    u64* const AB = p.xch + AT_OFF;
-    u64* const YB = p.xch + Y_OFF;
-    u64* const RB = p.xch + RS_OFF;
+    const Xch xc{__builtin_amdgcn_make_buffer_rsrc(p.xch, (short)0, XCH_QUADS * 16, 0x00020000)};
+    constexpr int XB = X_OFF, QB = QKV_OFF, AB = AT_OFF, YB = Y_OFF, RB = RS_OFF;      // quad offsets of the buffers in the arena
 
     for (int k = TC + tid_k; k < KP; k += 256) {
         sm.xs[0][k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -275,9 +301,10 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
 
     float4 wq[Q_KT / 2];
     wload<Q_KT>(wq, p.L[0].wq + (size_t)w * (Q_KT / 2) * 256, tid_k);
-    if (tid_k < RS_PER) {                                 // layer 0's input (the sampler's plain rows) enters the same exchange as every other layer's
-        const int b = tid_k / NP, c = NP * w + tid_k % NP;
-        ll_store(XB, b * TC + c, b < B ? p.x_in[b * TC + c] : 0.f, epoch << 4);
+    if (tid_k < 16) {                                     // layer 0's input (the sampler's plain rows) enters the same exchange as every other layer's
+        const int b = tid_k >> 1, h = tid_k & 1;
+        const float* x = p.x_in + b * TC + NP * w + 3 * h;
+        q_store(xc, XB + b * XQ + 2 * w + h, b < B ? x[0] : 0.f, b < B ? x[1] : 0.f, b < B ? x[2] : 0.f, epoch << 4);
     }
 
     for (int l = 0; l < p.NL; ++l) {
@@ -293,22 +320,18 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
         const float c_bq = tid < 8 * NQ ? L.bq[NQ * w + tid % NQ] : 0.f;
         const float c_bf = tid < 8 * NF ? L.bf[NF * w + tid % NF] : 0.f;
         const float c_bp = tid < RS_PER ? L.bp[NP * w + tid % NP] : 0.f;
-        const float c_b2 = tid < RS_PER ? L.b2[NP * w + (tid >> 3)] : 0.f;      // (P5's output slot is [column][row])
+        float c_b2[3];                                         // P5's output triples: thread (row tid / 2, columns 3 (tid % 2) .. + 2)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c_b2[j] = tid < 16 ? L.b2[NP * w + 3 * (tid & 1) + j] : 0.f;
         // ------------------------------------------------------------------------------------------------ P1: ln_1 + c_attn
         float v[8][3];
-        {
-            float f[24];
-            ll_poll<24>(XB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, tag, f, ps);
-#pragma unroll
-            for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
-        }
+        q_poll8(xc, [&](int b) { return XB + b * XQ + tid; }, tag, v, ps);
         STAMP(0);
+        if ((tid >> 1) == w) {                               // the 6 columns this workgroup owns: residual for P2b
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {                        // the 6 columns this workgroup owns: residual for P2b
-            const int c = tid + 256 * m - NP * w;
-            if (c >= 0 && c < NP)
+            for (int b = 0; b < 8; ++b)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) sm.own_x[b * NP + c] = v[b][m];
+                for (int j = 0; j < 3; ++j) sm.own_x[b * NP + 3 * (tid & 1) + j] = v[b][j];
         }
         ln8(v, L.g1, L.be1, sm, tid);
         rows_to_tile(v, sm, tid);
@@ -316,7 +339,13 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
         STAMP(10);
         const float rq = col_gemv<Q_PN, Q_KL, Q_KT>(wq, sm, tid);
         STAMP(11);
-        if (tid < 8 * NQ) ll_store(QB, (tid / NQ) * (3 * TC) + NQ * w + tid % NQ, rq + c_bq, tag);
+        if (tid < 8 * NQ) sm.oq[tid] = rq + c_bq;
+        __syncthreads();
+        if (tid < 8 * NQ / 3) {                               // 6 triples per row
+            const int b = tid / (NQ / 3), t3 = tid - b * (NQ / 3);
+            const float* o = sm.oq + b * NQ + 3 * t3;
+            q_store(xc, QB + b * (3 * XQ) + (NQ / 3) * w + t3, o[0], o[1], o[2], tag);
+        }
         // prefetch for P2 / P2b: the cached keys of this (head, row), the c_proj slice.  K is channel-major with the keys contiguous:
         // thread (kq = tid / 4, cgp = tid % 4) holds channels [12 cgp, 12 cgp + 12) of the 4 consecutive keys 4 (kq + 64 u) .. + 3
         const float* cb = p.kv + (size_t)l * p.kv_layer + (size_t)ab * p.kv_bs;
@@ -334,20 +363,20 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
                 for (int c = 0; c < 12; ++c) kreg[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        float4 wp[P_KT / 2];
-        wload<P_KT>(wp, L.wp + (size_t)w * (P_KT / 2) * 256, tid);
         STAMP(1);
         // ------------------------------------------------------------------------------------------------ P2: attention
-        {
-            float f[1];
-            const int e = tid % 144, which = e / TD, c = e - which * TD;
-            ll_poll<1>(QB, [&](int) { return ab * (3 * TC) + which * TC + ah * TD + c; }, tag, f, ps);
-            if (tid < 144) {
-                sm.qkv[which][c] = which == 0 ? f[0] * 0.14433756729740643f : f[0];      // q / sqrt(48)
+        if (tid < 3 * TD / 3) {                               // q, k, v of this (row, head): 16 triples each
+            const int which = tid >> 4, i = tid & 15;
+            float f[3];
+            q_poll1(xc, QB + ab * (3 * XQ) + which * XQ + ah * (TD / 3) + i, tag, f, ps);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c = 3 * i + j;
+                sm.qkv[which][c] = which == 0 ? f[j] * 0.14433756729740643f : f[j];      // q / sqrt(48)
                 if (arow && which > 0) {                      // KV append at the row's position
                     float* cbw = p.kv + (size_t)l * p.kv_layer + (size_t)ab * p.kv_bs;
-                    if (which == 1) cbw[(size_t)(ah * TD + c) * p.cap + ncach] = f[0];
-                    else cbw[(size_t)TC * p.cap + (size_t)ncach * TC + ah * TD + c] = f[0];
+                    if (which == 1) cbw[(size_t)(ah * TD + c) * p.cap + ncach] = f[j];
+                    else cbw[(size_t)TC * p.cap + (size_t)ncach * TC + ah * TD + c] = f[j];
                 }
             }
         }
@@ -477,37 +506,32 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
                 }
                 o = ((o0 + o1) + (o2 + o3) + sc[ncach] * sm.qkv[2][tid]) / lsum;      // + the key just produced
             }
-            ll_store(AB, ab * TC + ah * TD + tid, o, tag);
+            sm.oq[tid] = o;
         }
+        __syncthreads();
+        if (tid < TD / 3) q_store(xc, AB + ab * XQ + ah * (TD / 3) + tid, sm.oq[3 * tid], sm.oq[3 * tid + 1], sm.oq[3 * tid + 2], tag);
         STAMP(3);
-        // prefetch for P3: the c_fc slice
+        // prefetch for P2b / P3: the c_proj and c_fc slices
+        float4 wp[P_KT / 2];
+        wload<P_KT>(wp, L.wp + (size_t)w * (P_KT / 2) * 256, tid);
         float4 wf[F_KT / 2];
         wload<F_KT>(wf, L.wf + (size_t)w * (F_KT / 2) * 256, tid);
         // ------------------------------------------------------------------------------------------------ P2b: c_proj + residual
-        {
-            float f[24];
-            ll_poll<24>(AB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, tag, f, ps);
-            STAMP(4);
-            __syncthreads();                                   // the PV partials (aliasing the tile) have been consumed
-#pragma unroll
-            for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
-        }
+        q_poll8(xc, [&](int b) { return AB + b * XQ + tid; }, tag, v, ps);
+        STAMP(4);
+        __syncthreads();                                       // the PV partials (aliasing the tile) have been consumed
         rows_to_tile(v, sm, tid);
         __syncthreads();
         const float rp = col_gemv<P_PN, P_KL, P_KT>(wp, sm, tid);
-        if (tid < RS_PER) {
-            const float y = rp + c_bp + sm.own_x[tid];
-            sm.own_y[tid] = y;
-            ll_store(YB, (tid / NP) * TC + NP * w + tid % NP, y, tag);
+        if (tid < RS_PER) sm.own_y[tid] = rp + c_bp + sm.own_x[tid];
+        __syncthreads();
+        if (tid < 16) {
+            const float* y = sm.own_y + (tid >> 1) * NP + 3 * (tid & 1);
+            q_store(xc, YB + (tid >> 1) * XQ + 2 * w + (tid & 1), y[0], y[1], y[2], tag);
         }
         STAMP(5);
         // ------------------------------------------------------------------------------------------------ P3: ln_2 + c_fc + gelu + mlp c_proj partial
-        {
-            float f[24];
-            ll_poll<24>(YB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, tag, f, ps);
-#pragma unroll
-            for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
-        }
+        q_poll8(xc, [&](int b) { return YB + b * XQ + tid; }, tag, v, ps);
         STAMP(6);
         ln8(v, L.g2, L.be2, sm, tid);                          // (its first barrier also orders col_gemv's LDS reads before the tile rewrite)
         rows_to_tile(v, sm, tid);
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
             }
             STAMP(15);
             // The partial goes to the owners as [owner][source][column][row] words.  Through LDS first ([column 0..767][row] is exactly
-            // that order for a fixed source), so that a wave's store instruction writes 64 consecutive words: full 64-byte lines
+            // that order for a fixed source), so that a wave's store instruction writes 64 consecutive 16-byte words: full 64-byte lines
             // (24 scattered 8-byte stores per thread cost 17 us per layer: every one a partial-line write-through).
             {
                 float* st = sm.red + 24 * tid;                 // columns 3 tid .. 3 tid + 2, 8 rows each
@@ -557,9 +581,10 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                const int j = tid + 256 * i, owner = j / RS_PER;
-                ll_store(RB, (owner * TG + w) * RS_PER + (j - owner * RS_PER), sm.red[j], tag);
+            for (int i = 0; i < 8; ++i) {
+                const int j = tid + 256 * i, owner = j / RS_Q;
+                const float* r = sm.red + 3 * j;
+                q_store(xc, RB + (owner * TG + w) * RS_Q + (j - owner * RS_Q), r[0], r[1], r[2], tag);
             }
             // prefetch for the next layer's P1 (unconditional: a conditional reload keeps the old slice live across the whole layer)
             wload<Q_KT>(wq, p.L[l + 1 < p.NL ? l + 1 : l].wq + (size_t)w * (Q_KT / 2) * 256, tid);
@@ -567,12 +592,14 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
         STAMP(7);
         // ------------------------------------------------------------------------------------------------ P5: owner sum -> next X
         {
-            float f[24];
-            ll_poll<24>(RB + (size_t)w * TG * RS_PER, [&](int i) { return tid + 256 * i; }, tag, f, ps);
+            float f[8][3];
+            q_poll8(xc, [&](int i) { return RB + w * TG * RS_Q + tid + 256 * i; }, tag, f, ps);
             STAMP(8);
-            __syncthreads();                                   // col_gemv's reads of `red` are done
+            __syncthreads();                                   // the transposed partials in `red` have been stored
 #pragma unroll
-            for (int i = 0; i < 24; ++i) sm.red[tid + 256 * i] = f[i];
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) sm.red[3 * (tid + 256 * i) + j] = f[i][j];
         }
         __syncthreads();
         if (tid < 4 * RS_PER) {                                // 4 groups of 32 sources, then the 4 group sums: a fixed order
@@ -589,11 +616,15 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
             sm.part[g][o] = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
-        if (tid < RS_PER) {
-            // slot layout [column][row] -> (row b, column c) = (tid % 8, tid / 8); own_y is [row][column]
-            const int c = tid >> 3, b = tid & 7;
-            const float xn = ((sm.part[0][tid] + sm.part[1][tid]) + (sm.part[2][tid] + sm.part[3][tid])) + c_b2 + sm.own_y[b * NP + c];
-            ll_store(XB, b * TC + NP * w + c, xn, ((epoch << 4) | (unsigned)(l + 1)));
+        if (tid < 16) {                                        // slot layout [column][row]; own_y is [row][column]
+            const int b = tid >> 1, h = tid & 1;
+            float xn[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c = 3 * h + j, o = c * 8 + b;
+                xn[j] = ((sm.part[0][o] + sm.part[1][o]) + (sm.part[2][o] + sm.part[3][o])) + c_b2[j] + sm.own_y[b * NP + c];
+            }
+            q_store(xc, XB + b * XQ + 2 * w + h, xn[0], xn[1], xn[2], ((epoch << 4) | (unsigned)(l + 1)));
         }
         STAMP(9);
         __syncthreads();                                       // `red` is free again
@@ -603,10 +634,8 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
         const int tid = tid_k, l = p.NL;
         float4 wh[H_KT / 2];
         wload<H_KT>(wh, p.wh + (size_t)(w * 3) * (H_KT / 2) * 256, tid);
-        float v[8][3], f[24];
-        ll_poll<24>(XB, [&](int i) { return (i / 3) * TC + tid + 256 * (i % 3); }, (epoch << 4) | (unsigned)p.NL, f, ps);
-#pragma unroll
-        for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = f[i];
+        float v[8][3];
+        q_poll8(xc, [&](int b) { return XB + b * XQ + tid; }, (epoch << 4) | (unsigned)p.NL, v, ps);
         STAMP(0);
         ln8(v, p.lnf_g, p.lnf_b, sm, tid);
         ln8(v, p.fin_g, p.fin_b, sm, tid);
@@ -618,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void gpt_token_kernel(const GptTokenParams 
                     float* col = (ctl->latents && step < ctl->max_steps) ? ctl->latents + (long long)b * ctl->lat_bs + step : nullptr;
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
-                        const int c = tid + 256 * m;
+                        const int c = 3 * tid + m;
                         p.lat[b * TC + c] = v[b][m];
                         if (col) col[(long long)c * ctl->lat_cs] = v[b][m];
                     }
@@ -704,6 +733,7 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
     static long long* d_trace = nullptr;
     GptTokenParams q = p;
     q.trace = nullptr;
+    if (const char* v = getenv("DTTS_GPT_TOKEN_NL")) q.NL = atoi(v);      // debug: fewer layers
     const bool tracing = trace_at > 0 && ++launches == trace_at;
     if (tracing) {
         if (!d_trace) DTTS_CHECK_HIP(hipMalloc(&d_trace, sizeof(long long) * 2 * 16 * 16));
@@ -716,6 +746,33 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
         long long h[2 * 16 * 16];
         DTTS_CHECK_HIP(hipMemcpyAsync(h, d_trace, sizeof(h), hipMemcpyDeviceToHost, s));
         DTTS_CHECK_HIP(hipStreamSynchronize(s));
+        if (getenv("DTTS_GPT_TOKEN_DUMP")) {                 // per-row checksums of the last layer's exchange buffers
+            std::vector<float> hx((size_t)RS_OFF * 4);
+            DTTS_CHECK_HIP(hipMemcpy(hx.data(), p.xch, hx.size() * 4, hipMemcpyDeviceToHost));
+            const int offs[4] = {X_OFF, QKV_OFF, AT_OFF, Y_OFF}, nq[4] = {XQ, 3 * XQ, XQ, XQ};
+            const char* bn[4] = {"X", "QKV", "AT", "Y"};
+            for (int k = 0; k < 4; ++k)
+                for (int b = 0; b < 8; ++b) {
+                    double sum = 0, asum = 0;
+                    for (int q = 0; q < nq[k]; ++q)
+                        for (int j = 0; j < 3; ++j) { const float v = hx[((size_t)offs[k] + (size_t)b * nq[k] + q) * 4 + j]; sum += v; asum += std::fabs(v); }
+                    unsigned tg; memcpy(&tg, &hx[((size_t)offs[k] + (size_t)b * nq[k]) * 4 + 3], 4);
+                    fprintf(stderr, "[dump] %-3s row %d sum %.6f abs %.6f tag %x\n", bn[k], b, sum, asum, tg);
+                }
+        }
+        if (getenv("DTTS_GPT_TOKEN_DUMP")) {
+            std::vector<float> hx((size_t)8 * XQ * 4);
+            DTTS_CHECK_HIP(hipMemcpy(hx.data(), p.xch, hx.size() * 4, hipMemcpyDeviceToHost));
+            for (int b : {2, 4}) {
+                fprintf(stderr, "[dump] X row %d vs row 0, differing columns:", b);
+                int n = 0;
+                for (int c = 0; c < TC && n < 40; ++c) {
+                    const float v0 = hx[((size_t)(c / 3)) * 4 + c % 3], vb = hx[((size_t)b * XQ + c / 3) * 4 + c % 3];
+                    if (v0 != vb) { fprintf(stderr, " %d(%.3f/%.3f)", c, v0, vb); ++n; }
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         static const char* names[16] = {"X", "QKVst", "qkv", "ATst", "AT", "Yst", "Y", "RSst", "RS", "X'st", "p1tile", "p1gemv", "p3tile", "p3gemv", "gelu", "w2fma"};
         static const int order[16] = {0, 10, 11, 1, 2, 3, 4, 5, 6, 12, 13, 14, 15, 7, 8, 9};
         for (int g = 0; g < 2; ++g) {

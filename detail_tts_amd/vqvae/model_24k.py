@@ -407,6 +407,10 @@ class SynthesizerTrn:
                     fut.result()
                 except Exception:
                     pass
+            # ... and so must the abandoned request's vocoder (its own stream and scratch arena): a plain infer() right after would
+            # otherwise run its stage C on the same arena under it
+            if pending is not None:
+                pending[2].synchronize()
 
     def infer_gpt(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
                   forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False):
