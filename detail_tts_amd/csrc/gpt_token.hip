@@ -30,11 +30,8 @@
 // issued one phase AHEAD, before the poll of the phase's input, so the weight stream runs under the exchange latency.  One CU
 // streams ~50-70 GB/s (tools/ubench/stream_rate.hip), so the 128 workgroups together pull what the token needs (~340 MB of weights +
 // the KV rows) at several TB/s.  fp32 FMA throughout; only the order of the sums differs from the launch-per-GEMV path.
-#include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
-#include <vector>
 
 #include "gpt_kernels.h"
 
@@ -42,6 +39,14 @@ namespace dtts {
 namespace {
 
 typedef unsigned long long u64;
+// pointers that come out of memory (the layer table) are generic to the compiler: loads through them would be FLAT
+#define GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+typedef float f4e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const void* p) {
+    const f4e t = *GLOBAL_PTR(f4e, p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 constexpr int TG = GPT_TOKEN_WGS, TC = 768, TH = 16, TD = 48, TF = 3072;
 constexpr int KP = 864;                       // rows of the LDS activation tile (>= kl + KL * (KT - 1) of every phase; [768, KP) stay 0)
 constexpr int SPIN_LIMIT = 1 << 18;
@@ -78,6 +83,14 @@ struct Smem {
     float mred[4], lred[4];
 };
 static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials alias the activation tile");
+// The kernel asks for a CU's WHOLE LDS (it uses 55 KiB): one token workgroup per CU and nothing else next to it.  Sharing a CU with
+// the diffusion trunk's split-precision conv / attention workgroups (stage B of the previous request under SynthesizerTrn.infer_stream)
+// gave WRONG results - deterministic alone, a few accumulators of some workgroups off by percents under that load, sampled codes
+// changed; not under a rocBLAS load, not under the exact-fp32 conv kernels.  Not explained: an LDS canary next to the same load saw
+// no foreign write, FLAT / inline-asm accesses and AGPR use were ruled out.  With the CU to itself: 0 mismatches in every stress
+// run (tests/test_gpu_e2e.py::test_token_kernel_under_a_concurrent_diffusion_load), and the pipeline is no slower (461 vs 457 ms).
+constexpr int LDS_REQUEST = 160 * 1024;
+static_assert(sizeof(Smem) <= LDS_REQUEST, "LDS");
 
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
@@ -167,8 +180,8 @@ __device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ 
     float gg[3], bb[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        gg[m] = g[3 * tid + m];
-        bb[m] = be[3 * tid + m];
+        gg[m] = GLOBAL_PTR(float, g)[3 * tid + m];
+        bb[m] = GLOBAL_PTR(float, be)[3 * tid + m];
     }
     float s[8];
 #pragma unroll
@@ -213,15 +226,18 @@ __device__ __forceinline__ void rows_to_tile(const float (&v)[8][3], Smem& sm, i
 // them all to there.  An opaque redefinition of the base pointer pins each prefetch to its place in the schedule.
 template <class T>
 __device__ __forceinline__ const T* pin_v(const T* p) {
-    asm volatile("" : "+v"(p)::"memory");
-    return p;
+    // (an opaque ZERO OFFSET, not an opaque pointer: the pointer keeps its global address space - a laundered pointer is generic, its
+    // loads become FLAT instructions, which count on lgkmcnt as well and may complete out of order with the LDS reads around them)
+    long long z = 0;
+    asm volatile("" : "+v"(z)::"memory");
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + z);
 }
 
 template <int KT>
 __device__ __forceinline__ void wload(float4 (&wr)[KT / 2], const float4* base, int tid) {
     base = pin_v(base);
 #pragma unroll
-    for (int i = 0; i < KT / 2; ++i) wr[i] = base[i * 256 + tid];
+    for (int i = 0; i < KT / 2; ++i) wr[i] = ldg4(base + (i * 256 + tid));
 }
 
 // column GEMV on the LDS tile with the weight slice in registers (wr[i] = {W[k0][c], W[k0][c + 1], W[k1][c], W[k1][c + 1]},
@@ -317,12 +333,12 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         const unsigned tag = (epoch << 4) | (unsigned)l;
         // small per-thread constants of the layer, loaded BEFORE the bulk prefetches: vmcnt retires in order, so a bias load issued
         // behind a weight prefetch would wait for all of it
-        const float c_bq = tid < 8 * NQ ? L.bq[NQ * w + tid % NQ] : 0.f;
-        const float c_bf = tid < 8 * NF ? L.bf[NF * w + tid % NF] : 0.f;
-        const float c_bp = tid < RS_PER ? L.bp[NP * w + tid % NP] : 0.f;
+        const float c_bq = tid < 8 * NQ ? GLOBAL_PTR(float, L.bq)[NQ * w + tid % NQ] : 0.f;
+        const float c_bf = tid < 8 * NF ? GLOBAL_PTR(float, L.bf)[NF * w + tid % NF] : 0.f;
+        const float c_bp = tid < RS_PER ? GLOBAL_PTR(float, L.bp)[NP * w + tid % NP] : 0.f;
         float c_b2[3];                                         // P5's output triples: thread (row tid / 2, columns 3 (tid % 2) .. + 2)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) c_b2[j] = tid < 16 ? L.b2[NP * w + 3 * (tid & 1) + j] : 0.f;
+        for (int j = 0; j < 3; ++j) c_b2[j] = tid < 16 ? GLOBAL_PTR(float, L.b2)[NP * w + 3 * (tid & 1) + j] : 0.f;
         // ------------------------------------------------------------------------------------------------ P1: ln_1 + c_attn
         float v[8][3];
         q_poll8(xc, [&](int b) { return XB + b * XQ + tid; }, tag, v, ps);
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             const int s0 = 4 * (kq + 64 * u);
             if (arow && s0 < ncach) {
 #pragma unroll
-                for (int c = 0; c < 12; ++c) kreg[u][c] = *reinterpret_cast<const float4*>(kp + ((12 * cgp + c) * p.cap + s0));
+                for (int c = 0; c < 12; ++c) kreg[u][c] = ldg4(kp + ((12 * cgp + c) * p.cap + s0));
             } else {
 #pragma unroll
                 for (int c = 0; c < 12; ++c) kreg[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -438,10 +454,10 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         for (int u = 0; u < 6; ++u) {
             const int s = slot + 64 * u;
             if (arow && s < ncach) {
-                const float4* src = reinterpret_cast<const float4*>(vp + (s * TC + cg * 12));
-                vr[u][0] = src[0];
-                vr[u][1] = src[1];
-                vr[u][2] = src[2];
+                const float* src = vp + (s * TC + cg * 12);
+                vr[u][0] = ldg4(src);
+                vr[u][1] = ldg4(src + 4);
+                vr[u][2] = ldg4(src + 8);
             } else {
                 vr[u][0] = vr[u][1] = vr[u][2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             const float* src = pin_v(L.w2 + (size_t)(NF * w) * TC) + 3 * tid;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const f3 t = *reinterpret_cast<const f3*>(src + j * TC);
+                const f3 t = *GLOBAL_PTR(f3, src + j * TC);
                 w2[j][0] = t.x; w2[j][1] = t.y; w2[j][2] = t.z;
             }
         }
@@ -724,7 +740,7 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
     static bool once = false;
     if (!once) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gpt_token_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gpt_token_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQUEST));
         once = true;
     }
     // DTTS_GPT_TOKEN_TRACE = n: the n-th launch records wall-clock stamps of workgroups 0 and 37 at every exchange and prints them
@@ -733,46 +749,18 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
     static long long* d_trace = nullptr;
     GptTokenParams q = p;
     q.trace = nullptr;
-    if (const char* v = getenv("DTTS_GPT_TOKEN_NL")) q.NL = atoi(v);      // debug: fewer layers
     const bool tracing = trace_at > 0 && ++launches == trace_at;
     if (tracing) {
         if (!d_trace) DTTS_CHECK_HIP(hipMalloc(&d_trace, sizeof(long long) * 2 * 16 * 16));
         DTTS_CHECK_HIP(hipMemsetAsync(d_trace, 0, sizeof(long long) * 2 * 16 * 16, s));
         q.trace = d_trace;
     }
-    hipLaunchKernelGGL(gpt_token_kernel, dim3(TG), dim3(256), sizeof(Smem), s, q);
+    hipLaunchKernelGGL(gpt_token_kernel, dim3(TG), dim3(256), LDS_REQUEST, s, q);
     DTTS_CHECK_HIP(hipGetLastError());
     if (tracing) {
         long long h[2 * 16 * 16];
         DTTS_CHECK_HIP(hipMemcpyAsync(h, d_trace, sizeof(h), hipMemcpyDeviceToHost, s));
         DTTS_CHECK_HIP(hipStreamSynchronize(s));
-        if (getenv("DTTS_GPT_TOKEN_DUMP")) {                 // per-row checksums of the last layer's exchange buffers
-            std::vector<float> hx((size_t)RS_OFF * 4);
-            DTTS_CHECK_HIP(hipMemcpy(hx.data(), p.xch, hx.size() * 4, hipMemcpyDeviceToHost));
-            const int offs[4] = {X_OFF, QKV_OFF, AT_OFF, Y_OFF}, nq[4] = {XQ, 3 * XQ, XQ, XQ};
-            const char* bn[4] = {"X", "QKV", "AT", "Y"};
-            for (int k = 0; k < 4; ++k)
-                for (int b = 0; b < 8; ++b) {
-                    double sum = 0, asum = 0;
-                    for (int q = 0; q < nq[k]; ++q)
-                        for (int j = 0; j < 3; ++j) { const float v = hx[((size_t)offs[k] + (size_t)b * nq[k] + q) * 4 + j]; sum += v; asum += std::fabs(v); }
-                    unsigned tg; memcpy(&tg, &hx[((size_t)offs[k] + (size_t)b * nq[k]) * 4 + 3], 4);
-                    fprintf(stderr, "[dump] %-3s row %d sum %.6f abs %.6f tag %x\n", bn[k], b, sum, asum, tg);
-                }
-        }
-        if (getenv("DTTS_GPT_TOKEN_DUMP")) {
-            std::vector<float> hx((size_t)8 * XQ * 4);
-            DTTS_CHECK_HIP(hipMemcpy(hx.data(), p.xch, hx.size() * 4, hipMemcpyDeviceToHost));
-            for (int b : {2, 4}) {
-                fprintf(stderr, "[dump] X row %d vs row 0, differing columns:", b);
-                int n = 0;
-                for (int c = 0; c < TC && n < 40; ++c) {
-                    const float v0 = hx[((size_t)(c / 3)) * 4 + c % 3], vb = hx[((size_t)b * XQ + c / 3) * 4 + c % 3];
-                    if (v0 != vb) { fprintf(stderr, " %d(%.3f/%.3f)", c, v0, vb); ++n; }
-                }
-                fprintf(stderr, "\n");
-            }
-        }
         static const char* names[16] = {"X", "QKVst", "qkv", "ATst", "AT", "Yst", "Y", "RSst", "RS", "X'st", "p1tile", "p1gemv", "p3tile", "p3gemv", "gelu", "w2fma"};
         static const int order[16] = {0, 10, 11, 1, 2, 3, 4, 5, 6, 12, 13, 14, 15, 7, 8, 9};
         for (int g = 0; g < 2; ++g) {

@@ -385,7 +385,7 @@ class SynthesizerTrn:
         if self._a_pool is None:
             self._a_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dtts-stage-a")
         fut = self._a_pool.submit(stage_a, first)
-        pending = None
+        pending = launched = None
         try:
             while fut is not None:
                 sts, fut = fut.result(), None   # the only wait on the GPU: this group's codes (their lengths size stage B)
@@ -394,6 +394,7 @@ class SynthesizerTrn:
                     fut = self._a_pool.submit(stage_a, g)            # the next group's stage A starts now, under this group's diffusion
                 for st in sts:
                     out = launch_bc(st)         # stage B / C of this request: enqueued, not waited for
+                    launched = out
                     if pending is not None:
                         pending[2].synchronize()
                         yield pending[0], pending[1]
@@ -409,8 +410,8 @@ class SynthesizerTrn:
                     pass
             # ... and so must the abandoned request's vocoder (its own stream and scratch arena): a plain infer() right after would
             # otherwise run its stage C on the same arena under it
-            if pending is not None:
-                pending[2].synchronize()
+            if launched is not None:
+                launched[2].synchronize()
 
     def infer_gpt(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
                   forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False):

@@ -260,10 +260,20 @@ def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
     G = 24
     outs = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos))
     assert len(outs) == len(reqs)
-    # ... and with two consecutive requests of <= 8 utterances decoded as ONE <= 16-row session (per-row seeds): the same waveforms
-    paired = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos, pair_stage_a=True))
-    for (w0, l0), (w1, l1) in zip(outs, paired):
+    # ... and with two consecutive requests of <= 8 utterances decoded as ONE <= 16-row session (per-row seeds): the same waveforms.
+    # A 16-row session runs the launch-per-GEMV decode kernels; bit for bit against 8-row sessions on the same kernels, and the
+    # persistent token kernel's sessions (the default up to 8 rows) against those to fp32 summation-order noise in the latents (2e-6),
+    # which the 50 sampling steps carry to ~2e-4 RMS on these waveforms.
+    model.rt.set_option("gpt_token_kernel", 0)
+    try:
+        chain = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos))
+        paired = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=suppress_eos, pair_stage_a=True))
+    finally:
+        model.rt.set_option("gpt_token_kernel", 1)
+    for (w0, l0), (w1, l1) in zip(chain, paired):
         assert l0 == l1 and torch.equal(w0, w1)
+    for (w0, l0), (w1, l1) in zip(outs, chain):
+        assert l0 == l1 and float((w0 - w1).pow(2).mean().sqrt()) < 1e-3        # north_star's tolerance (24 kHz waveform RMS)
     for r, (wav, lens) in zip(reqs, outs):
         ref, rlens = model.infer(r["text"], r["text_length"], r["refer"], r["refer_lengths"], batch=True, seed=r["seed"],
                                  sample_ids=r["sample_ids"], max_generate_length=G, suppress_eos=suppress_eos, return_lengths=True)
@@ -289,3 +299,50 @@ def test_infer_stream_closed_early_leaves_the_handle_usable(model):
     again = model.infer(text, req["text_length"], refer, req["refer_lengths"], batch=True, seed=5, sample_ids=[0, 1], max_generate_length=12,
                         suppress_eos=True)
     assert torch.equal(again, ref)
+
+
+def test_token_kernel_under_a_concurrent_diffusion_load(model):
+    """Stage A's persistent token kernel runs under the previous request's diffusion in SynthesizerTrn.infer_stream: a decode session
+    repeated while another host thread keeps the diffusion sampler (split-precision convs / attention with LDS-DMA) running on its own
+    stream must give the same codes and latents bit for bit.  (With the token workgroups SHARING CUs with those kernels it did not:
+    csrc/gpt_token.hip, LDS_REQUEST.)"""
+    import threading
+    rt = model.rt
+    rs = np.random.RandomState(10)
+    B, G = 3, 24
+    refer = torch.from_numpy((rs.randn(B, 128, 200) * 2 - 5).astype(np.float32)).cuda()
+    texts = [np.concatenate([rs.randint(3, 255, 10), [0]]).astype(np.int32) for _ in range(B)]
+
+    def gen():
+        c, n, l = rt.gpt_generate(refer, None, texts, 5, list(range(B)), max_generate_length=G, suppress_eos=True)
+        return c, l.clone()
+
+    c0, l0 = gen()
+    stop = threading.Event()
+    failed = []
+
+    def load():
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                r8 = torch.from_numpy((np.random.RandomState(1).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
+                ce = rt.diff_timestep_independent(torch.randn(8, 768, 100, device="cuda"), rt.diff_conditioning(r8))
+                while not stop.is_set():
+                    rt.diff_sample(ce, 3, list(range(8)), n_steps=4)
+                    s.synchronize()
+        except Exception as e:      # pragma: no cover
+            failed.append(e)
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        import time
+        time.sleep(1.0)
+        for _ in range(6):
+            c1, l1 = gen()
+            assert np.array_equal(c0, c1) and torch.equal(l0, l1)
+    finally:
+        stop.set()
+        th.join()
+    assert not failed, failed
