@@ -160,3 +160,25 @@ def test_token_kernel_equals_the_launch_per_gemv_chain(rt):
     finally:
         rt.set_option("gpt_token_kernel", 1)
     assert np.array_equal(c2[0], c3[0]) and np.array_equal(c2[1], c3[1])
+
+
+def test_token_kernel_long_session_equals_the_chain(rt):
+    """Sessions whose key count passes 512 (the register-resident K rounds) and 384 (the V rounds) of the persistent token kernel: a
+    400-token prompt + 200 teacher-forced tokens, latents against the launch-per-GEMV chain at every position; and free sampling at
+    that prompt length gives the same codes."""
+    rs = np.random.RandomState(71)
+    B, G = 2, 200
+    refer = (rs.randn(B, 128, 150) * 2 - 5).astype(np.float32)
+    texts = [np.concatenate([rs.randint(3, 255, 400 - 30 * b), [0]]).astype(np.int32) for b in range(B)]
+    forced = [rs.randint(0, 8192, G).astype(np.int32) for _ in range(B)]
+    args = (dev(refer), None, texts, 9, [3, 4])
+    rt.set_option("gpt_token_kernel", 0)
+    try:
+        l0 = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2].clone()
+        c0 = rt.gpt_generate(*args, max_generate_length=60, suppress_eos=True)[0]
+    finally:
+        rt.set_option("gpt_token_kernel", 1)
+    l1 = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2]
+    assert float((l0[:, :, :G] - l1[:, :, :G]).abs().max()) < 2e-4
+    c1 = rt.gpt_generate(*args, max_generate_length=60, suppress_eos=True)[0]
+    assert np.array_equal(c0, c1)
