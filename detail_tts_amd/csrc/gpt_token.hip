@@ -86,9 +86,12 @@ static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials a
 // The kernel asks for a CU's WHOLE LDS (it uses 55 KiB): one token workgroup per CU and nothing else next to it.  Sharing a CU with
 // the diffusion trunk's split-precision conv / attention workgroups (stage B of the previous request under SynthesizerTrn.infer_stream)
 // gave WRONG results - deterministic alone, a few accumulators of some workgroups off by percents under that load, sampled codes
-// changed; not under a rocBLAS load, not under the exact-fp32 conv kernels.  Not explained: an LDS canary next to the same load saw
-// no foreign write, FLAT / inline-asm accesses and AGPR use were ruled out.  With the CU to itself: 0 mismatches in every stress
-// run (tests/test_gpu_e2e.py::test_token_kernel_under_a_concurrent_diffusion_load), and the pipeline is no slower (461 vs 457 ms).
+// changed; not under a rocBLAS load, not under the exact-fp32 conv kernels.  An LDS canary next to the same load saw no foreign
+// write; FLAT / inline-asm accesses and AGPR use were ruled out.  What does remove it: this file built with -fno-slp-vectorize, i.e.
+// WITHOUT the packed fp32 instructions (the first corrupted values traced to the hi lane of `v_pk_fma_f32 ... op_sel_hi:[1,0,1]`
+// in col_gemv) - 24 of 24 sessions identical while sharing CUs, at +5 % decode time alone (89.4 vs 85.0 ms) and -1 % pipeline time.
+// Kept: packed math AND the CU to itself - 0 mismatches in every stress run
+// (tests/test_gpu_e2e.py::test_token_kernel_under_a_concurrent_diffusion_load), and the pipeline is no slower (461 vs 457 ms).
 constexpr int LDS_REQUEST = 160 * 1024;
 static_assert(sizeof(Smem) <= LDS_REQUEST, "LDS");
 
