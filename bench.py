@@ -310,6 +310,48 @@ def main():
                        "(slower than the unprofiled stage_ms); the ResBlock1 convs of the two wide generator stages run on the split-precision "
                        "fp16 pipe (conv_x3d), everything else on fp32 MFMA - `frac_fp32_mfma` quotes the fp32-equivalent FLOP/s of the whole "
                        "stage against the fp32 MFMA peak"}
+    # ---- extra measurements of the SAME run (untimed region, rank 0, N = 1 only): what the headline number is NOT --------------------
+    extra = {}
+    if world == 1 and os.environ.get("DTTS_BENCH_NO_EXTRA") != "1":
+        def timed(fn, n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn(n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3, r
+        # (a) the same batches WITHOUT the three-stream request pipeline: one blocking infer() per step
+        ms, _ = timed(lambda n: [model.infer(text, tl, refer, rl, batch=True, seed=4000 + i, sample_ids=sample_ids, max_generate_length=n_codes + 1,
+                                             suppress_eos=True) for i in range(n)], 3)
+        extra["unpipelined_ms_per_step"] = round(ms, 2)
+        extra["unpipelined_audio_s_per_s"] = round((n_codes * 1024 / 24000.0) * B / (ms * 1e-3), 2)
+        # (b) batch 1 (configs[1]): latency of one blocking infer(), and the pipelined period of a stream of single-utterance requests
+        r1 = dict(text=text[:1], text_length=tl[:1], refer=refer[:1], refer_lengths=rl[:1], sample_ids=sample_ids[:1])
+        model.infer(text[:1], tl[:1], refer[:1], rl[:1], batch=True, seed=1, sample_ids=sample_ids[:1], max_generate_length=n_codes + 1, suppress_eos=True)
+        ms, _ = timed(lambda n: [model.infer(text[:1], tl[:1], refer[:1], rl[:1], batch=True, seed=4100 + i, sample_ids=sample_ids[:1],
+                                             max_generate_length=n_codes + 1, suppress_eos=True) for i in range(n)], 3)
+        extra["batch1_latency_ms"] = round(ms, 2)
+        ms, _ = timed(lambda n: list(model.infer_stream((dict(r1, seed=4200 + i) for i in range(n)), max_generate_length=n_codes + 1, suppress_eos=True)), 6)
+        extra["batch1_pipelined_ms_per_request"] = round(ms, 2)
+        # (c) a RAGGED batch of 8 (code counts 97 .. 234, prompts 512 .. 936 frames, texts 25 .. 61 ids; forced codes through the KV-cache
+        # decode so that the lengths are what they are here): no two-equal-length shortcut - the unconditional half of the
+        # conditioning_timestep_integrator is evaluated once per DISTINCT length (7 here, 1 in the headline batch)
+        rsr = np.random.RandomState(91)
+        rn = [234, 180, 201, 97, 234, 234, 150, 222][:B] if n_codes == N_CODES else [max(1, n_codes - 3 * b) for b in range(B)]
+        rrl = [936, 700, 936, 512, 801, 936, 936, 640][:B]
+        rtl = [61, 40, 61, 25, 50, 61, 61, 33][:B]
+        rrefer = torch.from_numpy((rsr.randn(B, 128, T_REF) * 2 - 5).astype(np.float32)).to(dev)
+        rtext = np.zeros((B, 61), np.int32)
+        for b in range(B):
+            rtext[b, : rtl[b] - 1] = rsr.randint(3, 255, rtl[b] - 1)
+        rcodes = [rsr.randint(0, 8192, size=rn[b]) for b in range(B)]
+        rreq = dict(text=torch.from_numpy(rtext), text_length=torch.tensor(rtl), refer=rrefer, refer_lengths=torch.tensor(rrl),
+                    sample_ids=sample_ids, forced_codes=rcodes)
+        list(model.infer_stream((dict(rreq, seed=4300 + i) for i in range(2)), max_generate_length=n_codes + 1))
+        ms, ro = timed(lambda n: list(model.infer_stream((dict(rreq, seed=4310 + i) for i in range(n)), max_generate_length=n_codes + 1)), 4)
+        assert ro[-1][1] == [1024 * v for v in rn]
+        extra["ragged_batch"] = {"codes": rn, "prompt_frames": rrl, "text_ids": rtl, "ms_per_step": round(ms, 2),
+                                 "audio_s_per_s": round(sum(rn) * 1024 / 24000.0 / (ms * 1e-3), 2), "distinct_lengths": len(set(rn)),
+                                 "note": "pipelined like the headline; audio counted per utterance's own length; forced codes through the decode session"}
     rank_ms = [dt / args.steps * 1e3]
     if multi:
         t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -395,6 +437,17 @@ def main():
                     "note": ("latency-bound: 5 memory-exchange hops per layer (~2.5 us each) + the per-phase compute between them, not the "
                              "HBM stream; measured alone (stage-timing pass), under the pipeline it takes ~160 ms per request: DESIGN.md section 4")
                     if token_kernel else "latency-bound chain of short dependent kernels, not bandwidth-bound: DESIGN.md section 4"}
+    # the unconditional half of the conditioning_timestep_integrator depends only on (timestep, length): it is evaluated once per DISTINCT
+    # length of the batch (csrc/model.hip: plan_pair).  The headline batch has 8 EQUAL lengths, so 7 of its 8 evaluations are not done.
+    dcfg = model.cfg["diffusion"]
+    Cd, Td = dcfg["model_channels"], 4 * n_codes
+    Ci, Co = dcfg["in_channels"], dcfg["out_channels"]
+    layer_f = 2.0 * 8 * Cd * Cd * Td + 4.0 * Td * Td * Cd          # DiffusionLayer: 1x1 + k3 + qkv + proj convs + attention (flops per sample)
+    rb_f = 2.0 * 4 * Cd * Cd * Td                                  # ResBlock: 1x1 + k3
+    fwd_f = 2.0 * Td * 3 * Ci * Cd + 3 * layer_f + 2.0 * Td * 2 * Cd * Cd + 10 * layer_f + 3 * rb_f + 2.0 * Td * 3 * Cd * Co      # 166.9 GFLOP at T = 936
+    dedup = {"enabled": True, "distinct_lengths_in_headline_batch": 1,
+             "flops_removed_frac_of_diffusion": round(0.5 * 3 * layer_f / fwd_f * (B - 1) / B, 4),
+             "note": "identical values (the branch never sees x_t or the utterance); a ragged batch keeps one evaluation per distinct length - see ragged_batch"}
     out = {
         "metric": "generated audio seconds/sec (24 kHz), 10 s prompt, batch 8 per GPU", "value": round(value, 3), "unit": "audio_s/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -403,11 +456,13 @@ def main():
         "config": {"workload": "configs[2]: 1xMI355X batch-8, 10 s prompts (T_ref=936), 234 codes -> 9.984 s audio per utterance; "
                                "GPT KV-cache decode + 50-step CFG diffusion + flow-VAE/HiFiGAN vocoder, seed-0 random-init weights",
                    "batch_per_gpu": B, "codes": n_codes, "diffusion_steps": 50, "parallelism": f"replica x{world}",
+                   "uncond_integrator_dedup": dedup,
                    "pipelining": ("stage A of batch i + 1 on a high-priority HIP stream under stage B of batch i, stage C of batch i under stage B of "
                                   "batch i + 1 (SynthesizerTrn.infer_stream)") if pipeline else
                                  ("stage C of batch i on a second HIP stream under the GPT decode of batch i + 1" if overlap else "none")},
         "rank_ms_per_step": rank_ms, "weight_broadcast": bcast,
         "stage_ms": stage_ms,
+        **extra,
         "roofline": roof,
         "roofline_attention": roof_att,
         "roofline_decode": roof_dec,

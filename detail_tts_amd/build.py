@@ -22,9 +22,20 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _extra_flags(src):
+    """Per-file flags: a `// hipcc-flags: ...` line among the first five lines of the source (gpt_token.hip: -fno-slp-vectorize)."""
+    out = []
+    with open(os.path.join(CSRC, src)) as f:
+        for _ in range(5):
+            line = f.readline()
+            if line.startswith("// hipcc-flags:"):
+                out += line.split(":", 1)[1].split()
+    return out
+
+
 def _digest(src):
     h = hashlib.sha1()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + _extra_flags(src)).encode())
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".h"):
             h.update(open(os.path.join(CSRC, f), "rb").read())
@@ -39,7 +50,7 @@ def _compile(src):
     dig = _digest(src)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC, *FLAGS, *_extra_flags(src), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

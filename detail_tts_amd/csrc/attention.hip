@@ -240,12 +240,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 template <int D>
 static void launch_d(const AttnParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     const int mode = (p.bias_tab ? 1 : 0) | (p.causal ? 2 : 0) | (p.band ? 4 : 0);
-    static bool attr[8] = {false};
-    auto go = [&](auto kern, int m) {
-        if (lds > 64 * 1024 && !attr[m]) {
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr[m] = true;
-        }
+    auto go = [&](auto kern, int) {
+        if (lds > 64 * 1024) lds_optin(reinterpret_cast<const void*>(kern), (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     };
     switch (mode) {

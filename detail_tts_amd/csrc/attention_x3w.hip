@@ -251,11 +251,7 @@ __global__ __launch_bounds__(256, 3) void flash_attn_x3w_kernel(const AttnParams
 void launch_flash_attention_x3w(const AttnParams& p, hipStream_t stream) {
     DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out && p.planes, "attention_x3w covers head dim 48 with the T5 bias on operand images");
     constexpr size_t lds = 2 * BUF_BYTES + sizeof(float) * (2 * BIAS_CLIP + 1);
-    static bool attr = false;
-    if (!attr) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    lds_optin(reinterpret_cast<const void*>(flash_attn_x3w_kernel), (int)lds);
     const dim3 grid(cdiv(p.T, QPB) * p.H * p.B);
     hipLaunchKernelGGL(flash_attn_x3w_kernel, grid, dim3(NW * 64), lds, stream, p);
     DTTS_CHECK_HIP(hipGetLastError());

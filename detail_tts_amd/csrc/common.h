@@ -28,6 +28,13 @@ struct Error : std::runtime_error {
                                         " [" #cond "] at " + __FILE__ + ":" + std::to_string(__LINE__)); \
     } while (0)
 
+// Opt-in LDS sizes (hipFuncSetAttribute(MaxDynamicSharedMemorySize)) are a per-DEVICE property of a kernel: applied once per
+// (device, kernel), under a lock, so that handles on several GPUs of one process and the stage threads of infer_stream are all served
+// (device.hip).  lds_optin throws on failure; device_fits reports whether the current device can hold `wgs` co-resident workgroups
+// of `lds_bytes` each, one per CU (the persistent kernels' requirement).
+void lds_optin(const void* kernel, int bytes);
+bool device_fits(int wgs, int lds_bytes);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

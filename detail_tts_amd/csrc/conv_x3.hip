@@ -819,20 +819,7 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     const long long nwg = ntile * S;
     const int nstg = force_stg ? force_stg : (nwg <= max4 ? 4 : (nwg <= max3 ? 3 : 2));
     const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16;
-    static bool attr = false;
-    if (!attr) {
-        const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float) + 16;
-        const void* fns[] = {reinterpret_cast<const void*>(conv_x3_kernel<2, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<2, false, 3>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<2, false, 4>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<0, false, 2>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 2>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<0, true, 2>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 2>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<0, false, 3>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 3>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<0, true, 3>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 3>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<0, false, 4>), reinterpret_cast<const void*>(conv_x3_kernel<1, false, 4>),
-                             reinterpret_cast<const void*>(conv_x3_kernel<0, true, 4>),  reinterpret_cast<const void*>(conv_x3_kernel<1, true, 4>)};
-        for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
-        attr = true;
-    }
+    const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float) + 16;      // the attribute is a maximum: every instantiation gets the 4-stage size
     const dim3 grid((unsigned)nwg);
     const double cols = (double)p.B * p.Nout;
     const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 3x this in fp16
@@ -845,9 +832,9 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
         const bool epi = p.epi_act != ACT_NONE || p.out_scale != 1.f;
 #define DTTS_LAUNCH_X3(E, K3)                                                                                          \
     do {                                                                                                               \
-        if (nstg == 4) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 4>), grid, dim3(256), lds, s, p);                      \
-        else if (nstg == 3) hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p);                 \
-        else hipLaunchKernelGGL((conv_x3_kernel<E, K3, 2>), grid, dim3(256), lds, s, p);                                \
+        if (nstg == 4) { lds_optin(reinterpret_cast<const void*>(conv_x3_kernel<E, K3, 4>), l4); hipLaunchKernelGGL((conv_x3_kernel<E, K3, 4>), grid, dim3(256), lds, s, p); } \
+        else if (nstg == 3) { lds_optin(reinterpret_cast<const void*>(conv_x3_kernel<E, K3, 3>), l4); hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p); } \
+        else { lds_optin(reinterpret_cast<const void*>(conv_x3_kernel<E, K3, 2>), l4); hipLaunchKernelGGL((conv_x3_kernel<E, K3, 2>), grid, dim3(256), lds, s, p); } \
     } while (0)
         if (p.qkv_planes) {
             DTTS_REQUIRE(p.KW == 1 && !epi && !p.res && p.Cout % 144 == 0 && p.qkv_heads * 144 == p.Cout, "qkv planes epilogue: 48-channel heads, 1x1 conv");

@@ -213,23 +213,15 @@ void launch_conv_x3d(const ConvParams& p, hipStream_t s) {
     DTTS_REQUIRE(round_up(p.Nout, BN) + (XCOLS - BN) + p.x3_halo <= p.x3_tp, "conv_x3d: time padding");
     const int MI = p.CoutP % 128 == 0 ? 2 : 1, BM = 64 * MI;
     const size_t lds = (size_t)2 * NK * BM * 16 + 2 * XTILE + BM * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        const int lmax = 2 * NK * 128 * 16 + 2 * XTILE + 128 * (int)sizeof(float);
-        const void* fns[] = {reinterpret_cast<const void*>(conv_x3d_kernel<3, 2>), reinterpret_cast<const void*>(conv_x3d_kernel<7, 2>),
-                             reinterpret_cast<const void*>(conv_x3d_kernel<11, 2>), reinterpret_cast<const void*>(conv_x3d_kernel<3, 1>),
-                             reinterpret_cast<const void*>(conv_x3d_kernel<7, 1>), reinterpret_cast<const void*>(conv_x3d_kernel<11, 1>)};
-        for (const void* f : fns) DTTS_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lmax));
-        attr = true;
-    }
+    const int lmax = 2 * NK * 128 * 16 + 2 * XTILE + 128 * (int)sizeof(float);
     const dim3 grid((unsigned)((long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B));
     const double cols = (double)p.B * p.Nout;
     ProfScope ps(MI == 2 ? "conv_x3d_kernel<128,192>" : "conv_x3d_kernel<64,192>", 2.0 * p.Cout * p.Cin * p.KW * cols,
                  4.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 4.0 * (double)p.Cout * p.Cin * p.KW, s);
 #define DTTS_LAUNCH_X3D(K)                                                                            \
     do {                                                                                              \
-        if (MI == 2) hipLaunchKernelGGL((conv_x3d_kernel<K, 2>), grid, dim3(256), lds, s, p);          \
-        else hipLaunchKernelGGL((conv_x3d_kernel<K, 1>), grid, dim3(256), lds, s, p);                  \
+        if (MI == 2) { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 2>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 2>), grid, dim3(256), lds, s, p); } \
+        else { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 1>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 1>), grid, dim3(256), lds, s, p); } \
     } while (0)
     if (p.KW == 3) DTTS_LAUNCH_X3D(3);
     else if (p.KW == 7) DTTS_LAUNCH_X3D(7);

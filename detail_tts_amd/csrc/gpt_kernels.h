@@ -134,8 +134,10 @@ struct GptTokenParams {
     int* err;                        // raised when an exchange poll times out
     unsigned* epoch;                 // launch counter (>= 1), bumped by the kernel
     long long* trace;                // debug: wall-clock stamps (DTTS_GPT_TOKEN_TRACE), normally null
+    int exclusive_cu;                // ask for a CU's whole LDS: one token workgroup per CU, no LDS-using workgroup next to it
 };
 bool gpt_token_supported(int C, int H, int F, int NL, int V);
+bool gpt_token_prepare();            // device check + kernel attributes at bind time; false = use the chain
 size_t gpt_token_pack_floats(int which);
 void launch_gpt_token_pack(int which, const float* W, int N, int CoutP, float* out, hipStream_t s);
 void launch_gpt_token(const GptTokenParams& p, hipStream_t s);

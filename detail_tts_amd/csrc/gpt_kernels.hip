@@ -921,12 +921,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
 void launch_sampler(const SamplerParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.V <= SORT_MAX && p.V < 65535, "vocabulary too large for the LDS sampler");
     const size_t lds = sizeof(float) * (size_t)(((p.V + 3) & ~3) + SORT_MAX) + sizeof(unsigned short) * SORT_MAX;
-    static bool once = false;
-    if (!once) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024));
-        once = true;
-    }
+    lds_optin(reinterpret_cast<const void*>(sampler_kernel), 150 * 1024);
     hipLaunchKernelGGL(sampler_kernel, dim3(p.B), dim3(SAMP_THREADS), lds, s, p);
     DTTS_CHECK_HIP(hipGetLastError());
 }

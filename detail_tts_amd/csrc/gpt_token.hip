@@ -1,3 +1,5 @@
+// hipcc-flags: -fno-slp-vectorize
+// (build.py reads the line above: this file is compiled WITHOUT packed fp32 math - see "CU sharing" below.)
 // One decode token of the GPT-2 stack as ONE persistent kernel (gpt/model.py:107-185 GPT2InferenceModel.forward with the KV cache;
 // HF GPT2Block: ln_1 -> c_attn -> attention -> c_proj -> + -> ln_2 -> c_fc -> gelu_new -> c_proj -> +; then ln_f, final_norm,
 // mel_head: gpt/model.py:41, 173).
@@ -83,17 +85,19 @@ struct Smem {
     float mred[4], lred[4];
 };
 static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials alias the activation tile");
-// The kernel asks for a CU's WHOLE LDS (it uses 55 KiB): one token workgroup per CU and nothing else next to it.  Sharing a CU with
-// the diffusion trunk's split-precision conv / attention workgroups (stage B of the previous request under SynthesizerTrn.infer_stream)
+// CU sharing.  Built with packed fp32 math (`v_pk_fma_f32`, the SLP vectoriser's default), token workgroups that shared a CU with the
+// diffusion trunk's split-precision conv / attention workgroups (stage B of the previous request under SynthesizerTrn.infer_stream)
 // gave WRONG results - deterministic alone, a few accumulators of some workgroups off by percents under that load, sampled codes
 // changed; not under a rocBLAS load, not under the exact-fp32 conv kernels.  An LDS canary next to the same load saw no foreign
-// write; FLAT / inline-asm accesses and AGPR use were ruled out.  What does remove it: this file built with -fno-slp-vectorize, i.e.
-// WITHOUT the packed fp32 instructions (the first corrupted values traced to the hi lane of `v_pk_fma_f32 ... op_sel_hi:[1,0,1]`
-// in col_gemv) - 24 of 24 sessions identical while sharing CUs, at +5 % decode time alone (89.4 vs 85.0 ms) and -1 % pipeline time.
-// Kept: packed math AND the CU to itself - 0 mismatches in every stress run
-// (tests/test_gpu_e2e.py::test_token_kernel_under_a_concurrent_diffusion_load), and the pipeline is no slower (461 vs 457 ms).
-constexpr int LDS_REQUEST = 160 * 1024;
-static_assert(sizeof(Smem) <= LDS_REQUEST, "LDS");
+// write; FLAT / inline-asm accesses and AGPR use were ruled out; the first corrupted values traced to the hi lane of
+// `v_pk_fma_f32 ... op_sel_hi:[1,0,1]` in col_gemv.  Round 3 shipped packed math + an occupancy trick (request the CU's whole LDS so
+// that nothing with LDS co-resides); zero-LDS kernels could still share the CU.  Since round 4 the file is built with
+// -fno-slp-vectorize (first line; no packed fp32 instruction is left in the object: tests/test_host_logic.py disassembles it), which
+// is the variant that was bit-identical in every shared-CU run, AND the exclusive-CU request stays available as a policy knob
+// (option "gpt_token_exclusive_cu" / DTTS_GPT_TOKEN_EXCLUSIVE_CU, see DESIGN.md for the measured choice); the stress tests run both
+// settings next to LDS kernels, zero-LDS kernels and the vocoder (tests/test_gpu_e2e.py::test_token_kernel_under_concurrent_*).
+constexpr int LDS_EXCLUSIVE = 160 * 1024;
+static_assert(sizeof(Smem) <= 64 * 1024, "LDS");
 
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
@@ -719,6 +723,25 @@ void pack(const float* W, int K, int N, int CoutP, int PN, int KL, int KT, int N
 
 bool gpt_token_supported(int C, int H, int F, int NL, int V) { return C == TC && H == TH && F == TF && NL >= 1 && NL <= GPT_TOKEN_MAX_LAYERS && V <= GPT_TOKEN_VS; }
 
+// Bind-time device check + kernel attributes (per device, outside any stream capture): the 128 workgroups must all be resident at the
+// same time, one per CU - fewer CUs (partition modes, CU masks, a 64 KiB-LDS part asked for a whole CU) would run every exchange poll
+// into SPIN_LIMIT.  false -> the caller keeps the launch-per-GEMV chain.
+bool gpt_token_prepare() {
+    if (!device_fits(TG, LDS_EXCLUSIVE)) return false;
+    try {
+        lds_optin(reinterpret_cast<const void*>(gpt_token_kernel), LDS_EXCLUSIVE);
+    } catch (const Error&) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gpt_token_kernel), 256, LDS_EXCLUSIVE) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return nb >= 1;
+}
+
 size_t gpt_token_pack_floats(int which) {
     switch (which) {
         case 0: return (size_t)TG * (Q_KT / 2) * 256 * 4;
@@ -741,11 +764,7 @@ void launch_gpt_token_pack(int which, const float* W, int N, int CoutP, float* o
 void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.B >= 1 && p.B <= 8 && p.NL >= 1 && p.NL <= GPT_TOKEN_MAX_LAYERS && p.Vs == GPT_TOKEN_VS, "persistent decode token: shape");
     DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
-    static bool once = false;
-    if (!once) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gpt_token_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQUEST));
-        once = true;
-    }
+    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)sizeof(Smem);       // the attribute was raised by gpt_token_prepare (bind time)
     // DTTS_GPT_TOKEN_TRACE = n: the n-th launch records wall-clock stamps of workgroups 0 and 37 at every exchange and prints them
     static const int trace_at = []() { const char* v = getenv("DTTS_GPT_TOKEN_TRACE"); return v ? atoi(v) : 0; }();
     static int launches = 0;
@@ -758,7 +777,7 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
         DTTS_CHECK_HIP(hipMemsetAsync(d_trace, 0, sizeof(long long) * 2 * 16 * 16, s));
         q.trace = d_trace;
     }
-    hipLaunchKernelGGL(gpt_token_kernel, dim3(TG), dim3(256), LDS_REQUEST, s, q);
+    hipLaunchKernelGGL(gpt_token_kernel, dim3(TG), dim3(256), lds_request, s, q);
     DTTS_CHECK_HIP(hipGetLastError());
     if (tracing) {
         long long h[2 * 16 * 16];

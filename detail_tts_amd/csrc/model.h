@@ -205,7 +205,9 @@ public:
         else if (key == "conv_x3") opt_conv_x3_ = value != 0;
         else if (key == "gpt_graph") opt_gpt_graph_ = value != 0;
         else if (key == "x3_range_check") opt_range_check_ = value != 0;
-        else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; gpt_drop_graphs(); }
+        else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; if (value != 0) tok_failed_ = false; gpt_drop_graphs(); }
+        else if (key == "gpt_token_exclusive_cu") { opt_tok_exclusive_ = value != 0; gpt_drop_graphs(); }
+        else if (key == "gpt_token_fault") opt_tok_fault_ = value;       // test hook: the n-th token launch from now on times out
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else throw Error(-1, "unknown option '" + key + "'");
     }
@@ -294,6 +296,21 @@ private:
     GptTokenParams tokp_;                 // its launch parameters (weight side filled at bind time, session side at prefill)
     bool tok_ok_ = false;                 // the model has the shape the token kernel is written for
     bool opt_gpt_token_ = true;           // option "gpt_token_kernel"
+    bool opt_tok_exclusive_ = true;       // option "gpt_token_exclusive_cu": the token kernel asks for whole CUs
+    bool tok_failed_ = false;             // an exchange timed out once: this handle stays on the chain (until the option is set again)
+    int opt_tok_fault_ = 0;               // option "gpt_token_fault"
+    // what dtts_gpt_prefill was called with, kept so that a session whose token kernel timed out can be replayed on the chain
+    struct GptReplay {
+        bool valid = false;
+        int Tr = 0, Lt_max = 0, B = 0, lat_stride = 0;
+        bool has_refer_lens = false, has_text_lens = false;
+        std::vector<int> refer_lens, text, text_lens, sample_ids, forced_codes;
+        std::vector<unsigned long long> row_seeds;
+        dtts_gpt_options o;
+        float* latents_cm = nullptr;
+    } replay_;
+    Arena gpt_replay_;                    // device copy of the prompt mel of the running session
+    bool replaying_ = false;
     bool gpt_use_token_kernel() const;
     Arena gpt_state_;                     // decode session state (fixed addresses: the captured graphs point into it)
     GptSession gs_;

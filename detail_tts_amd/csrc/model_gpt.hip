@@ -62,6 +62,8 @@ void Model::build_gpt(hipStream_t s) {
     // the persistent token kernel's register-order weight copies (gpt_token.hip)
     tok_ok_ = gpt_token_supported(C, cfg.gpt_heads, gpt_layers_.empty() ? 0 : gpt_layers_[0].fc.Cout, (int)gpt_layers_.size(), cfg.gpt_mel_codes);
     for (auto& w : gpt_layers_) tok_ok_ = tok_ok_ && w.fc2.CoutP == C && w.fc.Cout == 4 * C;
+    tok_ok_ = tok_ok_ && gpt_token_prepare();            // 128 co-resident workgroups + the opt-in LDS size on THIS device
+    tok_failed_ = false;
     if (tok_ok_) {
         const size_t per_layer = gpt_token_pack_floats(0) + gpt_token_pack_floats(1) + gpt_token_pack_floats(2);
         gpt_tokw_.ensure(sizeof(float) * (per_layer * gpt_layers_.size() + gpt_token_pack_floats(3) + GPT_TOKEN_VS) + 65536 +
@@ -106,7 +108,7 @@ void Model::build_gpt(hipStream_t s) {
 // sessions of <= 8 rows decode a token with ONE persistent kernel (DTTS_GPT_TOKEN_KERNEL=0: the launch-per-GEMV chain)
 bool Model::gpt_use_token_kernel() const {
     static const bool env_on = []() { const char* v = getenv("DTTS_GPT_TOKEN_KERNEL"); return !(v && v[0] == '0'); }();
-    return env_on && opt_gpt_token_ && tok_ok_ && gs_.B <= 8 && gs_.xch != nullptr;
+    return env_on && opt_gpt_token_ && tok_ok_ && !tok_failed_ && gs_.B <= 8 && gs_.xch != nullptr;
 }
 
 // HF GPT-2 stack (without ln_f) over x [B, C, L] in place; optionally fills the KV cache.
@@ -202,6 +204,26 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     DTTS_REQUIRE(o.max_generate_length >= 1 && o.max_generate_length + 1 <= cfg.gpt_max_mel_pos, "max_generate_length");
     DTTS_REQUIRE(!latents_cm || lat_stride >= o.max_generate_length, "latent buffer too small");
     DTTS_REQUIRE(o.sample_ids, "sample_ids");
+    if (!replaying_) {                               // keep the call's inputs: a timed-out token kernel is replayed on the chain (gpt_finish)
+        GptReplay& r = replay_;
+        r.valid = false;
+        if (tok_ok_ && !tok_failed_ && B <= 8) {
+            const size_t nref = (size_t)B * cfg.mel_channels * Tr;
+            gpt_replay_.ensure(sizeof(float) * nref + 256);
+            DTTS_CHECK_HIP(hipMemcpyAsync(gpt_replay_.f32(nref), refer, sizeof(float) * nref, hipMemcpyDeviceToDevice, s));
+            r.Tr = Tr; r.Lt_max = Lt_max; r.B = B; r.lat_stride = lat_stride; r.latents_cm = latents_cm;
+            r.has_refer_lens = refer_lens_host != nullptr;
+            r.has_text_lens = text_lens_host != nullptr;
+            if (refer_lens_host) r.refer_lens.assign(refer_lens_host, refer_lens_host + B);
+            r.text.assign(text_host, text_host + (size_t)B * Lt_max);
+            if (text_lens_host) r.text_lens.assign(text_lens_host, text_lens_host + B);
+            r.sample_ids.assign(o.sample_ids, o.sample_ids + B);
+            r.o = o;
+            if (o.forced_codes) r.forced_codes.assign(o.forced_codes, o.forced_codes + (size_t)B * o.max_generate_length);
+            if (o.row_seeds) r.row_seeds.assign(o.row_seeds, o.row_seeds + B);
+            r.valid = true;
+        }
+    }
     ArenaUse use_stage_a_arena(ws_gpt_);             // decode steps use only gpt_state_; the prefill's scratch is stage A's own
     const int C = cfg.gpt_dim, V = cfg.gpt_mel_codes, G = o.max_generate_length;
     const int NL = (int)gpt_layers_.size();
@@ -367,6 +389,13 @@ void Model::gpt_step_launches(hipStream_t s) {
         p.logits = gs_.logits;
         p.err = gs_.tok_err;
         p.epoch = gs_.tok_epoch;
+        static const int env_excl = []() { const char* v = getenv("DTTS_GPT_TOKEN_EXCLUSIVE_CU"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
+        p.exclusive_cu = env_excl >= 0 ? env_excl : (opt_tok_exclusive_ ? 1 : 0);
+        if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)
+            const int one = 1;
+            DTTS_CHECK_HIP(hipMemcpyAsync(gs_.tok_err, &one, sizeof(int), hipMemcpyHostToDevice, s));
+            DTTS_CHECK_HIP(hipStreamSynchronize(s));
+        }
         {
             ProfScope ps("gpt_token", 0.0, 0.0, s);
             launch_gpt_token(p, s);
@@ -548,9 +577,41 @@ void Model::gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s) {
     if (gs_.tok_err) DTTS_CHECK_HIP(hipMemcpyAsync(&tok_err, gs_.tok_err, sizeof(int), hipMemcpyDeviceToHost, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
     if (tok_err) {
+        // An exchange poll of the persistent token kernel gave up (its 128 workgroups were not all resident: CU mask, partition mode,
+        // another process holding CUs).  The handle leaves the token kernel for good and THIS session is replayed from its prefill on
+        // the launch-per-GEMV chain - same sampler, same Philox draws, so the codes are the ones the chain would have produced.
         DTTS_CHECK_HIP(hipMemsetAsync(gs_.tok_err, 0, sizeof(int), s));
+        DTTS_CHECK_HIP(hipStreamSynchronize(s));
         gs_.active = false;
-        DTTS_REQUIRE(false, "persistent decode kernel: an activation exchange timed out (workgroups not co-resident?); set DTTS_GPT_TOKEN_KERNEL=0");
+        tok_failed_ = true;
+        gpt_drop_graphs();
+        int steps = gs_.steps;
+        for (int b = 0; b < B; ++b) steps = std::max(steps, std::min(hctl.step[b], G));
+        fprintf(stderr, "[detail_hip] persistent decode kernel: an activation exchange timed out; replaying %d tokens on the launch-per-GEMV chain "
+                        "(this handle stays on the chain)\n", steps);
+        DTTS_REQUIRE(replay_.valid && !replaying_, "persistent decode kernel: an activation exchange timed out and the session cannot be replayed; "
+                                                   "set DTTS_GPT_TOKEN_KERNEL=0");
+        GptReplay& r = replay_;
+        dtts_gpt_options o = r.o;
+        o.sample_ids = r.sample_ids.data();
+        o.forced_codes = r.forced_codes.empty() ? nullptr : r.forced_codes.data();
+        o.row_seeds = r.row_seeds.empty() ? nullptr : r.row_seeds.data();
+        replaying_ = true;
+        try {
+            gpt_replay_.reset();
+            const float* refer = gpt_replay_.f32((size_t)r.B * cfg.mel_channels * r.Tr);
+            gpt_prefill(refer, r.has_refer_lens ? r.refer_lens.data() : nullptr, r.Tr, r.text.data(), r.has_text_lens ? r.text_lens.data() : nullptr,
+                        r.Lt_max, r.B, o, r.latents_cm, r.lat_stride, s);
+            for (int i = 1; i < steps; ++i) gpt_step_launches(s);
+            gs_.steps = steps;
+        } catch (...) {
+            replaying_ = false;
+            throw;
+        }
+        replaying_ = false;
+        DTTS_CHECK_HIP(hipMemcpyAsync(hc.data(), gs_.codes, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, s));
+        DTTS_CHECK_HIP(hipMemcpyAsync(&hctl, gs_.ctl, sizeof(GptCtl), hipMemcpyDeviceToHost, s));
+        DTTS_CHECK_HIP(hipStreamSynchronize(s));
     }
     for (int b = 0; b < B; ++b) {
         const int done = std::max(0, std::min(hctl.step[b], G));

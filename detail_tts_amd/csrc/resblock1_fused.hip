@@ -446,13 +446,9 @@ void launch_resblock1x3_fused(const RbFusedParams& p_in, hipStream_t s) {
     auto al16 = [](const void* q, long long bs, int cs) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0 && (bs & 3) == 0 && (cs & 3) == 0; };
     p.vec_ok = (al16(p.x, p.x_bs, p.x_cs) && al16(p.y, p.y_bs, p.y_cs)) ? 1 : 0;
     const int CP = p.C <= 16 ? 16 : 32;
-    static bool attr = false;
     const size_t l16 = sizeof(float) * 2 * 16 * RbfGeo<16>::WP, l32 = sizeof(float) * 2 * 32 * RbfGeo<32>::WP;
-    if (!attr) {
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
-        DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32));
-        attr = true;
-    }
+    if (!p.w3[0]) lds_optin(CP == 16 ? reinterpret_cast<const void*>(resblock1x3_fused_kernel<16>) : reinterpret_cast<const void*>(resblock1x3_fused_kernel<32>),
+                            (int)(CP == 16 ? l16 : l32));
     // FLOPs: 6 convs x (3 + 7 + 11) taps x 2 C^2 per sample (useful channels); bytes: x in + mean out
     int taps = 0;
     for (int j = 0; j < 3; ++j) taps += ((p.branch_mask >> j) & 1) ? p.k[j] : 0;
@@ -460,19 +456,15 @@ void launch_resblock1x3_fused(const RbFusedParams& p_in, hipStream_t s) {
     ProfScope ps("resblock1x3_fused_kernel", 2.0 * 6.0 * taps * p.C * p.C * n, 8.0 * p.C * n, s);
     if (p.w3[0]) {                  // split-precision form (weights pre-split into fragment order)
         for (int q = 0; q < 18; ++q) DTTS_REQUIRE(p.w3[q] && p.b[q], "fused ResBlock1 (split precision): weights / biases");
-        static bool attr3 = false;
-        if (!attr3) {
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<16>::BUF));
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<32>::BUF));
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<16>::BUF));
-            DTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock1x3_fused_x3_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RbxGeo<32>::BUF));
-            attr3 = true;
-        }
         const dim3 g16(cdiv(p.T, RbxGeo<16>::TT), p.B), g32(cdiv(p.T, RbxGeo<32>::TT), p.B);
-        if (CP == 16 && !p.sat) hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<16, false>), g16, dim3(256), 2 * RbxGeo<16>::BUF, s, p);
-        else if (CP == 16) hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<16, true>), g16, dim3(256), 2 * RbxGeo<16>::BUF, s, p);
-        else if (!p.sat) hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<32, false>), g32, dim3(256), 2 * RbxGeo<32>::BUF, s, p);
-        else hipLaunchKernelGGL((resblock1x3_fused_x3_kernel<32, true>), g32, dim3(256), 2 * RbxGeo<32>::BUF, s, p);
+        auto go = [&](auto kern, dim3 g, int lds) {
+            lds_optin(reinterpret_cast<const void*>(kern), lds);
+            hipLaunchKernelGGL(kern, g, dim3(256), lds, s, p);
+        };
+        if (CP == 16 && !p.sat) go(resblock1x3_fused_x3_kernel<16, false>, g16, 2 * RbxGeo<16>::BUF);
+        else if (CP == 16) go(resblock1x3_fused_x3_kernel<16, true>, g16, 2 * RbxGeo<16>::BUF);
+        else if (!p.sat) go(resblock1x3_fused_x3_kernel<32, false>, g32, 2 * RbxGeo<32>::BUF);
+        else go(resblock1x3_fused_x3_kernel<32, true>, g32, 2 * RbxGeo<32>::BUF);
         DTTS_CHECK_HIP(hipGetLastError());
         return;
     }

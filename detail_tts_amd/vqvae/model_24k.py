@@ -218,7 +218,8 @@ class SynthesizerTrn:
         """Batch server: `infer(..., batch=True)` over a sequence of request batches, software-pipelined over three HIP streams.
 
         requests: iterable of dicts with keys text [B,Lt], text_length [B], refer [B,128,Tr], refer_lengths [B] and optionally seed,
-        sample_ids (any B; up to 16 utterances share one decode session; with pair_stage_a two consecutive requests of <= 8 utterances
+        sample_ids, forced_codes (per-row code arrays fed through the KV-cache decode instead of sampling: tests / ragged benchmarks;
+        <= 16 rows) (any B; up to 16 utterances share one decode session; with pair_stage_a two consecutive requests of <= 8 utterances
         are decoded as ONE session - stage A of requests i + 1 and i + 2 together under stage B of requests i - 1 and i).  Yields (wav [B,1,1024*n_max], lengths) per request, in order; every
         result is bit-identical to `infer(**request, batch=True)` with the same seed and sample ids.
 
@@ -250,7 +251,7 @@ class SynthesizerTrn:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             sids = list(range(B)) if req.get("sample_ids") is None else list(req["sample_ids"])
             texts = [text[b, : int(tl[b])].cpu().numpy().astype(np.int32) for b in range(B)]
-            return dict(B=B, rl=rl, seed=seed, sids=sids, texts=texts, refer_in=req["refer"])
+            return dict(B=B, rl=rl, seed=seed, sids=sids, texts=texts, refer_in=req["refer"], forced=req.get("forced_codes"))
 
         def launch_a(group):
             """stage A of one request, or of TWO requests of <= 8 utterances each as ONE decode session (<= 16 rows, per-row Philox
@@ -282,13 +283,17 @@ class SynthesizerTrn:
                             refer[r0:r0 + st["B"], :, : st["refer"].shape[2]] = st["refer"]
                             r0 += st["B"]
                         seeds = [st["seed"] for st in sts for _ in range(st["B"])]
+                    forced = None
+                    if any(st["forced"] is not None for st in sts):
+                        assert all(st["forced"] is not None for st in sts), "forced_codes: all requests of a shared session or none"
+                        forced = [c for st in sts for c in st["forced"]]
                     self.rt.gpt_prefill(refer, [v for st in sts for v in st["rl"]], [t for st in sts for t in st["texts"]], seeds,
-                                        [v for st in sts for v in st["sids"]], **kw)
+                                        [v for st in sts for v in st["sids"]], forced_codes=forced, **kw)
                     if suppress_eos:                           # fixed length: the whole decode is enqueued without a host round trip
                         self.rt.gpt_decode(max_generate_length)
                 else:                                          # more than one decode session: group after group, on this thread / stream
                     st = sts[0]
-                    st["gen"] = self.rt.gpt_generate(st["refer"], st["rl"], st["texts"], st["seed"], st["sids"], **kw)
+                    st["gen"] = self.rt.gpt_generate(st["refer"], st["rl"], st["texts"], st["seed"], st["sids"], forced_codes=st["forced"], **kw)
             if tr:
                 for st in sts:
                     st["tr"]["host_a1"] = time.perf_counter()

@@ -255,8 +255,15 @@ def _rng_for(seed: int, name: str) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=[int(seed) & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
 
 
-def synthetic_state_dict(seed: int = 0, cfg=None, only_prefixes=None) -> "OrderedDict[str, np.ndarray]":
+def synthetic_state_dict(seed: int = 0, cfg=None, only_prefixes=None, variant=None) -> "OrderedDict[str, np.ndarray]":
     """Deterministic random-init weights in *state-dict form* (fp32 numpy).
+
+    ``variant="signal"``: the same draws, rescaled so that the vocoder's output DEPENDS ON ITS INPUT.  With the plain fan-in
+    init every generator conv attenuates its input by ~0.58 (uniform +-1/sqrt(fan_in) has std 1/sqrt(3 fan_in)) while every bias
+    injects +-0.05, so after 7 convs the waveform is 99 % bias (generator(z) - generator(0) is 1e-3 RMS on a 7e-3 RMS output): a
+    waveform comparison under those weights cannot see an error upstream.  The variant multiplies the generator's non-residual
+    gains (conv_pre, cond, ups.*.weight_g, conv_post) by 2.0 and its biases by 0.3 (output RMS 0.2, 6/7 of it driven by z, tanh
+    not saturated) and makes the prior's mean count against its noise (enc_p.proj: m_p rows x 6, logs_p bias - 1.5).
 
     Every tensor is drawn from its own Philox stream keyed by (seed, crc32(name)),
     so a subset (``only_prefixes``) yields the same values as the full set.  Zero-
@@ -301,8 +308,27 @@ def synthetic_state_dict(seed: int = 0, cfg=None, only_prefixes=None) -> "Ordere
             a = r.normal(0.0, 1.0, size=shape)
         else:  # pragma: no cover
             raise ValueError(kind)
+        if variant == "signal":
+            a = _signal_variant(name, a)
+        elif variant is not None:
+            raise ValueError(f"unknown weight variant {variant!r}")
         out[name] = np.ascontiguousarray(a, dtype=np.float32)
     return out
+
+
+def _signal_variant(name, a):
+    if name.startswith("dec."):
+        if name.endswith("bias"):
+            return a * 0.3
+        if name in ("dec.conv_pre.weight", "dec.conv_post.weight", "dec.cond.weight") or (name.startswith("dec.ups.") and name.endswith("weight_g")):
+            return a * 2.0
+    if name == "enc_p.proj.weight":
+        a = a.copy()
+        a[: a.shape[0] // 2] *= 6.0
+    if name == "enc_p.proj.bias":
+        a = a.copy()
+        a[a.shape[0] // 2:] -= 1.5
+    return a
 
 
 def synthetic_tensor(seed, name, spec=None):

@@ -238,7 +238,14 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
  *   "gpt_token_kernel" (default 1): decode sessions of <= 8 rows run a token as ONE persistent kernel (128 resident workgroups that
  *                 exchange activations through memory, csrc/gpt_token.hip) + the sampler; 0 = the chain of 5 launches per layer
- *                 (always used by 9..16-row sessions).  Same fp32 arithmetic, different summation order; env DTTS_GPT_TOKEN_KERNEL=0;
+ *                 (always used by 9..16-row sessions).  Same fp32 arithmetic, different summation order; env DTTS_GPT_TOKEN_KERNEL=0.
+ *                 Bound only when the device can hold its 128 workgroups at once (>= 128 CUs, opt-in LDS); if an exchange of a
+ *                 running session ever times out, dtts_gpt_finish replays that session on the chain (same codes as the chain) and the
+ *                 handle stays on the chain until this option is set to 1 again;
+ *   "gpt_token_exclusive_cu" (default 1): the token kernel asks for a CU's whole LDS, so no LDS-using workgroup shares its CUs;
+ *                 0 = it shares CUs with whatever else runs.  A scheduling policy, not a correctness requirement (both settings are
+ *                 stress-tested bit-identical under stage B / C loads); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
+ *   "gpt_token_fault" (test hook, default 0): n > 0 makes the n-th token-kernel launch from now on behave like an exchange time-out;
  *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
  *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
  *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1;

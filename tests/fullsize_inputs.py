@@ -48,3 +48,25 @@ def e2e_inputs_b(seed=22):
     d["text"] = np.concatenate([rs.randint(3, 255, (1, 40)), [[0]]], 1).astype(np.int32)
     d["codes"] = rs.randint(0, 8192, (1, 150)).astype(np.int64)
     return d
+
+
+def longform_inputs(seed=31):
+    """Inputs of tests/golden/longform.npz (make_golden_r4.py): BASELINE.json configs[4] - one 60 s utterance, T = 5624 mel frames."""
+    rs = np.random.RandomState(seed)
+    d = {"seed_inputs": seed}
+    d["x"] = rs.randn(1, 128, T_LONG).astype(np.float32)
+    d["code_emb"] = (rs.randn(1, 768, T_LONG) * 0.5).astype(np.float32)
+    d["mel"] = (rs.randn(1, 128, T_LONG) * 2 - 5).astype(np.float32)
+    return d
+
+
+def signal_small_inputs(seed=41, T=48):
+    """Inputs of the small vocoder fixture under the "signal" weight variant (tests/golden/signal_weights.npz)."""
+    rs = np.random.RandomState(seed)
+    return {"seed_inputs": seed, "mel": (rs.randn(1, 128, T) * 2 - 5).astype(np.float32)}
+
+
+# waveform subsample of the 60 s fixture: every WAV_STRIDE-th sample + dense windows around the seams of the streamed vocoder
+WAV_STRIDE = 11
+SEAM_FRAMES = 256          # dtts_vocoder_stream chunk_frames of the test
+SEAM_HALF = 1024           # samples kept on each side of a seam

@@ -58,7 +58,9 @@ def install_shim():
     gm.GPT2InferenceModel.__bases__ = (GPT2PreTrainedModel, GenerationMixin)
 
 
-def build_reference_model():
+def build_reference_model(variant=None):
+    """variant: detail_tts_amd.weights.synthetic_state_dict's `variant` (None = the plain seed-0 set, "signal" = the vocoder rescaled so
+    that its output depends on its input)"""
     import torch
     from vqvae.utils.data_utils import HParams
     from vqvae.model_24k import SynthesizerTrn
@@ -68,7 +70,7 @@ def build_reference_model():
     hps = HParams(**cfg)
     torch.manual_seed(0)
     model = SynthesizerTrn(1024 // 2 + 1, 10240 // 256, **hps.vaegan, cfg=hps).eval()
-    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(SEED_W).items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(SEED_W, variant=variant).items()}
     res = model.load_state_dict(sd, strict=False)
     assert not res.unexpected_keys, res.unexpected_keys
     allowed = ("enc_q.", "quantizer.", "vq_enc.", "vq_dec.", "vq_ref_enc.", "gpt.text_head.",

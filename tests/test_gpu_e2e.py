@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from conftest import tol
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -26,8 +28,8 @@ def test_e2e_forced_codes_vs_reference_golden(model, golden):
     wav = wav.cpu().numpy()
     assert wav.shape == g["wav"].shape
     r = rms(wav, g["wav"])
-    assert r < 1e-3, r                       # north_star: <= 1e-3 RMS on the 24 kHz waveform
-    assert float(np.sqrt(np.mean(g["wav"] ** 2))) > 20 * r
+    # north_star: <= 1e-3 RMS on the 24 kHz waveform; the gate is ~20 x the measured error (the seed-0 generator is bias-dominated)
+    tol("e2e_forced_small_wav_rms", r, 1e-7)
 
 
 def test_e2e_free_sampling_batch_vs_oracle(model, weights):
@@ -47,7 +49,7 @@ def test_e2e_free_sampling_batch_vs_oracle(model, weights):
         ref = pipeline.infer_one(weights, texts[b], refer[b, :, :rl[b]], 4321, 70 + b, max_generate_length=5, suppress_eos=True)
         assert lens[b] == ref.shape[0] == 4 * 1024
         r = rms(wav[b, 0, :lens[b]], ref)
-        assert r < 1e-3, (b, r)
+        tol(f"e2e_free_sampling_row{b}_vs_oracle_rms", r, 1e-7)
 
 
 def test_load_model_surface():
@@ -71,7 +73,7 @@ def test_full_size_batch_invariance_and_determinism(model):
     assert torch.equal(wav, wav2)
     alone, _ = model.infer(text[1:2], torch.tensor([61]), refer[1:2], torch.tensor([936]), batch=True, sample_ids=[41], **kw)
     diff = (wav[1] - alone[0]).double()
-    assert float(diff.pow(2).mean().sqrt()) < 1e-5, float(diff.abs().max())
+    tol("full_size_row1_vs_alone_rms", float(diff.pow(2).mean().sqrt()), 1e-7)
     assert float(wav[1].double().pow(2).mean().sqrt()) > 1e-3
 
 
@@ -98,7 +100,7 @@ def test_infer_gpt_forced_codes_vs_reference_golden(model, golden):
     wav = model.infer_gpt(text, torch.tensor([4]), torch.from_numpy(g["refer"]), torch.tensor([g["refer"].shape[2]]),
                           seed=int(g["seed"]), sample_ids=[int(g["sample_id"])], forced_codes=[g["codes"][0]]).cpu().numpy()
     assert wav.shape == g["wav"].shape
-    assert rms(wav, g["wav"]) < 1e-3
+    tol("infer_gpt_forced_wav_rms", rms(wav, g["wav"]), 1e-7)
 
 
 def test_infer_gpt_free_sampling_vs_oracle(model, weights):
@@ -111,7 +113,7 @@ def test_infer_gpt_free_sampling_vs_oracle(model, weights):
     codes = G.generate(weights, refer, np.array([44]), text[None].astype(np.int64), 99, [12], 6, suppress_eos=True)
     ref = vq.infer_gpt_from_codes(weights, codes[0, :-1], refer[0], 99, 12)
     assert wav.shape[2] == ref.shape[0]
-    assert rms(wav[0, 0], ref) < 1e-3
+    tol("infer_gpt_free_vs_oracle_rms", rms(wav[0, 0], ref), 1e-7)
 
 
 def test_wav_in_wav_out_example(tmp_path):
@@ -159,7 +161,7 @@ def test_configs0_bundled_prompt_wav_in_wav_out_vs_oracle(model, weights):
                       suppress_eos=True).cpu().numpy()
     ref = pipeline.infer_one(weights, text[0].numpy(), spec[0].cpu().numpy(), 1234, 0, max_generate_length=7, suppress_eos=True)
     assert wav.shape == (1, 1, 6 * 1024)
-    assert rms(wav[0, 0], ref) < 1e-3
+    tol("configs0_wav_vs_oracle_rms", rms(wav[0, 0], ref), 1e-7)
 
 
 def test_multi_rank_bench_path_on_one_gpu(tmp_path):
@@ -243,7 +245,7 @@ def test_long_form_batch4_streaming_vocoder(model):
     g = torch.from_numpy((rs.randn(1, 768, 1) * 0.1).astype(np.float32)).cuda()
     full = model.dec(z, g=g)
     cat = torch.cat(list(model.dec.stream(z, g, chunk=64)), -1)
-    assert float((cat - full).abs().max()) < 1e-5
+    tol("long_form_streamed_vs_oneshot_maxabs", float((cat - full).abs().max()), 2e-7)
 
 
 @pytest.mark.parametrize("suppress_eos", [True, False])
@@ -273,7 +275,8 @@ def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
     for (w0, l0), (w1, l1) in zip(chain, paired):
         assert l0 == l1 and torch.equal(w0, w1)
     for (w0, l0), (w1, l1) in zip(outs, chain):
-        assert l0 == l1 and float((w0 - w1).pow(2).mean().sqrt()) < 1e-3        # north_star's tolerance (24 kHz waveform RMS)
+        assert l0 == l1
+        tol("infer_stream_token_vs_chain_rms", float((w0 - w1).pow(2).mean().sqrt()), 1e-6)       # latents differ by summation order (2e-6)
     for r, (wav, lens) in zip(reqs, outs):
         ref, rlens = model.infer(r["text"], r["text_length"], r["refer"], r["refer_lengths"], batch=True, seed=r["seed"],
                                  sample_ids=r["sample_ids"], max_generate_length=G, suppress_eos=suppress_eos, return_lengths=True)
@@ -301,48 +304,109 @@ def test_infer_stream_closed_early_leaves_the_handle_usable(model):
     assert torch.equal(again, ref)
 
 
-def test_token_kernel_under_a_concurrent_diffusion_load(model):
-    """Stage A's persistent token kernel runs under the previous request's diffusion in SynthesizerTrn.infer_stream: a decode session
-    repeated while another host thread keeps the diffusion sampler (split-precision convs / attention with LDS-DMA) running on its own
-    stream must give the same codes and latents bit for bit.  (With the token workgroups SHARING CUs with those kernels it did not:
-    csrc/gpt_token.hip, LDS_REQUEST.)"""
-    import threading
-    rt = model.rt
-    rs = np.random.RandomState(10)
-    B, G = 3, 24
+def _token_session(rt, seed=10, B=3, G=24):
+    rs = np.random.RandomState(seed)
     refer = torch.from_numpy((rs.randn(B, 128, 200) * 2 - 5).astype(np.float32)).cuda()
     texts = [np.concatenate([rs.randint(3, 255, 10), [0]]).astype(np.int32) for _ in range(B)]
 
     def gen():
         c, n, l = rt.gpt_generate(refer, None, texts, 5, list(range(B)), max_generate_length=G, suppress_eos=True)
         return c, l.clone()
+    return gen
 
-    c0, l0 = gen()
-    stop = threading.Event()
-    failed = []
 
-    def load():
-        try:
-            torch.cuda.set_device(0)
-            s = torch.cuda.Stream()
-            with torch.cuda.stream(s):
-                r8 = torch.from_numpy((np.random.RandomState(1).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
-                ce = rt.diff_timestep_independent(torch.randn(8, 768, 100, device="cuda"), rt.diff_conditioning(r8))
-                while not stop.is_set():
-                    rt.diff_sample(ce, 3, list(range(8)), n_steps=4)
-                    s.synchronize()
-        except Exception as e:      # pragma: no cover
-            failed.append(e)
+def _load_diffusion(rt):
+    """split-precision convs / attention with LDS-DMA (stage B of the previous request under infer_stream)"""
+    r8 = torch.from_numpy((np.random.RandomState(1).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
+    ce = rt.diff_timestep_independent(torch.randn(8, 768, 100, device="cuda"), rt.diff_conditioning(r8))
+    return lambda: rt.diff_sample(ce, 3, list(range(8)), n_steps=4)
 
-    th = threading.Thread(target=load)
-    th.start()
+
+def _load_vocoder(rt):
+    """conv_x3d + the LDS-resident fused ResBlock1 + fp32-MFMA convs (stage C of request i - 1 also runs under stage A)"""
+    mel = torch.from_numpy((np.random.RandomState(2).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
+    return lambda: rt.vocoder(mel, 3, list(range(8)))
+
+
+def _load_zero_lds(rt):
+    """kernels WITHOUT LDS - they can sit on a token workgroup's CU whatever LDS it asks for: torch elementwise / copy kernels and
+    the Philox generator"""
+    a = torch.randn(64 << 20, device="cuda")
+    b = torch.randn(64 << 20, device="cuda")
+
+    def go():
+        for _ in range(8):
+            a.mul_(1.0000001).add_(b, alpha=1e-9)
+            b.copy_(a)
+            torch.sin(a, out=b)
+            rt.op_philox_normal(1 << 20, 3, list(range(8)), 2, 0)
+    return go
+
+
+@pytest.mark.parametrize("exclusive", [1, 0])
+@pytest.mark.parametrize("load", ["diffusion", "vocoder", "zero_lds"])
+def test_token_kernel_under_concurrent_load(model, load, exclusive):
+    """Stage A's persistent token kernel runs under the previous request's stages B and C in SynthesizerTrn.infer_stream.  200 decode
+    sessions repeated while another host thread keeps that load running on its own stream must give the same codes and latents bit
+    for bit - with the token workgroups on CUs of their own (exclusive = 1) AND sharing CUs with the load (exclusive = 0: the round-3
+    build with packed fp32 math failed exactly this next to the LDS-DMA kernels; csrc/gpt_token.hip "CU sharing")."""
+    import threading
+    import time
+    rt = model.rt
+    gen = _token_session(rt)
+    rt.set_option("gpt_token_exclusive_cu", exclusive)
     try:
-        import time
-        time.sleep(1.0)
-        for _ in range(6):
-            c1, l1 = gen()
-            assert np.array_equal(c0, c1) and torch.equal(l0, l1)
+        c0, l0 = gen()
+        stop = threading.Event()
+        failed = []
+        rounds = [0]
+
+        def run_load():
+            try:
+                torch.cuda.set_device(0)
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    body = {"diffusion": _load_diffusion, "vocoder": _load_vocoder, "zero_lds": _load_zero_lds}[load](rt)
+                    while not stop.is_set():
+                        body()
+                        s.synchronize()
+                        rounds[0] += 1
+            except Exception as e:      # pragma: no cover
+                failed.append(e)
+
+        th = threading.Thread(target=run_load)
+        th.start()
+        try:
+            time.sleep(1.0)
+            bad = 0
+            for _ in range(200):
+                c1, l1 = gen()
+                bad += not (np.array_equal(c0, c1) and torch.equal(l0, l1))
+            assert bad == 0, f"{bad} of 200 sessions differ under the {load} load (exclusive_cu={exclusive})"
+        finally:
+            stop.set()
+            th.join()
+        assert not failed, failed
+        assert rounds[0] >= 2, "the load did not run next to the sessions"
     finally:
-        stop.set()
-        th.join()
-    assert not failed, failed
+        rt.set_option("gpt_token_exclusive_cu", 1)
+
+
+def test_token_kernel_timeout_is_replayed_on_the_chain(model):
+    """An exchange poll that gives up (the kernel's 128 workgroups not co-resident) must not lose the session: dtts_gpt_finish replays it
+    on the launch-per-GEMV chain and the handle stays on the chain.  The test hook raises the error flag before the 7th token launch."""
+    rt = model.rt
+    gen = _token_session(rt, seed=11, B=2, G=20)
+    rt.set_option("gpt_token_kernel", 0)
+    c_chain, l_chain = gen()
+    rt.set_option("gpt_token_kernel", 1)
+    c_tok, l_tok = gen()
+    assert np.array_equal(c_chain, c_tok)
+    rt.set_option("gpt_token_fault", 7)
+    c1, l1 = gen()                                   # 6 good tokens, a dead kernel from the 7th on, then the replay
+    assert np.array_equal(c1, c_chain) and torch.equal(l1, l_chain)
+    c2, l2 = gen()                                   # the handle stays on the chain
+    assert np.array_equal(c2, c_chain) and torch.equal(l2, l_chain)
+    rt.set_option("gpt_token_kernel", 1)             # setting the option again clears the latch
+    c3, l3 = gen()
+    assert np.array_equal(c3, c_tok) and torch.equal(l3, l_tok)

@@ -4,6 +4,7 @@ attention length T = 5624.  Two checkers: `tests/golden/fullsize.npz` = subsampl
 import numpy as np
 import pytest
 
+from conftest import tol
 from fullsize_inputs import N_CODES, T, inputs, sub
 
 pytestmark = pytest.mark.gpu
@@ -116,10 +117,13 @@ def test_vocoder_T936_vs_reference_and_oracle(rt, weights, I, G):
     wav, z = host(wav)[0, 0], host(z)[0]
     check_sub(z, G, "voc_z", 2e-4)
     ref_rms = float(G["voc_wav_rms"])
-    assert rms(wav[::97], G["voc_wav_s"]) < 1e-4 and rms(wav[-2048:], G["voc_wav_t"]) < 1e-4
-    assert ref_rms > 100 * rms(wav[::97], G["voc_wav_s"])
+    # seed-0 weights: the waveform is 7e-3 RMS of which only 1e-3 is driven by z, so the limit sits at ~20 x the measured error
+    # (1e-8 class), not at north_star's 1e-3; the "signal" weight set below makes the same comparison on a waveform that is 6/7 z-driven
+    tol("voc936_wav_sub_rms", rms(wav[::97], G["voc_wav_s"]), 2e-7)
+    tol("voc936_wav_tail_rms", rms(wav[-2048:], G["voc_wav_t"]), 2e-7)
+    assert ref_rms > 1e4 * rms(wav[::97], G["voc_wav_s"])
     ref = V.infer_flowvae(weights, I["mel"], [T], 1234, [3])
-    assert rms(wav, np.asarray(ref).reshape(-1)) < 1e-4
+    tol("voc936_wav_vs_oracle_rms", rms(wav, np.asarray(ref).reshape(-1)), 2e-7)
 
 
 def test_gpt_decode_latents_234_codes_vs_reference(rt, I, G):
@@ -202,7 +206,7 @@ def test_configs2_batch8_full_size_batch_invariance(model):
     for b in (0, 5, 7):
         alone, _ = model.infer(text[b:b + 1], torch.tensor([61]), refer[b:b + 1], torch.tensor([936]), batch=True, sample_ids=[b], **kw)
         d = (wav[b] - alone[0]).double()
-        assert float(d.pow(2).mean().sqrt()) < 1e-5, (b, float(d.abs().max()))
+        tol(f"configs2_row{b}_vs_alone_rms", float(d.pow(2).mean().sqrt()), 1e-7)
         assert float(wav[b].double().pow(2).mean().sqrt()) > 1e-3
 
 
@@ -224,10 +228,10 @@ def test_configs4_long_form_60s_batch4(model):
     ws, _ = model.infer(text, torch.full((B,), 31), refer, torch.full((B,), 300), sample_ids=list(range(B)), forced_codes=codes,
                         stream_vocoder=True, **kw)
     for b in range(B):
-        assert float((ws[b, 0, :lens[b]] - wav[b, 0, :lens[b]]).abs().max()) < 1e-5, b
+        tol(f"configs4_row{b}_streamed_vs_oneshot_maxabs", float((ws[b, 0, :lens[b]] - wav[b, 0, :lens[b]]).abs().max()), 2e-7)
     alone, _ = model.infer(text[3:4], torch.tensor([31]), refer[3:4], torch.tensor([300]), sample_ids=[3], forced_codes=codes[3:4], **kw)
     d = (wav[3, 0, :lens[3]] - alone[0, 0]).double()
-    assert float(d.pow(2).mean().sqrt()) < 1e-5
+    tol("configs4_row3_vs_alone_rms", float(d.pow(2).mean().sqrt()), 1e-7)
 
 
 # ------------------------------------------------------------------------------------------------ device sampler
@@ -341,8 +345,9 @@ def test_e2e_234_codes_B1_vs_reference_waveform(synth, E, EI, x3):
     assert w.shape == E["wav"].shape
     r = rms(w, E["wav"])
     print(f"\n[e2e 234 codes, B=1, conv_x3={x3}] waveform RMS error {r:.3e} (reference RMS {float(E['wav_rms']):.3e}), max-abs {maxabs(w, E['wav']):.3e}")
-    assert r < 1e-3, r
-    assert float(E["wav_rms"]) > 20 * r            # and small against the signal itself, not only in absolute terms
+    # north_star asks for 1e-3 RMS; with the seed-0 weights generator(z = 0) alone is within 1.04e-3 of the reference, so that limit
+    # would prove nothing: the gate sits at ~20 x the measured error (4.3e-9), 4 orders below the z-driven part of the signal
+    tol(f"e2e_B1_wav_rms_x3={x3}", r, 1e-7)
 
 
 @pytest.mark.parametrize("x3", [1, 0])
@@ -361,8 +366,7 @@ def test_e2e_234_codes_row5_of_ragged_B8_vs_reference_waveform(synth, E, EI, x3)
     w = host(wav)[5, 0, : lens[5]]
     r = rms(w, E["wav"])
     print(f"\n[e2e 234 codes, row 5 of ragged B=8, conv_x3={x3}] waveform RMS error {r:.3e}, max-abs {maxabs(w, E['wav']):.3e}")
-    assert r < 1e-3, r
-    assert float(E["wav_rms"]) > 20 * r
+    tol(f"e2e_row5_of_B8_wav_rms_x3={x3}", r, 1e-7)
 
 
 def test_e2e_two_rows_of_a_ragged_B8_batch_both_vs_reference_waveforms(synth, E, EI, golden):
@@ -389,7 +393,7 @@ def test_e2e_two_rows_of_a_ragged_B8_batch_both_vs_reference_waveforms(synth, E,
         w = host(wav)[row, 0, : lens[row]]
         r = rms(w, ref["wav"])
         print(f"\n[ragged B=8, row {row}: {lens[row] // 1024} codes] waveform RMS error {r:.3e} (reference RMS {float(ref['wav_rms']):.3e})")
-        assert r < 1e-3 and float(ref["wav_rms"]) > 20 * r, (row, r)
+        tol(f"e2e_two_rows_row{row}_wav_rms", r, 1e-7)
         assert np.all(host(wav)[row, 0, lens[row]:] == 0)
 
 
@@ -416,8 +420,9 @@ def test_e2e_sampler_drift_along_the_50_step_chain(synth, E, EI, x3):
         rt.set_option("conv_x3", 1)
     print(f"\n[sampler drift, conv_x3={x3}] max-abs vs the reference after step 49/40/25/0 and on the de-normalised mel: " +
           ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
-    assert errs[49] < 2e-4 and errs[40] < 1e-3 and errs[25] < 2e-3 and errs[0] < 2e-3, errs
-    assert errs["mel"] < 2e-2, errs            # de-normalisation scales by (2.7 + 11.51) / 2 = 7.1
+    # limits ~ 20 x the measured drift (r03: 7e-7 / 1.2e-6 / 4.5e-6 / 1.4e-5, mel 1.0e-4 split precision, 1.6e-4 exact fp32)
+    for k, lim in ((49, 2e-5), (40, 4e-5), (25, 1e-4), (0, 2e-4), ("mel", 2e-3)):        # de-normalisation scales by (2.7 + 11.51) / 2 = 7.1
+        tol(f"drift_x3={x3}_{k}", errs[k], lim)
 
 
 def test_free_sampling_234_tokens_vs_reference_hf_loop(golden, EI, weights):

@@ -326,3 +326,28 @@ def test_configs0_cpu_plumbing_on_bundled_prompt(weights):
     assert len(ids) == 38
     wav = pipeline.infer_one(weights, text, mel, 1234, 0, max_generate_length=4, suppress_eos=True, diffusion_steps=2)
     assert wav.shape == (3 * 1024,) and np.isfinite(wav).all() and float(np.abs(wav).max()) > 1e-4
+
+
+def test_token_kernel_object_has_no_packed_fp32_math():
+    """csrc/gpt_token.hip is built with -fno-slp-vectorize (build.py reads its `// hipcc-flags:` line): with packed fp32 math its
+    results were wrong when its workgroups shared CUs with the split-precision kernels (DESIGN.md par. 4).  The gfx950 code object of the
+    built library must not contain a packed fp32 instruction in gpt_token_kernel."""
+    import shutil
+    import subprocess
+    from detail_tts_amd import build as B
+    assert "-fno-slp-vectorize" in B._extra_flags("gpt_token.hip")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(B.OBJ, "gpt_token.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("no object file / llvm-objdump here (the build directory does not travel)")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        o2 = os.path.join(td, "gpt_token.o")
+        shutil.copy(obj, o2)
+        subprocess.run([objdump, "--offloading", o2], check=True, capture_output=True, cwd=td)
+        dev = [f for f in os.listdir(td) if "gfx950" in f]
+        assert dev, os.listdir(td)
+        asm = subprocess.run([objdump, "-d", os.path.join(td, dev[0])], check=True, capture_output=True, text=True).stdout
+    assert "gpt_token_kernel" in asm and "v_fma_f32" in asm
+    packed = [l for l in asm.splitlines() if "v_pk_fma_f32" in l or "v_pk_mul_f32" in l or "v_pk_add_f32" in l]
+    assert not packed, packed[:5]

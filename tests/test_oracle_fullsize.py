@@ -72,3 +72,19 @@ def test_oracle_free_sampling_234_tokens_vs_reference_hf_loop(weights, golden):
     if not np.array_equal(got, ref):
         k = int(np.nonzero(got != ref)[0][0])
         assert float(g["f64_margins"][k]) < 1e-6, (k, got[k], ref[k], float(g["f64_margins"][k]))
+
+
+def test_oracle_vocoder_under_the_signal_weight_set_vs_reference(golden):
+    """signal_weights.npz: the reference's infer_flowvae under synthetic_state_dict(0, variant="signal") - the weight set whose waveform
+    is driven by z, not by the generator's biases.  Pins the oracle's vocoder on a signal where an error would show (relative RMS)."""
+    from detail_tts_amd.weights import select_inference_params, synthetic_state_dict
+    from fullsize_inputs import signal_small_inputs
+    g, I = golden("signal_weights"), signal_small_inputs()
+    P = select_inference_params(synthetic_state_dict(0, variant="signal"))
+    rms = lambda a: float(np.sqrt(np.mean(np.asarray(a, np.float64) ** 2)))
+    assert rms(g["wav"] - g["wav_z0"]) > 0.5 * rms(g["wav"]) > 0.05
+    tr = {}
+    wav = V.infer_flowvae(P, I["mel"], [I["mel"].shape[2]], int(g["seed"]), [int(g["sample_id"])], trace=tr)
+    assert maxabs(tr["m_p"], g["m_p"]) < 5e-5 and maxabs(tr["logs_p"], g["logs_p"]) < 5e-5 and maxabs(tr["z"], g["z"]) < 1e-4
+    assert rms(np.asarray(wav) - g["wav"]) < 2e-5 * rms(g["wav"])
+    assert rms(np.asarray(V.generator(P, np.zeros_like(tr["z"]), tr["g"])) - g["wav_z0"]) < 2e-5 * rms(g["wav_z0"])
