@@ -88,4 +88,19 @@ __device__ __forceinline__ int xcd_remap(int i, int nblk) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
+// sums of 8 values per lane over the wave in 10 shuffles (halving exchange): every lane gets the total of value (lane >> 3) & 7
+__device__ __forceinline__ float wave_sum8(const float (&s)[8], int lane) {
+    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+    float t[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (h32 ? s[4 + i] : s[i]) + __shfl_xor(h32 ? s[i] : s[4 + i], 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (h16 ? t[2 + i] : t[i]) + __shfl_xor(h16 ? t[i] : t[2 + i], 16);
+    float w = (h8 ? u[1] : u[0]) + __shfl_xor(h8 ? u[0] : u[1], 8);
+    w += __shfl_xor(w, 4);
+    w += __shfl_xor(w, 2);
+    w += __shfl_xor(w, 1);
+    return w;
+}
+
 }  // namespace dtts

@@ -61,6 +61,19 @@ struct ConvParams {
     // conv_x3 only, filled by its launcher: split-K for launches far smaller than the chip (batch 1).  The channel blocks are divided
     // among `ksplit` workgroups per output tile; each leaves its raw accumulators in `kpart`, the last to arrive (counter in `kcount`)
     // sums them in split order - deterministic - and runs the epilogue.
+    // conv_x3 only: the GroupNorm that FOLLOWS this conv folded into its epilogue (conv_x3.h "fused GroupNorm"): the tile publishes
+    // partial statistics of its output, waits for the partials of the groups its rows belong to, applies GN (x AdaGN (1 + scale) + shift),
+    // the activation and the fp16 split in registers and writes the consumer's operand planes.  y may then be null (no fp32 output).
+    void* gn_out3 = nullptr;           // planes of the normalised output [B][Cout/8][2][x3_tp][8 fp16]; null = no fused norm
+    const float *gn_gamma = nullptr, *gn_beta = nullptr;
+    const float* gn_ada = nullptr;     // AdaGN table: scale = 1 + ada[c * stride + off], shift = ada[(Cout + c) * stride + off]
+    int gn_ada_stride = 0;
+    const int* gn_ada_idx = nullptr;   // [B] per-sample offset `off` into the table (null: 0)
+    int gn_act = ACT_NONE, gn_groups = 32;
+    float gn_eps = 1e-5f;
+    void* gn_xch = nullptr;            // exchange words (conv_x3_gn_xch_bytes), one buffer per launch stream
+    unsigned gn_tag = 0;               // != 0, unique per launch on this buffer
+    int* gn_err = nullptr;             // raised (system scope) when a poll gives up
     int ksplit = 1;
     int epi_vec = 0;               // conv_x3: y / res rows are 16-byte aligned -> LDS-staged epilogue with 16-byte stores (set by the launcher)
     float* kpart = nullptr;

@@ -35,6 +35,21 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
 // uses p.w3 / p.x3 / p.x3_tp (+ the epilogue fields of ConvParams); stride 1, dilation 1, pad <= X3_HALO, no gate / phases / badd
 void launch_conv_x3(const ConvParams& p, hipStream_t s);
 
+// ---- fused GroupNorm (p.gn_out3): the norm + activation + split that FOLLOWS a trunk conv runs in that conv's epilogue.  A tile holds
+// 128 rows x 192 columns of one sample; a GroupNorm group is 24 channels x all T columns, so a tile needs the statistics of the <= 7
+// groups its rows touch over ALL N tiles (and, for the groups that straddle its row range, of the neighbouring M tile).  Every wave
+// publishes {mean, M2, count, tag} of its 8 row chunks x 96 columns as 16-byte words (agent scope, the token kernel's protocol), a
+// tile polls the words of its groups, combines them in a fixed order (Chan's parallel variance: deterministic, no cancellation) and
+// normalises its accumulators where they sit.  Tiles of a fused launch are ordered (sample, M tile, N tile): a tile waits only for
+// tiles at most 2 N - 1 positions ahead of it in dispatch order, so at most that many workgroups per XCD can ever be waiting for an
+// undispatched one - with N <= GN_FUSE_MAX_NT that is far below the workgroup slots of an XCD even with a second fused launch on
+// another stream and the persistent GPT token kernel holding CUs.  Longer sequences and split-K launches keep the
+// separate gn_split_planes pass.
+constexpr int GN_FUSE_MAX_NT = 6;
+size_t conv_x3_gn_xch_bytes(int B, int Cout, int T);
+// whether launch_conv_x3 can run p with the fused norm (else: conv to p.y, then launch_gn_split_planes)
+bool conv_x3_gn_fusable(int Cout, int CoutP, int Cin, int KW, int groups, int B, int T);
+
 // ---- dilated / wide-kernel variant (conv_x3d.hip): HiFiGAN ResBlock1 convs, k = 3 / 7 / 11, any dilation with (k - 1) dil <= 64
 constexpr int X3D_HALO = 32;                          // left zero columns of its planes (>= the largest pad: (11 * 5 - 5) / 2 = 25)
 static inline int x3d_tp(int T) { return round_up(T, X3_BN) + 64 + X3D_HALO; }

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <mutex>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "conv_x3.h"
@@ -25,6 +27,12 @@ constexpr int BM = 128, BN = X3_BN;
 constexpr int WTILE = NK * BM * 16;                  // 8 KiB: [kind][128 rows][16 B]
 constexpr int XMAIN = NK * BN * 16;                  // 12 KiB: [kind][192 columns][16 B]
 constexpr int XBUF = XMAIN + NK * 2 * 16;            // + 2 halo columns per kind
+// fused GroupNorm epilogue (EPI 3): exchange words are 16-byte {mean, M2, count, tag}, agent-scope (sc1) raw-buffer accesses
+typedef unsigned gn_u4 __attribute__((ext_vector_type(4)));
+constexpr int GN_AUX_SC1 = 16;                       // gfx940+ cache policy bit 4 = sc1
+constexpr int GN_MAXW = 8;                           // (unused words area kept small)
+constexpr int GN_SPIN_LIMIT = 1 << 22;
+static_assert(7 * 32 <= 256 && 3 * GN_FUSE_MAX_NT <= 32 && (4 * 16 * 104 + 4 * GN_MAXW + 16 + 2 * BM) * 4 <= 2 * (WTILE + XBUF), "fused GroupNorm epilogue: LDS / lanes");
 
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ wp, int C8, int CoutP, uint4* __restrict__ out) {
     const int m = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, tap = blockIdx.z;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(1024) void gn_split_planes_reg_kernel(const float* 
 // Every wave issues the SAME number of LDS-DMA instructions per step (5 for k = 1; 3, + 1 halo at the last tap, for k = 3), so the
 // counted wait is one immediate for all waves; VMEM loads complete in order.
 template <int EPI, bool KW3, int NSTG>
-__global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_kernel(ConvParams p) {
     constexpr int KW = KW3 ? 3 : 1, D = NSTG - 1;       // D: prefetch distance in steps (W, X of k = 1) / channel blocks (X of k = 3)
     constexpr int XOFF = NSTG * WTILE;                  // LDS: W stages | X buffers | bias
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -271,9 +279,12 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     const int mtiles = p.CoutP / BM, ntiles = (p.Nout + BN - 1) / BN;
     const int Ls = xcd_remap(blockIdx.x, gridDim.x);
     const int S = p.ksplit, L = Ls / S, z = Ls - L * S;                  // the splits of a tile are adjacent logical ids (one XCD)
-    const int mt = L % mtiles, nb = L / mtiles;
-    const int b = nb / ntiles;
-    const int m0 = mt * BM, n0 = (nb - b * ntiles) * BN;
+    // EPI 3 (fused GroupNorm): (sample, M tile, N tile) order - a tile waits for statistics of tiles at most 2 N - 1 ids ahead (conv_x3.h)
+    const bool mt_major = EPI == 3 && !(p.ablate & 16);
+    const int mt = mt_major ? (L / ntiles) % mtiles : L % mtiles;
+    const int b = mt_major ? L / (ntiles * mtiles) : (L / mtiles) / ntiles;
+    const int nti = mt_major ? L % ntiles : (L / mtiles) - b * ntiles;
+    const int m0 = mt * BM, n0 = nti * BN;
     const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
     if (n0 >= nvalid) return;
     const int C8 = p.Cin >> 3, call = p.Cin >> 4, Tp = p.x3_tp;
@@ -365,6 +376,22 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     // the tile's 128 bias values -> LDS (read back in the epilogue; the first K-step barrier orders the write)
     float* bias_s = reinterpret_cast<float*>(smem + XOFF + NSTG * XBUF);
     if (tid < BM) bias_s[tid] = (p.bias && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.f;
+    // fused GroupNorm: the norm's per-row affine with the AdaGN (1 + scale, shift) folded in -> LDS now, so that the kernel's tail has
+    // no global round trip left but the statistics exchange itself:  y_hat = (y - mu) rstd ga + gb
+    float* ga_s = bias_s + BM + 4;
+    float* gb_s = ga_s + BM;
+    if (EPI == 3 && tid < BM) {
+        const int c = m0 + tid;
+        float ga = p.gn_gamma[c], gb = p.gn_beta[c];
+        if (p.gn_ada) {
+            const float* ad = p.gn_ada + (p.gn_ada_idx ? (long long)p.gn_ada_idx[b] : 0);
+            const float sc = 1.f + ad[(long long)c * p.gn_ada_stride], sh = ad[(long long)(p.Cout + c) * p.gn_ada_stride];
+            ga *= sc;
+            gb = gb * sc + sh;
+        }
+        ga_s[tid] = ga;
+        gb_s[tid] = gb;
+    }
 
     int c16 = 0, tap = 0;                               // the step being computed
     int sw = 0, sx = 0;                                 // its W stage / X buffer; the step being issued uses (sw + D) % NSTG, (sx + D) % NSTG
@@ -408,16 +435,77 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
     constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // term-major: one cross product over the wave's 6 accumulators per group, smallest terms first
     {
     hf8 a[2][NPL], bb[3][NPL];
-    for (int ks = 0; ks < nks; ++ks) {
+    int ks = 0;
+    // ---- main part, unrolled over one PERIOD of the (W stage, X buffer, tap) cycle: NSTG steps for k = 1, 3 NSTG for k = 3.  Inside it
+    // every stage index, tap, LDS offset and the form of the pointer advance is a compile-time constant and every piece is live, so
+    // a K-step carries its 18 MFMAs, 10 fragment reads, 5 pieces and a handful of scalar pointer adds - no stage / tap / liveness
+    // bookkeeping (round 3: 3.7 scalar instructions per MFMA, and with one wave per SIMD the wave's own issue slots between two MFMAs
+    // are what the K-step runs out of).  The generic loop below finishes the last < PERIOD + D steps (and runs everything when
+    // DTTS_CONV_UNROLL=0: p.ablate bit 9).
+    constexpr int PERIOD = KW * NSTG;
+    auto ustep = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;                        // step index inside the period
+        constexpr int TAPc = k % KW, SWc = k % NSTG, SXc = (k / KW) % NSTG;
+        constexpr int SWI = (SWc + D) % NSTG, SXI = (SXc + D) % NSTG;
+        if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(a, bb, SWc, SXc, TAPc);
+        int slot = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
+                if (slot < 5) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot < 2) issue_w(slot, SWI);
+                    else if (!KW3) issue_x1(slot - 2, SXI);
+                    else if (slot == 2) issue_x3(TAPc, SXI);
+                    else if (slot == 3 && TAPc == 2) issue_halo(SXI);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ++slot;
+            }
+        // pointers of the step issued next: W one tap / one channel block further (the tap being ISSUED is (TAPc + D) % KW), X per block
+        if (!KW3) {
+            wq += wblkB;
+            xq += xblkB;
+        } else {
+            if ((TAPc + D) % KW < 2) wq += wtapB;
+            else wq += wblkB - 2 * wtapB;
+            if (TAPc == KW - 1) xblk += xblkB;
+        }
+    };
+    auto uperiod = [&](auto... kc) { (ustep(kc), ...); };
+    // measured at the bench's 240-tile launches (tools/bench_forward.py): k = 3 89.9 -> 80.8 us (- 10 %), qkv conv 84.5 -> 82.9, the 1 x 1
+    // convs of the ResBlock / proj 38.2 -> 39.1 (+ 2 %: they keep the generic loop)
+    constexpr bool UNROLL = KW3 || EPI == 2;
+    if (UNROLL && !(p.ablate & 512)) {
+        // whole periods while every step of the period (and the D steps it issues ahead) lies inside the loop
+        // (k = 3: the X block of channel block c16 + D is issued piece by piece over c16's three taps, so c16 + D must exist too)
+        const int nper = KW3 ? (c16n - D) / NSTG : (nks - D) / PERIOD;
+        for (int q = 0; q < nper; ++q) {
+            if constexpr (PERIOD == 2) uperiod(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            else if constexpr (PERIOD == 3) uperiod(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            else if constexpr (PERIOD == 4) uperiod(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+            else if constexpr (PERIOD == 6) uperiod(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+            else if constexpr (PERIOD == 9) uperiod(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{});
+            else uperiod(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{});
+        }
+        // hand over to the generic loop: a whole number of periods leaves stage, buffer and tap where they started
+        ks = nper * PERIOD;
+        c16 = ks / KW;
+        itap = D % KW;
+    }
+    for (; ks < nks; ++ks) {
         // Data of this step was issued D steps (blocks) ago; the loads of the D - 1 steps issued since may stay in flight.  The
         // barrier also orders the previous step's ds_reads of the stage / buffer refilled next (WAR).
         // counted wait only while every one of the last D - 1 iterations issued its full set (2 W + 1 X for k = 3, 2 + 3 for k = 1)
         if (NSTG == 2 || ks + D > nks || (KW3 && c16 + D >= c16n)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
         __builtin_amdgcn_s_barrier();
-        // (reading the NEXT step's fragments into a second register set under the last MFMA triples - the barrier moved inside the
-        // step - measured 38.6 -> 37.8 us for k = 1 and 107 -> 118 us for k = 3 at 240 tiles: the LDS port, not the read latency, is
-        // what the fragment reads cost; not kept)
         read_frags(a, bb, sw, sx, tap);
         // ONE LDS-DMA piece after every three MFMAs (as a burst the pieces of a CU's waves queue on the texture-address path while
         // every MFMA pipe idles and the co-resident workgroups fall into lock-step)
@@ -474,6 +562,244 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 3 : 2) void conv_x3_kernel(ConvPar
                     for (int r = 0; r < 16; ++r)
                         acc[i][j][r] += __hip_atomic_load(src + ((i * 3 + j) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+
+    if (EPI == 3) {
+        // ---- fused GroupNorm epilogue (conv_x3.h).  Phases: (1) y = acc * s + bias (+ residual, transposed through the LDS so that its
+        // rows arrive 16 B per lane); (2) two-pass statistics of the wave's 8 row chunks x 96 columns -> published as tagged words;
+        // (3) the fp32 rows of y, if anybody needs them (16-byte stores through the LDS) - issued BEFORE the poll so that the neighbours'
+        // latency is spent on useful stores; (4) poll the words of the tile's groups, combine, per-row coefficients; (5) normalise,
+        // activate, split and store the planes from the registers (a lane pair exchanges half chunks: v_permlane32_swap).
+        constexpr int EP_LD = 104;
+        if (p.ablate & 64) return;
+        __syncthreads();                                               // every wave has left the K loop: its LDS stages are free
+        float* st = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);
+        float* prt = reinterpret_cast<float*>(smem) + 4 * 16 * EP_LD;   // [word][4]: mean, M2, count of one (chunk, N tile, column half)
+        float* gst = prt + 4 * GN_MAXW;                                 // [8 groups][2]: mean, rstd
+        float* sa = gst + 16;                                           // [128 rows]: y -> a y + d
+        float* sd = sa + BM;
+        const int ncol0 = n0 + wn0;
+        const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
+        // every residual load of the tile is in flight before the first one is used: one memory latency instead of four
+        float4 rv[4][6];
+        if (rb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + wm0 + (q >> 1) * 32 + (q & 1) * 16 + rl, n = ncol0 + c4 * 4;
+                    const float* src = rb + (long long)row * p.res_cs + n;
+                    rv[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n + 3 < nvalid) rv[q][k] = *reinterpret_cast<const float4*>(src);
+                    else if (n < nvalid) {
+                        rv[q][k].x = src[0];
+                        if (n + 1 < nvalid) rv[q][k].y = src[1];
+                        if (n + 2 < nvalid) rv[q][k].z = src[2];
+                    }
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = q >> 1, rowt0 = wm0 + i * 32 + (q & 1) * 16;
+            if (rb) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24;
+                    *reinterpret_cast<float4*>(st + rl * EP_LD + c4 * 4) = rv[q][k];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = (q & 1) * 8 + rr, rl = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
+                    float v = acc[i][j][r] * XS_ACC_SCALE + bias_s[rowt0 + rl];
+                    if (rb) v += p.res_scale * st[rl * EP_LD + j * 32 + l31];
+                    acc[i][j][r] = v;
+                }
+            if (rb) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- (2) statistics of chunk ck = i * 4 + (r >> 2) (8 rows x this wave's valid columns), two passes in registers
+        bool okj[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) okj[j] = ncol0 + j * 32 + l31 < nvalid;
+        const int nvh = min(max(nvalid - ncol0, 0), 96);
+        const float cnt = 8.f * (float)nvh, rcnt = nvh > 0 ? 1.f / cnt : 0.f;
+        float s8[8];
+#pragma unroll
+        for (int ck = 0; ck < 8; ++ck) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += okj[j] ? acc[ck >> 2][j][4 * (ck & 3) + e] : 0.f;
+            s8[ck] = a;
+        }
+        const float tot = wave_sum8(s8, lane);
+#pragma unroll
+        for (int ck = 0; ck < 8; ++ck) {
+            const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 8 * ck)) * rcnt;
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dv = acc[ck >> 2][j][4 * (ck & 3) + e] - mu;
+                    a += okj[j] ? dv * dv : 0.f;
+                }
+            s8[ck] = a;
+        }
+        const float m2 = wave_sum8(s8, lane);
+        const int C8o = p.Cout >> 3, NTs = ntiles;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(p.gn_xch, (short)0, (int)((size_t)p.B * C8o * NTs * 2 * 16), 0x00020000);
+        if ((lane & 7) == 0) {
+            const int chunk = ((m0 + wm0) >> 3) + (lane >> 3);
+            const gn_u4 wv = {__float_as_uint(tot * rcnt), __float_as_uint(m2), __float_as_uint(cnt), p.gn_tag};
+            __builtin_amdgcn_raw_buffer_store_b128(wv, xrs, (((b * C8o + chunk) * NTs + nti) * 2 + (wave & 1)) * 16, 0, GN_AUX_SC1);
+        }
+        // ---- (3) fp32 rows of y (residual stream), 16 bytes per lane through the LDS
+        if (p.y) {
+            float* yb = p.y + (long long)b * p.y_bs;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = q >> 1, rowt0 = wm0 + i * 32 + (q & 1) * 16;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = (q & 1) * 8 + rr, rl = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
+                        st[rl * EP_LD + j * 32 + l31] = acc[i][j][r];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + rowt0 + rl, n = ncol0 + c4 * 4;
+                    const float4 a4 = *reinterpret_cast<const float4*>(st + rl * EP_LD + c4 * 4);
+                    if (n < nvalid) {
+                        float* dst = yb + (long long)row * p.y_cs + n;
+                        if (n + 3 < nvalid) *reinterpret_cast<float4*>(dst) = a4;
+                        else {
+                            dst[0] = a4.x;
+                            if (n + 1 < nvalid) dst[1] = a4.y;
+                            if (n + 2 < nvalid) dst[2] = a4.z;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (p.ablate & 128) return;
+        // ---- (4) the statistics of the groups this tile's rows belong to.  Thread (group slot, k): k = (chunk of the group, valid N
+        // tile) polls the TWO column-half words of that (chunk, N tile) and combines them; a group's 3 x nvt pairs sit in one 16- or
+        // 32-lane segment of a wave and are combined there with xor shuffles (Chan's parallel variance, fixed order: deterministic)
+        const int cpg8 = (p.Cout / p.gn_groups) >> 3;                                  // chunks per group (3)
+        const int ct0 = m0 >> 3, g_lo = ct0 / cpg8, g_hi = (ct0 + BM / 8 - 1) / cpg8;
+        const int nvt = (nvalid + BN - 1) / BN, ppg = cpg8 * nvt;                      // valid N tiles; pairs per group (<= 18)
+        const int SL = ppg <= 16 ? 16 : 32;
+        {
+            const int gs = tid / SL, k = tid - gs * SL;
+            const bool active = gs <= g_hi - g_lo && k < ppg;
+            float pn = 0.f, pm = 0.f, pq = 0.f;
+            if (active) {
+                const int ch = k / nvt, nt = k - ch * nvt;
+                const int off = (((b * C8o + (g_lo + gs) * cpg8 + ch) * NTs + nt) * 2) * 16;
+                gn_u4 v0, v1;
+                int spins = 0;
+                for (;;) {
+                    v0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, GN_AUX_SC1);
+                    v1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16, 0, GN_AUX_SC1);
+                    if ((v0.w == p.gn_tag && v1.w == p.gn_tag) || (p.ablate & 8)) break;
+                    if (++spins > GN_SPIN_LIMIT) {
+                        __hip_atomic_store(p.gn_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const float m0v = __uint_as_float(v0.x), q0v = __uint_as_float(v0.y), n0v = __uint_as_float(v0.z);
+                const float m1v = __uint_as_float(v1.x), q1v = __uint_as_float(v1.y), n1v = __uint_as_float(v1.z);
+                pn = n0v + n1v;
+                const float rn = pn > 0.f ? 1.f / pn : 0.f, dm = m0v - m1v;
+                pm = (n0v * m0v + n1v * m1v) * rn;
+                pq = q0v + q1v + n0v * n1v * rn * dm * dm;
+            }
+            float N = pn, S = pn * pm;
+            for (int o = 1; o < SL; o <<= 1) {
+                N += __shfl_xor(N, o);
+                S += __shfl_xor(S, o);
+            }
+            const float mu = N > 0.f ? S / N : 0.f, dmu = pm - mu;
+            float M2 = pq + pn * dmu * dmu;
+            for (int o = 1; o < SL; o <<= 1) M2 += __shfl_xor(M2, o);
+            if (active && k == 0) {
+                gst[2 * gs] = mu;
+                gst[2 * gs + 1] = rsqrtf((N > 0.f ? M2 / N : 0.f) + p.gn_eps);
+            }
+        }
+        __syncthreads();
+        if (tid < BM) {                                                                // y_hat = a y + d per row
+            const int g = (m0 + tid) / (p.Cout / p.gn_groups) - g_lo;
+            const float a = gst[2 * g + 1] * ga_s[tid];
+            sa[tid] = a;
+            sd[tid] = gb_s[tid] - gst[2 * g] * a;
+        }
+        __syncthreads();
+        if (p.ablate & 256) return;
+        // ---- (5) normalise + activation + split -> the consumer's planes.  Columns of the tile beyond the sample's length are
+        // written as zeros (a k = 3 consumer reads one column past the end), and so are the halo columns next to the valid range.
+        const int Tp = p.x3_tp;
+        unsigned char* ob = static_cast<unsigned char*>(p.gn_out3) + (size_t)b * C8o * NPL * Tp * 16;
+        const bool silu = p.gn_act == ACT_SILU;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int n = ncol0 + j * 32 + l31;
+                const bool ok = n < nvalid;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int r16 = wm0 + i * 32 + 16 * k2;
+                    float ve[4], vo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ra = r16 + e + 4 * lhi, rb2 = ra + 8;
+                        float x0 = acc[i][j][8 * k2 + e] * sa[ra] + sd[ra], x1 = acc[i][j][8 * k2 + 4 + e] * sa[rb2] + sd[rb2];
+                        if (silu) {
+                            x0 = x0 * __frcp_rn(1.f + __expf(-x0));
+                            x1 = x1 * __frcp_rn(1.f + __expf(-x1));
+                        }
+                        ve[e] = ok ? x0 * XS_SCALE_X : 0.f;
+                        vo[e] = ok ? x1 * XS_SCALE_X : 0.f;
+                    }
+                    unsigned we0[2], we1[2], wo0[2], wo1[2];
+                    split_pair(ve[0], ve[1], we0[0], we1[0]);
+                    split_pair(ve[2], ve[3], we0[1], we1[1]);
+                    split_pair(vo[0], vo[1], wo0[0], wo1[0]);
+                    split_pair(vo[2], vo[3], wo0[1], wo1[1]);
+                    const auto s00 = __builtin_amdgcn_permlane32_swap(we0[0], wo0[0], false, false);
+                    const auto s01 = __builtin_amdgcn_permlane32_swap(we0[1], wo0[1], false, false);
+                    const auto s10 = __builtin_amdgcn_permlane32_swap(we1[0], wo1[0], false, false);
+                    const auto s11 = __builtin_amdgcn_permlane32_swap(we1[1], wo1[1], false, false);
+                    const int c8 = ((m0 + r16) >> 3) + lhi;
+                    unsigned char* o = ob + ((size_t)c8 * NPL * Tp + n + X3_HALO) * 16;
+                    if (p.ablate & 32) continue;
+                    *reinterpret_cast<uint4*>(o) = make_uint4(s00[0], s01[0], s00[1], s01[1]);
+                    *reinterpret_cast<uint4*>(o + (size_t)Tp * 16) = make_uint4(s10[0], s11[0], s10[1], s11[1]);
+                }
+            }
+        if (tid < 64) {                                                                // halo columns: 16 chunks x 2 planes each
+            const int side = tid >> 5, c8 = (m0 >> 3) + ((tid & 31) >> 1), pl = tid & 1;
+            const int tp = side == 0 ? 0 : n0 + BN + X3_HALO;
+            if (side == 0 ? n0 == 0 : (n0 + BN >= nvalid && tp < Tp))
+                *reinterpret_cast<uint4*>(ob + ((size_t)(c8 * NPL + pl) * Tp + tp) * 16) = make_uint4(0, 0, 0, 0);
+        }
+        return;
     }
 
     if (EPI != 2 && p.epi_vec) {
@@ -783,9 +1109,33 @@ KSplitWs ksplit_workspace(hipStream_t s, size_t nslabs) {
 }
 }  // namespace
 
+size_t conv_x3_gn_xch_bytes(int B, int Cout, int T) { return (size_t)B * (Cout / 8) * cdiv(T, BN) * 2 * 16; }
+
+static long long split_tiles_max() {
+    static const long long v = []() { const char* e = getenv("DTTS_CONV_KSPLIT_MAXTILE"); return e ? atoll(e) : 128LL; }();
+    return v;
+}
+
+bool conv_x3_gn_fusable(int Cout, int CoutP, int Cin, int KW, int groups, int B, int T) {
+    if (Cout != CoutP || Cout % BM || groups <= 0 || Cout % groups || Cout / groups != 24 || Cin % 16 || (KW != 1 && KW != 3)) return false;
+    const int nt = cdiv(T, BN);
+    // split-K launches (<= 128 tiles: batch 1) and long sequences keep the separate pass (conv_x3.h)
+    return nt <= GN_FUSE_MAX_NT && (long long)(CoutP / BM) * nt * B > split_tiles_max();
+}
+
 void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     ConvParams p = p_in;
-    DTTS_REQUIRE(p.w3 && p.x3 && (p.y || p.qkv_planes) && p.x3_tp > 0, "conv_x3: operands");
+    DTTS_REQUIRE(p.w3 && p.x3 && (p.y || p.qkv_planes || p.gn_out3) && p.x3_tp > 0, "conv_x3: operands");
+    const bool gn = p.gn_out3 != nullptr;
+    static const int env_ablate = []() { const char* v = getenv("DTTS_CONV_ABLATE"); return v ? atoi(v) : 0; }();
+    if (env_ablate) p.ablate = env_ablate;
+    if (gn) {
+        DTTS_REQUIRE(conv_x3_gn_fusable(p.Cout, p.CoutP, p.Cin, p.KW, p.gn_groups, p.B, p.Nout), "conv_x3: this launch cannot carry a fused GroupNorm");
+        DTTS_REQUIRE(p.gn_gamma && p.gn_beta && p.gn_xch && p.gn_tag && p.gn_err && !p.qkv_planes && p.epi_act == ACT_NONE && p.out_scale == 1.f &&
+                         (p.gn_act == ACT_NONE || p.gn_act == ACT_SILU), "conv_x3 fused GroupNorm: parameters");
+        auto a16 = [](const void* q, long long bs, int cs) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0 && (bs & 3) == 0 && (cs & 3) == 0; };
+        DTTS_REQUIRE((!p.y || a16(p.y, p.y_bs, p.y_cs)) && (!p.res || a16(p.res, p.res_bs, p.res_cs)), "conv_x3 fused GroupNorm: 16-byte aligned rows");
+    }
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
     DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3: channel padding");
     DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
@@ -803,10 +1153,10 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     static const int max_split = []() { const char* v = getenv("DTTS_CONV_KSPLIT"); const int n = v ? atoi(v) : 4; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
     int S = 1;
     // (k = 3: 144 K-steps per tile; the 48 steps of a 1x1 conv barely pay for the exchange: at most 2 there)
-    static const long long split_tiles = []() { const char* v = getenv("DTTS_CONV_KSPLIT_MAXTILE"); return v ? atoll(v) : 128LL; }();
+    const long long split_tiles = split_tiles_max();
     static const long long split_wgs = []() { const char* v = getenv("DTTS_CONV_KSPLIT_WGS"); return v ? atoll(v) : 256LL; }();
     if (ntile <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile), (p.Cin >> 4) / 8);
-    if (S < 1) S = 1;
+    if (S < 1 || gn) S = 1;
     p.ksplit = S;
     static const bool epi_vec_on = []() { const char* v = getenv("DTTS_X3_EPI_VEC"); return !(v && v[0] == '0'); }();
     auto al16 = [](const void* q, long long bs, int cs) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0 && (bs & 3) == 0 && (cs & 3) == 0; };
@@ -818,8 +1168,8 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     }
     const long long nwg = ntile * S;
     const int nstg = force_stg ? force_stg : (nwg <= max4 ? 4 : (nwg <= max3 ? 3 : 2));
-    const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16;
-    const int l4 = 4 * (WTILE + XBUF) + BM * (int)sizeof(float) + 16;      // the attribute is a maximum: every instantiation gets the 4-stage size
+    const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16 + (gn ? 2 * BM * sizeof(float) : 0);
+    const int l4 = 4 * (WTILE + XBUF) + 3 * BM * (int)sizeof(float) + 16;      // the attribute is a maximum: every instantiation gets the 4-stage size
     const dim3 grid((unsigned)nwg);
     const double cols = (double)p.B * p.Nout;
     const double flops = 2.0 * p.Cout * p.Cin * p.KW * cols;                      // fp32-equivalent; the MFMA pipe executes 3x this in fp16
@@ -836,7 +1186,10 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
         else if (nstg == 3) { lds_optin(reinterpret_cast<const void*>(conv_x3_kernel<E, K3, 3>), l4); hipLaunchKernelGGL((conv_x3_kernel<E, K3, 3>), grid, dim3(256), lds, s, p); } \
         else { lds_optin(reinterpret_cast<const void*>(conv_x3_kernel<E, K3, 2>), l4); hipLaunchKernelGGL((conv_x3_kernel<E, K3, 2>), grid, dim3(256), lds, s, p); } \
     } while (0)
-        if (p.qkv_planes) {
+        if (gn) {
+            if (p.KW == 3) DTTS_LAUNCH_X3(3, true);
+            else DTTS_LAUNCH_X3(3, false);
+        } else if (p.qkv_planes) {
             DTTS_REQUIRE(p.KW == 1 && !epi && !p.res && p.Cout % 144 == 0 && p.qkv_heads * 144 == p.Cout, "qkv planes epilogue: 48-channel heads, 1x1 conv");
             DTTS_LAUNCH_X3(2, false);
         } else if (p.KW == 3) {

@@ -209,6 +209,7 @@ public:
         else if (key == "gpt_token_exclusive_cu") { opt_tok_exclusive_ = value != 0; gpt_drop_graphs(); }
         else if (key == "gpt_token_fault") opt_tok_fault_ = value;       // test hook: the n-th token launch from now on times out
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
+        else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -246,10 +247,38 @@ private:
     // building blocks on [B, C, T] buffers (all lens are device pointers)
     void run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const;
     // xs: scratch for the split-precision input planes (x3_bytes(B, C, T)); null -> exact fp32 MFMA path
+    // GnNext / GnFuse: the GroupNorm + activation + split that FOLLOWS a block runs in the epilogue of the block's last conv
+    // (conv_x3.h "fused GroupNorm").  `f` carries the second planes buffer (producer and consumer planes ping-pong between xs and
+    // f->xs_alt), the exchange buffer of the launch stream and whether xs ALREADY holds the block's normalised input (written by the
+    // previous block's last conv).  next == nullptr: the block's output is left un-normalised (fp32 rows only).
+    struct GnNext {
+        const float *gamma = nullptr, *beta = nullptr;
+        int act = ACT_NONE;
+    };
+    struct GnFuse {
+        void* xs_alt = nullptr;
+        int slot = 0;                // exchange buffer / tag counter of this launch stream (gn_xch_)
+        bool in_ready = false;
+    };
     void attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens, int B,
-                         int T, int Ta, hipStream_t s, void* xs = nullptr);
+                         int T, int Ta, hipStream_t s, void* xs = nullptr, GnFuse* f = nullptr, const GnNext* next = nullptr);
     void res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T, int Ta,
-                       int step, hipStream_t s, void* xs = nullptr, const int* step_idx = nullptr);
+                       int step, hipStream_t s, void* xs = nullptr, const int* step_idx = nullptr, GnFuse* f = nullptr,
+                       const GnNext* next = nullptr);
+    // fused-GroupNorm plumbing: per launch stream an exchange buffer (zeroed when (re)allocated; only ever holds tags of earlier
+    // launches) and a tag counter; one host-mapped error flag the kernels raise when a poll gives up
+    struct GnXch {
+        void* buf = nullptr;
+        size_t bytes = 0;
+        unsigned tag = 0;
+    };
+    static constexpr int GN_SLOTS = 8;
+    GnXch gn_xch_[GN_SLOTS];
+    int* gn_err_host_ = nullptr;
+    int* gn_err_dev_ = nullptr;
+    bool opt_gn_fuse_ = false;            // option "gn_fuse" (measured neutral-to-negative: DESIGN.md par. 4; DTTS_GN_FUSE=0/1 overrides)
+    void gn_fill(ConvParams& p, int slot, size_t bytes, const GnNext& n, void* out3, int groups, hipStream_t s);
+    void gn_check();                      // throws when a fused-GroupNorm poll timed out since the last check
     bool use_x3() const;
     // cbuf0: [B + Nu, C, T] = B conditional code embeddings followed by Nu unconditional inputs (one per distinct length)
     // integ (optional): [B + Nu, C, T] outputs of the conditioning_timestep_integrator for this step (precompute_integrator)

@@ -61,6 +61,9 @@ Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) { DTTS_CHECK_H
 Model::~Model() {
     gpt_drop_graphs();
     if (x3_sat_) (void)hipFree(x3_sat_);
+    for (auto& g : gn_xch_)
+        if (g.buf) (void)hipFree(g.buf);
+    if (gn_err_host_) (void)hipHostFree(gn_err_host_);
     for (auto& kv : int_rings_) {
         IntRing& r = *kv.second;
         if (r.dev) (void)hipFree(r.dev);
@@ -396,16 +399,63 @@ bool Model::use_x3() const {
     return env_on && opt_conv_x3_;
 }
 
+// ------------------------------------------------------------------------------ fused GroupNorm plumbing (conv_x3.h)
+void Model::gn_fill(ConvParams& p, int slot, size_t bytes, const GnNext& n, void* out3, int groups, hipStream_t s) {
+    DTTS_REQUIRE(slot >= 0 && slot < GN_SLOTS, "fused GroupNorm: exchange slot");
+    GnXch& g = gn_xch_[slot];
+    if (!gn_err_host_) {
+        DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&gn_err_host_), sizeof(int), hipHostMallocMapped));
+        *gn_err_host_ = 0;
+        DTTS_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&gn_err_dev_), gn_err_host_, 0));
+    }
+    if (bytes > g.bytes) {
+        DTTS_CHECK_HIP(hipDeviceSynchronize());
+        if (g.buf) DTTS_CHECK_HIP(hipFree(g.buf));
+        g.buf = nullptr;
+        g.bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        DTTS_CHECK_HIP(hipMalloc(&g.buf, want));
+        DTTS_CHECK_HIP(hipMemsetAsync(g.buf, 0, want, s));
+        g.bytes = want;
+        g.tag = 0;
+    }
+    if (++g.tag == 0) {                    // 2^32 launches: stale tags could match again - start over from a clean buffer
+        DTTS_CHECK_HIP(hipMemsetAsync(g.buf, 0, g.bytes, s));
+        g.tag = 1;
+    }
+    p.gn_out3 = out3;
+    p.gn_gamma = n.gamma;
+    p.gn_beta = n.beta;
+    p.gn_act = n.act;
+    p.gn_groups = groups;
+    p.gn_eps = 1e-5f;
+    p.gn_xch = g.buf;
+    p.gn_tag = g.tag;
+    p.gn_err = gn_err_dev_;
+}
+
+void Model::gn_check() {
+    if (gn_err_host_ && *gn_err_host_) {
+        *gn_err_host_ = 0;
+        throw Error(-4, "fused GroupNorm: a statistics exchange timed out (the result of the previous diffusion call is invalid); "
+                        "dtts_set_option(\"gn_fuse\", 0) selects the separate pass");
+    }
+}
+
 // ------------------------------------------------------------------------------ building blocks
 // AttentionBlock (vqvae/utils/diff_util.py:209-215): y = x + proj(attn(qkv(GN(x))))
 void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float* qkv, float* att, float* ab, const int* lens,
-                            int B, int T, int Ta, hipStream_t s, void* xs) {
+                            int B, int T, int Ta, hipStream_t s, void* xs, GnFuse* f, const GnNext* next) {
     const int C = w.C, D = C / w.H;
     const long long bs = (long long)C * Ta;
     int groups = 32;
     while (C % groups) groups /= 2;
     const bool x3 = xs && w.qkv.w3 && w.proj.w3;
-    if (x3) launch_gn_split_planes(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ACT_NONE, xs, s);
+    DTTS_REQUIRE(!f || x3, "fused GroupNorm needs the split-precision path");
+    const bool in_ready = f && f->in_ready;             // xs already holds GN(x): written by the previous conv's epilogue
+    if (f) f->in_ready = false;
+    if (in_ready) {}
+    else if (x3) launch_gn_split_planes(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ACT_NONE, xs, s);
     else launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn_g, w.gn_b, 1e-5f, nullptr, 0, 0, ab, s);
     ConvParams p;
     p.B = B;
@@ -457,8 +507,10 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     // the proj conv's input planes come straight from the attention epilogue; xs still holds the zero halo / tail columns that
     // gn_split_planes wrote for the qkv conv (same B, T, lens), and the qkv conv has consumed the rest
     const bool att_planes = a.x3 && T + 1 < x3_tp(T);
+    DTTS_REQUIRE(!f || att_planes, "fused GroupNorm: the attention must write the proj conv's planes");
+    void* xs_att = f ? f->xs_alt : xs;                  // fused: the proj conv reads xs_alt and its epilogue writes xs (the next block's input)
     if (att_planes) {
-        a.out_x3 = xs;
+        a.out_x3 = xs_att;
         a.x3_tp = x3_tp(T);
     }
     launch_flash_attention(a, s);
@@ -479,21 +531,29 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     q.res_cs = Ta;
     if (x3) {
         if (!att_planes) launch_split_planes(att, bs, Ta, nullptr, ACT_NONE, lens, T, B, C, xs, s);
-        q.x3 = xs;
+        q.x3 = xs_att;
         q.x3_tp = x3_tp(T);
+    }
+    if (f && next) {                                    // the norm of the NEXT block in this conv's epilogue -> xs
+        gn_fill(q, f->slot, conv_x3_gn_xch_bytes(B, C, T), *next, xs, groups, s);
+        f->in_ready = true;
     }
     run_conv(w.proj, q, s);
 }
 
 // diffusion ResBlock (vqvae/diff_model.py:106-119): y = x + conv3(SiLU(AdaGN(conv1(SiLU(GN(x))))))
 void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* y, float* ab, const int* lens, int B, int T,
-                          int Ta, int step, hipStream_t s, void* xs, const int* step_idx) {
+                          int Ta, int step, hipStream_t s, void* xs, const int* step_idx, GnFuse* f, const GnNext* next) {
     const int C = cfg.diff_channels;
     const long long bs = (long long)C * Ta;
     int groups = 32;
     while (C % groups) groups /= 2;
     const bool x3 = xs && w.c1.w3 && w.c2.w3;
-    if (x3) launch_gn_split_planes(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, s);
+    DTTS_REQUIRE(!f || x3, "fused GroupNorm needs the split-precision path");
+    const bool in_ready = f && f->in_ready;             // xs already holds SiLU(GN1(x)): written by the previous conv's epilogue
+    if (f) f->in_ready = false;
+    if (in_ready) {}
+    else if (x3) launch_gn_split_planes(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, s);
     else launch_gn_coeffs(x, bs, Ta, lens, T, B, C, groups, w.gn1_g, w.gn1_b, 1e-5f, nullptr, 0, 0, ab, s);
     ConvParams p;
     p.B = B;
@@ -513,10 +573,24 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
         p.x3 = xs;
         p.x3_tp = x3_tp(T);
     }
-    run_conv(w.c1, p, s);
     const float* ada = ss_table_ + (size_t)w.index * 2 * C * n_steps_ + (step_idx ? 0 : step);   // step_idx: per-sample steps
-    if (x3) launch_gn_split_planes(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ACT_SILU, xs, s, step_idx);
-    else launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s, step_idx);
+    if (f) {                                            // AdaGN + SiLU + split of h1 in the 1x1 conv's epilogue; h1 itself is never stored (:106-119)
+        GnNext n2;
+        n2.gamma = w.gn2_g;
+        n2.beta = w.gn2_b;
+        n2.act = ACT_SILU;
+        ConvParams p1 = p;
+        p1.y = nullptr;
+        gn_fill(p1, f->slot, conv_x3_gn_xch_bytes(B, C, T), n2, f->xs_alt, groups, s);
+        p1.gn_ada = ada;
+        p1.gn_ada_stride = n_steps_;
+        p1.gn_ada_idx = step_idx;
+        run_conv(w.c1, p1, s);
+    } else {
+        run_conv(w.c1, p, s);
+        if (x3) launch_gn_split_planes(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ACT_SILU, xs, s, step_idx);
+        else launch_gn_coeffs(h1, bs, Ta, lens, T, B, C, groups, w.gn2_g, w.gn2_b, 1e-5f, ada, n_steps_, 0, ab, s, step_idx);
+    }
     ConvParams q = p;
     q.x = h1;
     q.pad = 1;
@@ -524,6 +598,13 @@ void Model::res_block_fwd(const ResBlockW& w, const float* x, float* h1, float* 
     q.res = x;
     q.res_bs = bs;
     q.res_cs = Ta;
+    if (f) {
+        q.x3 = f->xs_alt;
+        if (next) {                                     // the norm of the NEXT block in this conv's epilogue -> xs
+            gn_fill(q, f->slot, conv_x3_gn_xch_bytes(B, C, T), *next, xs, groups, s);
+            f->in_ready = true;
+        }
+    }
     run_conv(w.c2, q, s);
 }
 
@@ -651,6 +732,24 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         float* qkv = ws().f32(qkv_floats(n, C, T));
         float* ab = ws().f32((size_t)n * C * 2);
         void* xs = x3 ? ws().raw(x3_bytes(n, C, T)) : nullptr;
+        // fused GroupNorm (conv_x3.h): every GN + activation + split of the stack runs in the epilogue of the conv in front of it
+        // (8 -> 5 launches per DiffusionLayer); planes ping-pong between xs and xs2; chunk k uses exchange slot k
+        static const int env_fuse = []() { const char* v = getenv("DTTS_GN_FUSE"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
+        const bool fuse = x3 && (env_fuse >= 0 ? env_fuse != 0 : opt_gn_fuse_) && conv_x3_gn_fusable(C, C, C, 3, groups, n, T) && T + 1 < x3_tp(T);
+        GnFuse fz;
+        GnFuse* f = nullptr;
+        if (fuse) {
+            fz.xs_alt = ws().raw(x3_bytes(n, C, T));
+            fz.slot = k;
+            f = &fz;
+        }
+        auto norm_of = [](const float* g, const float* be, int act) {
+            GnNext nn;
+            nn.gamma = g;
+            nn.beta = be;
+            nn.act = act;
+            return nn;
+        };
         // integrating_conv, code half, accumulated onto the shared x-path term (the residual of stack sample b is xpath[b % B])
         ConvParams r = cp(code_path, C, bufB, C, n, T, Ta, lens);
         r.res = xpath + (size_t)(b0 % B) * C * Ta;
@@ -662,21 +761,36 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
             r.x3 = xs_code;
             r.x3_tp = x3_tp(T);
         }
+        const GnNext out_norm = norm_of(out_gn_g_, out_gn_b_, ACT_SILU);
+        auto first_norm = [&](size_t li, size_t ti) {      // GN1 of layer li of the stack, else of tail block ti, else the out norm
+            if (li < layers_.size()) return norm_of(layers_[li].rb.gn1_g, layers_[li].rb.gn1_b, ACT_SILU);
+            if (ti < tail_.size()) return norm_of(tail_[ti].gn1_g, tail_[ti].gn1_b, ACT_SILU);
+            return out_norm;
+        };
+        if (f) {
+            const GnNext n0 = first_norm(0, 0);
+            gn_fill(r, f->slot, conv_x3_gn_xch_bytes(n, C, T), n0, xs, groups, st);
+            f->in_ready = true;
+        }
         run_conv(integ2_, r, st);
         // main stack (:299-309)
         float* cur = bufB;
         float* t1 = bufA;
         float* t2 = bufC;
-        for (auto& l : layers_) {                       // output back into `cur` (x is dead after the residual add)
-            res_block_fwd(l.rb, cur, t1, t2, ab, lens, n, T, Ta, step, st, xs);
-            attention_block(l.at, t2, cur, qkv, t1, ab, lens, n, T, Ta, st, xs);
+        for (size_t li = 0; li < layers_.size(); ++li) {   // output back into `cur` (x is dead after the residual add)
+            const auto& l = layers_[li];
+            const GnNext na = norm_of(l.at.gn_g, l.at.gn_b, ACT_NONE), nn = first_norm(li + 1, 0);
+            res_block_fwd(l.rb, cur, t1, t2, ab, lens, n, T, Ta, step, st, xs, nullptr, f, &na);
+            attention_block(l.at, t2, cur, qkv, t1, ab, lens, n, T, Ta, st, xs, f, &nn);
         }
-        for (auto& rb : tail_) {
-            res_block_fwd(rb, cur, t1, t2, ab, lens, n, T, Ta, step, st, xs);
+        for (size_t ti = 0; ti < tail_.size(); ++ti) {
+            const GnNext nn = first_norm(layers_.size(), ti + 1);
+            res_block_fwd(tail_[ti], cur, t1, t2, ab, lens, n, T, Ta, step, st, xs, nullptr, f, &nn);
             std::swap(cur, t2);
         }
         // out: GN, SiLU, conv k3 (:312)
-        if (x3) launch_gn_split_planes(cur, bs, Ta, lens, T, n, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
+        if (f && f->in_ready) {}                            // already in xs: written by the last block's conv
+        else if (x3) launch_gn_split_planes(cur, bs, Ta, lens, T, n, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ACT_SILU, xs, st);
         else launch_gn_coeffs(cur, bs, Ta, lens, T, n, C, groups, out_gn_g_, out_gn_b_, 1e-5f, nullptr, 0, 0, ab, st);
         ConvParams o = cp(cur, C, out2 + (size_t)b0 * OC * T, OC, n, T, Ta, lens);
         o.pro_ab = ab;
@@ -772,12 +886,13 @@ static size_t pair_ws_bytes(int B, int C, int T) {
     // x path (2 act) + the chunks' scratch over the 2B stack (2 x 6 act) + the integrator evaluated in place (2 act out + 2 x 6 act
     // scratch, only without the precomputed integrator) ; split planes: x path (B) + chunks (2B) + code path (2B) + integrator (2B)
     return sizeof(float) * (2 * act + 2 * (3 * act + qkv_floats(B, C, T) + (size_t)2 * B * C) + 2 * act + 2 * (2 * act + qkv_floats(B, C, T) + (size_t)2 * B * C)) +
-           7 * x3_bytes(B, C, T) + 64 * 256;
+           9 * x3_bytes(B, C, T) + 64 * 256;
 }
 
 // ------------------------------------------------------------------------------ stage entry points
 void Model::diff_forward(const float* x, const float* code_emb, const int* lens_host, int B, int T, int step, int cond_free,
                          float* out, hipStream_t s) {
+    gn_check();
     DTTS_REQUIRE(bound_, "weights not bound");
     DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
     const int C = cfg.diff_channels, OC = cfg.diff_out_channels;
@@ -799,6 +914,7 @@ void Model::diff_forward(const float* x, const float* code_emb, const int* lens_
 void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int T, unsigned long long seed,
                         const int* sample_ids_host, int n_steps, const float* x_init, const float* step_noise, float* mel_out,
                         int denorm, hipStream_t s) {
+    gn_check();
     DTTS_REQUIRE(bound_, "weights not bound");
     const int C = cfg.diff_channels, OC = cfg.diff_out_channels, MC = cfg.mel_channels;
     if (n_steps <= 0 || n_steps > n_steps_) n_steps = n_steps_;
@@ -868,6 +984,7 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
 // GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at one sampling step, x in place
 void Model::diff_p_sample(float* x, const float* code_emb, const int* lens_host, int B, int T, int step, unsigned long long seed,
                           const int* sample_ids_host, const float* noise, float* x0_out, hipStream_t s) {
+    gn_check();
     DTTS_REQUIRE(bound_, "weights not bound");
     DTTS_REQUIRE(step >= 0 && step < n_steps_, "step out of range");
     DTTS_REQUIRE(sample_ids_host, "sample_ids");

@@ -214,6 +214,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
             r.Tr = Tr; r.Lt_max = Lt_max; r.B = B; r.lat_stride = lat_stride; r.latents_cm = latents_cm;
             r.has_refer_lens = refer_lens_host != nullptr;
             r.has_text_lens = text_lens_host != nullptr;
+            r.refer_lens.clear(); r.text_lens.clear(); r.forced_codes.clear(); r.row_seeds.clear();      // nothing of an earlier session survives
             if (refer_lens_host) r.refer_lens.assign(refer_lens_host, refer_lens_host + B);
             r.text.assign(text_host, text_host + (size_t)B * Lt_max);
             if (text_lens_host) r.text_lens.assign(text_lens_host, text_lens_host + B);

@@ -84,6 +84,38 @@ def test_diffusion_forward_T936_batch2_vs_oracle_dense(rt, weights, I):
         assert maxabs(ou[b, :, :L], ru) < 3e-4, (b, maxabs(ou[b, :, :L], ru))
 
 
+def test_fused_groupnorm_forward_B6_T936_vs_reference_and_unfused(rt, I, G):
+    """The trunk with every GroupNorm + activation + split folded into the epilogue of the conv in front of it (conv_x3.h "fused
+    GroupNorm": tiles exchange partial statistics through tagged words; batches of >= 5 utterances at T <= 1152) against (a) the
+    reference's own DiffusionTts.forward for row 0 and (b) the launch-by-launch GroupNorm passes for every row of a RAGGED batch of 6
+    (lengths that end inside a tile, on a tile edge - the zero halo column of the next tile - and one full row).  Only the order of
+    the statistics' fp32 sums differs between (a) and (b)."""
+    rs = np.random.RandomState(13)
+    B = 6
+    lens = [T, 800, T, 577, 768, 192]
+    x = np.concatenate([I["x"], rs.randn(B - 1, 128, T).astype(np.float32)])
+    ce = np.concatenate([I["code_emb"], (rs.randn(B - 1, 768, T) * 0.5).astype(np.float32)])
+    outs = {}
+    for fuse in (1, 0):
+        rt.set_option("gn_fuse", fuse)
+        try:
+            outs[fuse] = (host(rt.diff_forward(dev(x), 47, dev(ce), lens=lens)), host(rt.diff_forward(dev(x), 47, cond_free=True, lens=lens)))
+        finally:
+            rt.set_option("gn_fuse", 0)
+    check_sub(outs[1][0][0], G, "fwd47_cond", 3e-4)
+    check_sub(outs[1][1][0], G, "fwd47_uncond", 3e-4)
+    for h in (0, 1):
+        for b, L in enumerate(lens):
+            tol(f"fused_gn_vs_unfused_half{h}_row{b}", maxabs(outs[1][h][b, :, :L], outs[0][h][b, :, :L]), 5e-5)
+    # the fused path really ran: a repeated call is bit-identical (deterministic combination order)
+    rt.set_option("gn_fuse", 1)
+    try:
+        again = host(rt.diff_forward(dev(x), 47, dev(ce), lens=lens))
+    finally:
+        rt.set_option("gn_fuse", 0)
+    assert np.array_equal(again, outs[1][0]) and not np.array_equal(outs[1][0], outs[0][0])
+
+
 def test_p_sample_T936_vs_reference(rt, I, G):
     """One GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at i = 49, T = 936, Philox noise on the device."""
     x1, x0 = rt.diff_p_sample(dev(I["x"]), dev(I["code_emb"]), 49, 1234, [2], return_x0=True)
