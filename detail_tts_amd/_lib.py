@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdetail_hip.so")
+# DTTS_LIB_PATH: another build of the same library (diagnostic builds of tools/diag_token_pk.py); the default is the in-tree product library
+LIB_PATH = os.environ.get("DTTS_LIB_PATH") or os.path.join(HERE, "libdetail_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)

@@ -74,6 +74,24 @@ def build(verbose=True):
     return LIB
 
 
+def build_variant(name, token_flags):
+    """Diagnostics (tools/diag_token_pk.py): the library with csrc/gpt_token.hip compiled with OTHER flags than its `// hipcc-flags:` line
+    (e.g. [] = packed fp32 math back on), as libdetail_hip_<name>.so next to the product library.  DTTS_LIB_PATH selects it at load time."""
+    build(verbose=False)
+    vdir = os.path.join(CSRC, "build", "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    obj = os.path.join(vdir, "gpt_token.o")
+    r = subprocess.run([HIPCC, *FLAGS, *token_flags, "-c", os.path.join(CSRC, "gpt_token.hip"), "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in _sources() if f != "gpt_token.hip"] + [obj]
+    lib = os.path.join(HERE, f"libdetail_hip_{name}.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return lib
+
+
 if __name__ == "__main__":
     build()
     sys.exit(0)

@@ -1167,7 +1167,8 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
         p.kcount = w.count;
     }
     const long long nwg = ntile * S;
-    const int nstg = force_stg ? force_stg : (nwg <= max4 ? 4 : (nwg <= max3 ? 3 : 2));
+    static const long long max4k3 = []() { const char* v = getenv("DTTS_CONV_STAGES4_MAXWG_K3"); return v ? atoll(v) : 128LL; }();
+    const int nstg = force_stg ? force_stg : (nwg <= (p.KW == 3 ? max4k3 : max4) ? 4 : (nwg <= max3 ? 3 : 2));
     const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16 + (gn ? 2 * BM * sizeof(float) : 0);
     const int l4 = 4 * (WTILE + XBUF) + 3 * BM * (int)sizeof(float) + 16;      // the attribute is a maximum: every instantiation gets the 4-stage size
     const dim3 grid((unsigned)nwg);

@@ -300,7 +300,9 @@ __device__ __forceinline__ float gelu_new(float v) {
 }
 
 __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) {
+#ifndef DTTS_TOKEN_NO_SETPRIO                              // (diagnostic builds only: tools/diag_token_pk.py)
     __builtin_amdgcn_s_setprio(3);                        // under the diffusion trunk: this latency chain's waves issue ahead of the resident conv waves
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
     const int tid_k = threadIdx.x, w = blockIdx.x;

@@ -276,7 +276,7 @@ def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
         assert l0 == l1 and torch.equal(w0, w1)
     for (w0, l0), (w1, l1) in zip(outs, chain):
         assert l0 == l1
-        tol("infer_stream_token_vs_chain_rms", float((w0 - w1).pow(2).mean().sqrt()), 1e-6)       # latents differ by summation order (2e-6)
+        tol("infer_stream_token_vs_chain_rms", float((w0 - w1).pow(2).mean().sqrt()), 1e-7)       # latents differ by summation order (2e-6)
     for r, (wav, lens) in zip(reqs, outs):
         ref, rlens = model.infer(r["text"], r["text_length"], r["refer"], r["refer_lengths"], batch=True, seed=r["seed"],
                                  sample_ids=r["sample_ids"], max_generate_length=G, suppress_eos=suppress_eos, return_lengths=True)

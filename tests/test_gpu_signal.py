@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-REL_WAV = 1e-4          # relative waveform RMS gate under the signal weights (measured ~1e-6: profiles/r04_measured_errors.txt)
+REL_WAV = 6e-5          # relative waveform RMS gate under the signal weights: ~20 x the measured 1.7e-6 .. 3.4e-6 (profiles/r04_measured_errors.txt)
 
 
 def maxabs(a, b):
@@ -57,12 +57,12 @@ def test_infer_flowvae_signal_weights_vs_reference(synth, golden):
     rt = synth.rt
     assert rms(g["wav"], g["wav_z0"]) > 0.5 * rms(g["wav"]) > 0.05          # the weight set does what it is for
     gg = host(rt.mel_style("ref_enc", dev(I["mel"])))
-    tol("signal_small_g_maxabs", maxabs(gg.reshape(-1), g["g"].reshape(-1)), 1e-4)
+    tol("signal_small_g_maxabs", maxabs(gg.reshape(-1), g["g"].reshape(-1)), 5e-6)
     m_p, logs_p = rt.op_enc_p(dev(I["mel"]))
-    tol("signal_small_m_p_maxabs", maxabs(host(m_p), g["m_p"]), 2e-4 * max(1.0, float(np.abs(g["m_p"]).max())))
-    tol("signal_small_logs_p_maxabs", maxabs(host(logs_p), g["logs_p"]), 2e-4)
+    tol("signal_small_m_p_maxabs", maxabs(host(m_p), g["m_p"]), 2e-5 * max(1.0, float(np.abs(g["m_p"]).max())))
+    tol("signal_small_logs_p_maxabs", maxabs(host(logs_p), g["logs_p"]), 2e-5)
     wav, z = rt.vocoder(dev(I["mel"]), int(g["seed"]), [int(g["sample_id"])], return_z=True)
-    tol("signal_small_z_maxabs", maxabs(host(z), g["z"]), 2e-4 * max(1.0, float(np.abs(g["z"]).max())))
+    tol("signal_small_z_maxabs", maxabs(host(z), g["z"]), 2e-5 * max(1.0, float(np.abs(g["z"]).max())))
     tol("signal_small_wav_rel_rms", rms(host(wav), g["wav"]) / rms(g["wav"]), REL_WAV)
     w0 = host(rt.generator(torch.zeros_like(z), dev(g["g"][:, :, 0])))
     tol("signal_small_wav_z0_rel_rms", rms(w0, g["wav_z0"]) / rms(g["wav_z0"]), REL_WAV)
@@ -177,7 +177,7 @@ def test_vocoder_60s_one_shot_and_streamed_vs_reference_waveform(synth, LF, chun
     if chunk == 0:
         wav, z = rt.vocoder(dev(I["mel"]), seed, [sid], return_z=True)
         s, t = sub(host(z)[0], LF)
-        tol("voc_T5624_z_maxabs", max(maxabs(s, LF["voc_z_s"]), maxabs(t, LF["voc_z_t"])), 2e-4 * max(1.0, float(np.abs(LF["voc_z_s"]).max())))
+        tol("voc_T5624_z_maxabs", max(maxabs(s, LF["voc_z_s"]), maxabs(t, LF["voc_z_t"])), 2e-5 * max(1.0, float(np.abs(LF["voc_z_s"]).max())))
     else:
         wav = rt.vocoder(dev(I["mel"]), seed, [sid], stream_chunk=chunk)
     w = host(wav)[0, 0]
@@ -189,4 +189,4 @@ def test_vocoder_60s_one_shot_and_streamed_vs_reference_waveform(synth, LF, chun
     h = int(LF["seam_half"])
     worst = max(rms(w[p - h: p + h], ref) for p, ref in zip(LF["seam_pos"], LF["voc_wav_seams"]))
     tol(f"voc_T5624_chunk{chunk}_wav_seams_rel_rms", worst / ref_rms, REL_WAV)
-    tol(f"voc_T5624_chunk{chunk}_wav_seams_maxabs", max(maxabs(w[p - h: p + h], ref) for p, ref in zip(LF["seam_pos"], LF["voc_wav_seams"])), 2e-4)
+    tol(f"voc_T5624_chunk{chunk}_wav_seams_maxabs", max(maxabs(w[p - h: p + h], ref) for p, ref in zip(LF["seam_pos"], LF["voc_wav_seams"])), 5e-5)

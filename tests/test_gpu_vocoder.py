@@ -57,7 +57,7 @@ def test_infer_flowvae_golden(rt, golden):
     g = golden("vocoder")
     wav, z = rt.vocoder(dev(g["mel"]), int(g["seed"]), [int(g["sample_id"])], return_z=True)
     assert maxabs(host(z), g["z"]) < 2e-4, maxabs(host(z), g["z"])
-    tol("infer_flowvae_golden_wav_rms", rms(host(wav), g["wav"]), 2e-7)   # see tests/test_gpu_signal.py for the z-driven weight set
+    tol("infer_flowvae_golden_wav_rms", rms(host(wav), g["wav"]), 1e-7)   # see tests/test_gpu_signal.py for the z-driven weight set
 
 
 def test_enc_p_unit_entry_vs_reference_and_oracle(rt, golden, weights):
@@ -87,7 +87,7 @@ def test_vocoder_varlen_batch_vs_oracle(rt, weights):
     for b, L in enumerate(lens):
         ref = V.infer_flowvae(weights, mel[b:b + 1, :, :L], [L], 77, [4 + b])[0, 0]
         got = wav[b, 0, :256 * L]
-        tol(f"vocoder_varlen_row{b}_vs_oracle_rms", rms(got, ref), 2e-7)
+        tol(f"vocoder_varlen_row{b}_vs_oracle_rms", rms(got, ref), 1e-7)
         assert np.all(wav[b, 0, 256 * L:] == 0)
 
 
@@ -106,7 +106,7 @@ def test_generator_long_input_halo_consistency(rt, weights):
     full = host(rt.generator(dev(z), dev(g)))[0, 0]
     part = host(rt.generator(dev(z[:, :, 40:120]), dev(g)))[0, 0]
     a, b = full[(40 + 16) * 256:(120 - 16) * 256], part[16 * 256:(80 - 16) * 256]
-    tol("generator_halo_consistency_maxabs", maxabs(a, b), 2e-7)
+    tol("generator_halo_consistency_maxabs", maxabs(a, b), 1e-7)
 
 
 # ---------------------------------------------------------------------------- infer_gpt's VQ decode path
@@ -122,7 +122,7 @@ def test_vq_decode_golden(rt_vq, golden):
     assert mel.shape == g["recon"].shape
     assert maxabs(mel, g["recon"]) < 2e-4, maxabs(mel, g["recon"])
     wav = host(rt_vq.vocoder(dev(mel), int(g["seed"]), [int(g["sample_id"])]))
-    tol("vq_decode_wav_rms", rms(wav, g["wav"]), 2e-7)
+    tol("vq_decode_wav_rms", rms(wav, g["wav"]), 1e-7)
 
 
 def test_vq_decode_varlen_batch_vs_oracle(rt_vq, weights):
@@ -209,7 +209,7 @@ def test_generator_stream_equals_full_and_wav_writer(weights, tmp_path):
     assert [p.shape[-1] for p in parts] == [48 * 256, 48 * 256, 48 * 256, 6 * 256]
     cat = torch.cat(parts, -1)
     assert cat.shape == full.shape
-    tol("generator_stream_vs_full_maxabs", float((cat - full).abs().max()), 2e-7)
+    tol("generator_stream_vs_full_maxabs", float((cat - full).abs().max()), 1e-7)
     path = tmp_path / "gen.wav"
     write_wav(path, full[0], 24000)
     with wave.open(str(path), "rb") as f:
