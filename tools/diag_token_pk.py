@@ -37,7 +37,7 @@ def build():
             print(name, "FAILED:", str(e)[-400:])
 
 
-def child(exclusive):
+def child(exclusive, load_kind="diffusion"):
     import threading
     import time
     import numpy as np
@@ -62,10 +62,41 @@ def child(exclusive):
         torch.cuda.set_device(0)
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            r8 = torch.from_numpy((np.random.RandomState(1).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
-            ce = rt.diff_timestep_independent(torch.randn(8, 768, 100, device="cuda"), rt.diff_conditioning(r8))
+            if load_kind == "diffusion":        # split-precision convs / attention: LDS-DMA, <= 168 VGPRs (fit next to a token wave on a SIMD)
+                r8 = torch.from_numpy((np.random.RandomState(1).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
+                ce = rt.diff_timestep_independent(torch.randn(8, 768, 100, device="cuda"), rt.diff_conditioning(r8))
+                body = lambda: rt.diff_sample(ce, 3, list(range(8)), n_steps=4)
+            elif load_kind == "fp32conv":       # the same diffusion on the exact-fp32 MFMA kernels (no LDS-DMA)
+                rt.set_option("conv_x3", 0)
+                r8 = torch.from_numpy((np.random.RandomState(1).randn(8, 128, 300) * 2 - 5).astype(np.float32)).cuda()
+                ce = rt.diff_timestep_independent(torch.randn(8, 768, 100, device="cuda"), rt.diff_conditioning(r8))
+                body = lambda: rt.diff_sample(ce, 3, list(range(8)), n_steps=4)
+            elif load_kind == "elementwise":    # no LDS, a handful of VGPRs: certainly co-resident on the token waves' SIMDs
+                a = torch.randn(64 << 20, device="cuda")
+                b = torch.randn(64 << 20, device="cuda")
+
+                def body():
+                    for _ in range(8):
+                        a.mul_(1.0000001).add_(b, alpha=1e-9)
+                        torch.sin(a, out=b)
+            elif load_kind in ("mfma_f16", "mfma_f32", "lds_dma"):      # tools/diag/loads.hip: one ingredient each, small registers, shares CUs
+                import ctypes
+                L = ctypes.CDLL(os.path.join(ROOT, "tools", "diag", "loads.so"))
+                outb = torch.zeros(16, device="cuda")
+                srcb = torch.randn(16 << 20, device="cuda")                # 64 MiB
+                st = ctypes.c_void_p(s.cuda_stream)
+                if load_kind == "lds_dma":
+                    body = lambda: L.diag_lds_dma(ctypes.c_void_p(srcb.data_ptr()), ctypes.c_void_p(outb.data_ptr()), 400, ctypes.c_uint((64 << 20) - 4096 - 1 & ~15), st)
+                elif load_kind == "mfma_f16":
+                    body = lambda: L.diag_mfma_f16(ctypes.c_void_p(outb.data_ptr()), 4000, st)
+                else:
+                    body = lambda: L.diag_mfma_f32(ctypes.c_void_p(outb.data_ptr()), 500, st)
+            else:                               # "matmul": hipBLASLt / rocBLAS fp32 GEMM
+                a = torch.randn(4096, 4096, device="cuda")
+                b = torch.randn(4096, 4096, device="cuda")
+                body = lambda: [torch.matmul(a, b) for _ in range(8)]
             while not stop.is_set():
-                rt.diff_sample(ce, 3, list(range(8)), n_steps=4)
+                body()
                 s.synchronize()
 
     th = threading.Thread(target=load)
@@ -94,12 +125,16 @@ def run():
         if not os.path.exists(lib):
             print(name, "no library")
             continue
-        for excl in (0, 1) if name == "pk" else (0,):
+        cases = [(0, "diffusion")]
+        if name == "pk":
+            cases += [(1, "diffusion"), (0, "fp32conv"), (0, "elementwise"), (0, "matmul"), (0, "mfma_f16"), (0, "mfma_f32"), (0, "lds_dma")]
+        for excl, kind in cases:
             env = dict(os.environ, DTTS_LIB_PATH=lib)
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(excl)], env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(excl), kind], env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            out[f"{name}, exclusive_cu={excl}"] = json.loads(line[-1]) if line else {"error": r.stderr[-300:]}
-            print(f"{name:10s} exclusive_cu={excl}: {out[f'{name}, exclusive_cu={excl}']}", flush=True)
+            key = f"{name}, exclusive_cu={excl}, load={kind}"
+            out[key] = json.loads(line[-1]) if line else {"error": r.stderr[-300:]}
+            print(f"{key}: {out[key]}", flush=True)
     return out
 
 
@@ -108,6 +143,6 @@ if __name__ == "__main__":
     if cmd == "build":
         build()
     elif cmd == "child":
-        child(int(sys.argv[2]))
+        child(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "diffusion")
     else:
         run()
