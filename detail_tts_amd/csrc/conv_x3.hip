@@ -810,23 +810,32 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
         // 24 residual loads + 24 stores of 1 KiB per wave.  Region: 16 rows x (96 + 8) floats = 6.5 KiB per wave (the K loop's
         // stages are free once every wave has left it: one barrier).
         constexpr int EP_LD = 104;
-        __syncthreads();
-        float* st = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);
         float* yb = p.y + (long long)b * p.y_bs;
         const float* rb = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
         const int ncol0 = n0 + wn0;
+        // Residual rows: with >= 3 LDS stages (register budget 256) ALL 24 loads of the tile are in flight before the first round -
+        // one memory latency for the tile instead of one per round (the rounds' LDS fences keep the compiler from hoisting them)
+        constexpr bool RES_AHEAD = NSTG >= 3;
+        float4 rva[RES_AHEAD ? 4 : 1][6];
+        auto load_res = [&](int q, float4 (&dst)[6]) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + wm0 + (q >> 1) * 32 + (q & 1) * 16 + rl, n = ncol0 + c4 * 4;
+                dst[k] = (row < p.Cout && n < nvalid) ? *reinterpret_cast<const float4*>(rb + (long long)row * p.res_cs + n)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if (RES_AHEAD && rb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_res(q, rva[q]);
+        }
+        __syncthreads();
+        float* st = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = q >> 1, rowt0 = wm0 + i * 32 + (q & 1) * 16;          // first tile row of this round
-            float4 rv[6];
-            if (rb) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + rowt0 + rl, n = ncol0 + c4 * 4;
-                    rv[k] = (row < p.Cout && n < nvalid) ? *reinterpret_cast<const float4*>(rb + (long long)row * p.res_cs + n)
-                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
+            float4 (&rv)[6] = rva[RES_AHEAD ? q : 0];
+            if (!RES_AHEAD && rb) load_res(q, rv);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll

@@ -237,6 +237,9 @@ class SynthesizerTrn:
         if self._voc_stream is None:
             self._voc_stream = torch.cuda.Stream(dev)
         sa, sc = self._gpt_stream, self._voc_stream
+        # DTTS_SERIAL_VOCODER=1: stage C on stage B's stream, between two requests' diffusions, instead of on a third stream under the
+        # next request's diffusion (measurement knob: under the pipeline the concurrent vocoder costs stage B more than its own 20 ms)
+        serial_c = os.environ.get("DTTS_SERIAL_VOCODER", "0") == "1"
         trace = self.stream_trace          # a list: per-request host times and stream events (tools/pipeline_trace.py)
         kw = dict(max_generate_length=max_generate_length, top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
                   repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
@@ -343,14 +346,15 @@ class SynthesizerTrn:
             ready.record(cur)
             if tr:
                 tr["ev_b1"].record(cur)
-            with torch.cuda.stream(sc):
-                sc.wait_event(ready)
+            with torch.cuda.stream(cur if serial_c else sc):
+                if not serial_c:
+                    sc.wait_event(ready)
                 wav = self.rt.vocoder(mel, st["seed"], st["sids"], lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
-                mel.record_stream(sc)
+                mel.record_stream(cur if serial_c else sc)
                 self.vocoder_done = torch.cuda.Event()
-                self.vocoder_done.record(sc)
+                self.vocoder_done.record(cur if serial_c else sc)
                 if tr:
-                    tr["ev_c1"].record(sc)
+                    tr["ev_c1"].record(cur if serial_c else sc)
                     tr["host_b1"] = time.perf_counter()
             wav.record_stream(cur)
             return wav, [1024 * v for v in n], self.vocoder_done
