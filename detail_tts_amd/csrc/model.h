@@ -352,9 +352,11 @@ private:
 
     bool opt_two_streams_ = true;
     bool opt_range_check_ = false;      // vocoder: detect activations beyond the split-precision planes' range (synchronises)
-    int* x3_sat_ = nullptr;             // device flag of the range check
-    int* x3_sat_flag(hipStream_t s);    // null unless the check is on; zeroed on s
-    void x3_sat_check(hipStream_t s);   // throws when the flag was raised
+    int* x3_sat_ = nullptr;             // host-mapped flag of the range check (raised by the kernels, read without synchronising)
+    int* x3_sat_dev_ = nullptr;         // its device address; null = check off
+    int* x3_sat_flag(hipStream_t s);    // device address of the flag (null when DTTS_X3_RANGE_CHECK=0); reports an earlier call's saturation
+    void x3_sat_report(bool this_call); // throws when the flag is up
+    void x3_sat_check(hipStream_t s);   // option x3_range_check: synchronise and report this call's saturation
     int opt_cfg_streams_ = 0;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into; 0 = by batch size
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies

@@ -60,7 +60,7 @@ Model::Model(const dtts_config& c, int dev) : cfg(c), device(dev) { DTTS_CHECK_H
 
 Model::~Model() {
     gpt_drop_graphs();
-    if (x3_sat_) (void)hipFree(x3_sat_);
+    if (x3_sat_) (void)hipHostFree(x3_sat_);
     for (auto& g : gn_xch_)
         if (g.buf) (void)hipFree(g.buf);
     if (gn_err_host_) (void)hipHostFree(gn_err_host_);

@@ -237,7 +237,7 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
     const bool x3 = xs && rb.c1[0].w3 && rb.c1[0].CoutP % 64 == 0 && vocoder_x3();     // (narrow stages carry w3 in the fused kernel's fragment order)
     auto conv3 = [&](const PackedConv& pc, ConvParams p, const float* in) {
         const int Tp = x3d_tp(T);
-        launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s, opt_range_check_ ? x3_sat_ : nullptr);
+        launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s, x3_sat_dev_);
         p.w3 = pc.w3;
         p.x3 = xs;
         p.x3_tp = Tp;
@@ -308,30 +308,44 @@ void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, cons
     for (int l = 0; l < 3; ++l) p.dil[l] = cfg.resblock_dilations[l];
     p.branch_mask = branch_mask;
     p.scale = scale;
-    p.sat = opt_range_check_ ? x3_sat_ : nullptr;
+    p.sat = x3_sat_dev_;
     launch_resblock1x3_fused(p, s);
 }
 
-// Range check of the split-precision operands of the generator's wide ResBlock1 convs (their inputs are UNNORMALISED activations: beyond
-// +-65504 / 16 = 4094 the fp16 planes saturate and the conv is silently wrong).  Opt-in (dtts_set_option "x3_range_check" or
-// DTTS_X3_RANGE_CHECK=1): the verdict is read back at the end of the generator, which synchronises the stream.
+// Range check of the split-precision operands of the generator's ResBlock1 convs (their inputs are UNNORMALISED activations: beyond
+// +-65504 / 16 = 4094 the fp16 planes saturate and the conv would be silently wrong).  ALWAYS ON since round 4: the
+// kernels raise a host-mapped flag, which costs no synchronisation - the flag is looked at when the next vocoder / generator call
+// of this handle starts (and reported then: "the previous call saturated").  dtts_set_option "x3_range_check" 1 / DTTS_X3_RANGE_CHECK=1
+// additionally reads it at the END of the generator, which synchronises the stream; DTTS_X3_RANGE_CHECK=0 switches the check off.
 int* Model::x3_sat_flag(hipStream_t s) {
-    static const bool env_on = []() { const char* v = getenv("DTTS_X3_RANGE_CHECK"); return v && v[0] == '1'; }();
-    if (env_on) opt_range_check_ = true;
-    if (!opt_range_check_) return nullptr;
-    if (!x3_sat_) DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&x3_sat_), sizeof(int)));
-    DTTS_CHECK_HIP(hipMemsetAsync(x3_sat_, 0, sizeof(int), s));
-    return x3_sat_;
+    static const int env = []() { const char* v = getenv("DTTS_X3_RANGE_CHECK"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
+    (void)s;
+    if (env == 1) opt_range_check_ = true;
+    if (env == 0 && !opt_range_check_) {
+        x3_sat_dev_ = nullptr;
+        return nullptr;
+    }
+    if (!x3_sat_) {
+        DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&x3_sat_), sizeof(int), hipHostMallocMapped));
+        *x3_sat_ = 0;
+        DTTS_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&x3_sat_dev_), x3_sat_, 0));
+    }
+    x3_sat_report(false);                   // a saturation of an EARLIER call (no synchronisation)
+    return x3_sat_dev_;
+}
+
+void Model::x3_sat_report(bool this_call) {
+    if (!x3_sat_ || !*x3_sat_) return;
+    *x3_sat_ = 0;
+    throw Error(-5, std::string("vocoder: an activation exceeds the range of the split-precision planes (|x| > 4094) - the ResBlock1 convs of ") +
+                        (this_call ? "this call" : "the PREVIOUS vocoder call of this handle") +
+                        " saturated; rerun with dtts_set_option(\"conv_x3\", 0) or DTTS_VOC_X3=0 (exact fp32 kernels)");
 }
 
 void Model::x3_sat_check(hipStream_t s) {
     if (!opt_range_check_ || !x3_sat_) return;
-    int flag = 0;
-    DTTS_CHECK_HIP(hipMemcpyAsync(&flag, x3_sat_, sizeof(int), hipMemcpyDeviceToHost, s));
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
-    if (flag)
-        throw Error(-5, "vocoder: an activation exceeds the range of the split-precision planes (|x| > 4094): the wide ResBlock1 convs "
-                        "saturated - rerun with dtts_set_option(\"conv_x3\", 0) or DTTS_VOC_X3=0 (exact fp32 kernels)");
+    x3_sat_report(true);
 }
 
 bool Model::vocoder_x3() const {

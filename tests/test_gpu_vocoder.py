@@ -288,3 +288,20 @@ def test_unit_wn_vs_oracle(rt, weights, flow):
         ref = V.wn(weights, f"flow.flows.{2 * flow}.enc", h[b:b + 1, :, :L], mf, g[b:b + 1, :, None])[0]
         assert maxabs(out[b, :, :L], ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), (flow, b)
         assert np.all(out[b, :, L:] == 0)
+
+
+def test_range_check_is_on_by_default_and_reports_at_the_next_call(weights):
+    """Without any option the kernels still raise the (host-mapped) saturation flag; no synchronisation is added, so the error surfaces
+    when the NEXT vocoder-side call of the handle starts - a saturated conv can no longer pass silently."""
+    from detail_tts_amd.runtime import DttsError, Runtime
+    rt2 = Runtime(weights, folded=True, parts=("vocoder",))
+    rs = np.random.RandomState(71)
+    x = (rs.randn(1, 200, 160) * 0.5).astype(np.float32)
+    ok = host(rt2.op_resblock1(0, 1, dev(x)))
+    bad = x.copy()
+    bad[0, 17, 40] = 5000.0
+    host(rt2.op_resblock1(0, 1, dev(bad)))             # saturates; returns (nothing synchronises on the flag here)
+    torch.cuda.synchronize()
+    with pytest.raises(DttsError, match="PREVIOUS vocoder call"):
+        rt2.op_resblock1(0, 1, dev(x))
+    assert np.array_equal(host(rt2.op_resblock1(0, 1, dev(x))), ok)      # the flag is cleared once reported
