@@ -450,12 +450,37 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
         if (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (KW3 ? 3 : 5)) : "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(a, bb, SWc, SXc, TAPc);
+        constexpr bool ASM_READS = NSTG >= 3;          // (the 2-stage instantiations live on 168 VGPRs: the wider live ranges would spill)
+        if (!ASM_READS) read_frags(a, bb, SWc, SXc, TAPc);
+        else {
+            // Fragments in the order the MFMA groups below consume them (low-plane A 0 + high-plane X 0..2 | low A 1 | high A 0 + low
+            // X 0..2 | high A 1), read by hand-written ds_read_b128 with COUNTED lgkmcnt waits in front of each group: the first group
+            // starts when 4 of the 10 reads have landed.  (Compiler-issued reads always get `s_waitcnt lgkmcnt(0)` in front of the first
+            // MFMA in this loop - the LDS-DMA traffic makes its wait insertion conservative - and with one wave per SIMD nothing else
+            // covers the ~10 x 1 KiB of LDS return time.)  The waits carry the fragment registers as in/out operands, so no use can be
+            // scheduled in front of its wait; an in-flight MFMA has read its operands long before a read issued after it returns.
+            const unsigned as_addr = (unsigned)(SWc * WTILE) + lhi * (BM * 16) + (wm0 + l31) * 16;
+            const unsigned xb_addr = (unsigned)(XOFF + SXc * XBUF);
+            auto rd = [&](hf8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+            auto a_addr = [&](int i, int pl) { return as_addr + pl * (2 * BM * 16) + i * 32 * 16; };
+            auto x_addr = [&](int j, int pl) {
+                const int nn = wn0 + j * 32 + l31 + TAPc;
+                return nn < BN ? xb_addr + lhi * (BN * 16) + nn * 16 + pl * (2 * BN * 16) : xb_addr + XMAIN + lhi * 32 + (nn - BN) * 16 + pl * 64;
+            };
+            rd(a[0][1], a_addr(0, 1)); rd(bb[0][0], x_addr(0, 0)); rd(bb[1][0], x_addr(1, 0)); rd(bb[2][0], x_addr(2, 0));
+            rd(a[1][1], a_addr(1, 1));
+            rd(a[0][0], a_addr(0, 0)); rd(bb[0][1], x_addr(0, 1)); rd(bb[1][1], x_addr(1, 1)); rd(bb[2][1], x_addr(2, 1));
+            rd(a[1][0], a_addr(1, 0));
+        }
         int slot = 0;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                if (ASM_READS && t == 0 && i == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][1]), "+v"(bb[0][0]), "+v"(bb[1][0]), "+v"(bb[2][0]));
+                if (ASM_READS && t == 0 && i == 1) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a[1][1]));
+                if (ASM_READS && t == 1 && i == 0) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[0][0]), "+v"(bb[0][1]), "+v"(bb[1][1]), "+v"(bb[2][1]));
+                if (ASM_READS && t == 1 && i == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]));
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], bb[j][TB[t]], acc[i][j], 0, 0, 0);
                 if (slot < 5) {

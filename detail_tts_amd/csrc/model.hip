@@ -103,8 +103,10 @@ const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
         if (g == r.seg && r.off != (size_t)g * seg_ints) continue;        // still inside the segment we are filling
         if (g != r.seg || r.off == (size_t)g * seg_ints) {               // entering segment g: retire its previous lap
             for (hipStream_t u : r.users[g]) {
-                DTTS_CHECK_HIP(hipEventRecord(r.ev, u));
-                DTTS_CHECK_HIP(hipEventSynchronize(r.ev));
+                // a stream the caller has destroyed since is retired by definition (hipStreamDestroy completes its work): the
+                // record fails with an invalid-handle error, which must not surface in an unrelated later call
+                if (hipEventRecord(r.ev, u) == hipSuccess) DTTS_CHECK_HIP(hipEventSynchronize(r.ev));
+                else (void)hipGetLastError();
             }
             r.users[g].clear();
             r.seg = g;
