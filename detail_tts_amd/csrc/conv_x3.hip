@@ -504,8 +504,9 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
         }
     };
     auto uperiod = [&](auto... kc) { (ustep(kc), ...); };
-    // measured at the bench's 240-tile launches (tools/bench_forward.py): k = 3 89.9 -> 80.8 us (- 10 %), qkv conv 84.5 -> 82.9, the 1 x 1
-    // convs of the ResBlock / proj 38.2 -> 39.1 (+ 2 %: they keep the generic loop)
+    // measured at the bench's 240-tile launches (tools/bench_forward.py): k = 3 85.3 -> 75.6 us (- 11 %, of which the hand-written
+    // fragment reads 1.5), qkv conv 75.7 -> 75.0; the 1 x 1 convs of the ResBlock / proj 34.8 -> 36.7 (+ 5 %: five pieces per step -
+    // they keep the generic loop)
     constexpr bool UNROLL = KW3 || EPI == 2;
     if (UNROLL && !(p.ablate & 512)) {
         // whole periods while every step of the period (and the D steps it issues ahead) lies inside the loop
