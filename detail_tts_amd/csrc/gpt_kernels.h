@@ -135,6 +135,8 @@ struct GptTokenParams {
     unsigned* epoch;                 // launch counter (>= 1), bumped by the kernel
     long long* trace;                // debug: wall-clock stamps (DTTS_GPT_TOKEN_TRACE), normally null
     int exclusive_cu;                // ask for a CU's whole LDS: one token workgroup per CU, no LDS-using workgroup next to it
+    int prio;                        // s_setprio 3 for the kernel's waves (default 1)
+    int poll_nap;                    // extra sleep rounds between two polls of an exchange word (default 0)
 };
 bool gpt_token_supported(int C, int H, int F, int NL, int V);
 bool gpt_token_prepare();            // device check + kernel attributes at bind time; false = use the chain

@@ -120,7 +120,12 @@ __device__ __forceinline__ void q_store(const Xch& x, int q, float a, float b, f
 struct PollState {
     int* err;
     bool dead;
+    int nap;              // extra s_sleep rounds between two polls (0: poll as fast as possible; stage A has slack under the pipeline)
 };
+__device__ __forceinline__ void poll_nap(const PollState& ps) {
+    __builtin_amdgcn_s_sleep(1);
+    for (int i = 0; i < ps.nap; ++i) __builtin_amdgcn_s_sleep(8);
+}
 
 // 8 quads idx(i): all loads in flight at once; while any of them is stale, all are read again
 template <class F>
@@ -139,7 +144,7 @@ __device__ __forceinline__ void q_poll8(const Xch& x, F idx, unsigned tag, float
             *ps.err = 1;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        poll_nap(ps);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -159,7 +164,7 @@ __device__ __forceinline__ void q_poll1(const Xch& x, int q, unsigned tag, float
             *ps.err = 1;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        poll_nap(ps);
     }
     out[0] = __uint_as_float(v.x);
     out[1] = __uint_as_float(v.y);
@@ -301,12 +306,12 @@ __device__ __forceinline__ float gelu_new(float v) {
 
 __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) {
 #ifndef DTTS_TOKEN_NO_SETPRIO                              // (diagnostic builds only: tools/diag_token_pk.py)
-    __builtin_amdgcn_s_setprio(3);                        // under the diffusion trunk: this latency chain's waves issue ahead of the resident conv waves
+    if (p.prio) __builtin_amdgcn_s_setprio(3);                        // under the diffusion trunk: this latency chain's waves issue ahead of the resident conv waves
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
     const int tid_k = threadIdx.x, w = blockIdx.x;
-    PollState ps{p.err, false};
+    PollState ps{p.err, false, p.poll_nap};
     if (*p.err) return;                                   // a timed-out session stays dead (no 0.3 s of spinning per token)
     const unsigned epoch = *p.epoch;
     const GptCtl* ctl = p.ctl;

@@ -395,7 +395,10 @@ private:
         int seg = 0;
         std::vector<hipStream_t> users[SEGS];   // streams whose launches read tables of this segment (current lap)
         hipEvent_t ev = nullptr;
+        unsigned long long last_use = 0;
     };
+    static constexpr size_t MAX_INT_RINGS = 16;      // rings of host threads that are gone are recycled, not leaked
+    unsigned long long ring_clock_ = 0;
     std::map<std::thread::id, std::unique_ptr<IntRing>> int_rings_;
     std::mutex ints_mu_;        // guards the map only; a ring is touched by its own thread
     IntRing& int_ring();

@@ -78,9 +78,31 @@ Model::~Model() {
 
 Model::IntRing& Model::int_ring() {
     std::lock_guard<std::mutex> lk(ints_mu_);
-    auto& slot = int_rings_[std::this_thread::get_id()];
+    const auto me = std::this_thread::get_id();
+    auto it = int_rings_.find(me);
+    if (it == int_rings_.end() && int_rings_.size() >= MAX_INT_RINGS) {
+        // hand the least recently used ring (most likely a finished thread's) to this thread: retire every segment of it first
+        auto lru = int_rings_.begin();
+        for (auto j = int_rings_.begin(); j != int_rings_.end(); ++j)
+            if (j->second->last_use < lru->second->last_use) lru = j;
+        std::unique_ptr<IntRing> r = std::move(lru->second);
+        int_rings_.erase(lru);
+        for (auto& us : r->users) {
+            for (hipStream_t u : us) {
+                if (hipEventRecord(r->ev, u) == hipSuccess) DTTS_CHECK_HIP(hipEventSynchronize(r->ev));
+                else (void)hipGetLastError();
+            }
+            us.clear();
+        }
+        r->off = 0;
+        r->seg = 0;
+        int_rings_[me] = std::move(r);
+    }
+    auto& slot = int_rings_[me];
+    if (slot) slot->last_use = ++ring_clock_;
     if (!slot) {
         slot.reset(new IntRing());
+        slot->last_use = ++ring_clock_;
         DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&slot->dev), INT_RING_BYTES));
         DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot->pinned), INT_RING_BYTES, hipHostMallocDefault));
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));

@@ -392,6 +392,10 @@ void Model::gpt_step_launches(hipStream_t s) {
         p.epoch = gs_.tok_epoch;
         static const int env_excl = []() { const char* v = getenv("DTTS_GPT_TOKEN_EXCLUSIVE_CU"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
         p.exclusive_cu = env_excl >= 0 ? env_excl : (opt_tok_exclusive_ ? 1 : 0);
+        static const int env_prio = []() { const char* v = getenv("DTTS_GPT_TOKEN_PRIO"); return v ? atoi(v) : 1; }();
+        static const int env_nap = []() { const char* v = getenv("DTTS_GPT_TOKEN_NAP"); return v ? atoi(v) : 0; }();
+        p.prio = env_prio;
+        p.poll_nap = env_nap;
         if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)
             const int one = 1;
             DTTS_CHECK_HIP(hipMemcpyAsync(gs_.tok_err, &one, sizeof(int), hipMemcpyHostToDevice, s));

@@ -362,9 +362,25 @@ class SynthesizerTrn:
         # Stage A is issued from its own host thread: a kernel-launch call blocks once its stream's hardware queue is full, so one
         # thread could not enqueue request i+1's decode (12 K launches) while it is still feeding request i's diffusion (10 K).  The
         # library supports exactly this split (include/detail_hip.h, "Threads"); ctypes releases the GIL inside the calls.
+        skip_state = {"i": 0, "last": None}
+
         def stage_a(group):
             torch.cuda.set_device(dev)
-            return finish_a(launch_a(group))
+            # DTTS_EXPERIMENT_SKIP_A=1 (measurement only, results are NOT valid synthesis): every second request reuses the previous
+            # request's codes / latents instead of running stage A - an upper bound on what halving stage A's work could give stage B
+            if os.environ.get("DTTS_EXPERIMENT_SKIP_A") == "1":
+                skip_state["i"] += 1
+                if skip_state["i"] % 2 == 0 and skip_state["last"] is not None and len(group) == 1:
+                    prev = skip_state["last"][0]
+                    st = parse(group[0])
+                    if st["B"] == prev["B"]:
+                        with torch.cuda.stream(sa):
+                            st["refer"] = torch.as_tensor(st.pop("refer_in")).to(dev, torch.float32).contiguous()
+                        st.update(gen=None, tr=None, lat=prev["lat"], n=prev["n"], a_done=prev["a_done"])
+                        return [st]
+            out = finish_a(launch_a(group))
+            skip_state["last"] = out
+            return out
 
         # requests -> stage-A groups: with pair_stage_a (or DTTS_PAIR_STAGE_A=1) two consecutive requests of <= 8 utterances share a decode
         # session.  Off by default: a 16-row decode step costs 1.6x an 8-row one (161 vs 103 ms per 234 tokens alone), and under the

@@ -305,3 +305,23 @@ def test_range_check_is_on_by_default_and_reports_at_the_next_call(weights):
     with pytest.raises(DttsError, match="PREVIOUS vocoder call"):
         rt2.op_resblock1(0, 1, dev(x))
     assert np.array_equal(host(rt2.op_resblock1(0, 1, dev(x))), ok)      # the flag is cleared once reported
+
+
+def test_calls_from_many_short_lived_host_threads(rt):
+    """Every host thread that calls in gets its own pinned upload ring; rings of threads that are gone are recycled (at most 16 per
+    handle) instead of accumulating.  24 threads, one after the other, each with lengths to upload: same result every time."""
+    import threading
+    rs = np.random.RandomState(72)
+    mel = dev((rs.randn(2, 128, 40) * 2 - 5).astype(np.float32))
+    ref = host(rt.mel_style("ref_enc", mel, [40, 31]))
+    outs = []
+
+    def work():
+        torch.cuda.set_device(0)
+        outs.append(host(rt.mel_style("ref_enc", mel, [40, 31])))
+
+    for _ in range(24):
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+    assert len(outs) == 24 and all(np.array_equal(o, ref) for o in outs)
