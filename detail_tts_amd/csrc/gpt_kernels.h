@@ -109,7 +109,8 @@ void launch_sampler(const SamplerParams& p, hipStream_t s);
 constexpr int GPT_TOKEN_WGS = 128;
 constexpr int GPT_TOKEN_MAX_LAYERS = 12;
 constexpr int GPT_TOKEN_VS = 66 * GPT_TOKEN_WGS;                     // logits row stride (mel_head columns padded to 66 per workgroup)
-constexpr int GPT_TOKEN_XCH_WORDS = 2 * (8 * 256 * 6 + 128 * 128 * 16);      // exchange arena in 8-byte units (it is addressed in 16-byte words)
+constexpr int GPT_TOKEN_ROWS = 16;                                   // rows of a session the token kernel covers (two instantiations: 8 and 16)
+constexpr int GPT_TOKEN_XCH_WORDS = 2 * (16 * 256 * 6 + 128 * 128 * 32);     // exchange arena of a 16-row session in 8-byte units (addressed in 16-byte words)
 struct GptTokenLayer {
     const float4 *wq, *wp, *wf;      // c_attn / attention c_proj / c_fc repacked in register order (launch_gpt_token_pack 0 / 1 / 2)
     const float* w2;                 // mlp c_proj, K-major [3072][768] as bound

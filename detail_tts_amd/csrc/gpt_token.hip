@@ -66,22 +66,30 @@ static_assert(255 / P_PN + P_KL * (P_KT - 1) < KP && 255 / Q_PN + Q_KL * (Q_KT -
                   255 / H_PN + H_KL * (H_KT - 1) < KP, "LDS activation tile");
 
 // exchange arena, in 16-byte words ("quads": 3 consecutive columns of one row + tag)
+// Everything below is written for NR rows per session, NR = 8 (round 3) or 16 (round 4: two requests of 8 utterances decoded as ONE
+// session - the weights stream once per token for both).  Per row the arithmetic and the order of every sum are the same in both
+// instantiations, so a row's latents do not depend on which one produced them.
 constexpr int XQ = TC / 3;                     // quads per row of a 768-wide buffer
-constexpr int X_OFF = 0, QKV_OFF = X_OFF + 8 * XQ, AT_OFF = QKV_OFF + 8 * 3 * XQ, Y_OFF = AT_OFF + 8 * XQ, RS_OFF = Y_OFF + 8 * XQ;
-constexpr int RS_PER = 8 * NP;                // values one source sends one owner: 6 columns x 8 rows, [column][row]
-constexpr int RS_Q = RS_PER / 3;              // = 16 quads
-constexpr int XCH_QUADS = RS_OFF + TG * TG * RS_Q;
-static_assert(2 * XCH_QUADS == GPT_TOKEN_XCH_WORDS, "exchange arena size");
+template <int NR>
+struct Geo {
+    static constexpr int X_OFF = 0, QKV_OFF = X_OFF + NR * XQ, AT_OFF = QKV_OFF + NR * 3 * XQ, Y_OFF = AT_OFF + NR * XQ, RS_OFF = Y_OFF + NR * XQ;
+    static constexpr int RS_PER = NR * NP;        // values one source sends one owner: 6 columns x NR rows, [column][row]
+    static constexpr int RS_Q = RS_PER / 3;       // 16 / 32 quads
+    static constexpr int XCH_QUADS = RS_OFF + TG * TG * RS_Q;
+    static constexpr int RED = NR == 8 ? 6144 : 12288;      // floats of the `red` scratch
+};
+static_assert(2 * Geo<16>::XCH_QUADS == GPT_TOKEN_XCH_WORDS && Geo<8>::XCH_QUADS < Geo<16>::XCH_QUADS, "exchange arena size");
 
-struct Smem {
-    float4 xs[2][KP];            // activation tile [row quad][k]: rows 0-3 | rows 4-7 of input k   (P2: the PV partials)
-    float red[6144];             // k-lane partials of a column GEMV | gathered mlp partials | attention scores
+template <int NR>
+struct SmemT {
+    float4 xs[NR / 4][KP];       // activation tile [row quad][k]: rows 4 q .. 4 q + 3 of input k   (P2: the PV partials)
+    float red[Geo<NR>::RED];     // k-lane partials of a column GEMV | gathered mlp partials | attention scores
     float qkv[3][TD];
-    float hs[NF][8];             // gelu(c_fc) of this workgroup's 24 columns, [column][row]
-    float own_x[RS_PER], own_y[RS_PER];      // residual rows of the 6 columns this workgroup owns
-    float st1[8][4], st2[8][4];  // LayerNorm: per-row wave partials
-    float part[4][RS_PER];
-    float oq[8 * NQ];            // a phase's outputs, regrouped into triples before they are stored
+    float hs[NF][NR];            // gelu(c_fc) of this workgroup's 24 columns, [column][row]
+    float own_x[Geo<NR>::RS_PER], own_y[Geo<NR>::RS_PER];      // residual rows of the 6 columns this workgroup owns
+    float st1[NR][4], st2[NR][4];  // LayerNorm: per-row wave partials
+    float part[4][Geo<NR>::RS_PER];
+    float oq[NR * NF];           // a phase's outputs, regrouped into triples before they are stored
     float mred[4], lred[4];
 };
 static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials alias the activation tile");
@@ -97,7 +105,7 @@ static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials a
 // (option "gpt_token_exclusive_cu" / DTTS_GPT_TOKEN_EXCLUSIVE_CU, see DESIGN.md for the measured choice); the stress tests run both
 // settings next to LDS kernels, zero-LDS kernels and the vocoder (tests/test_gpu_e2e.py::test_token_kernel_under_concurrent_*).
 constexpr int LDS_EXCLUSIVE = 160 * 1024;
-static_assert(sizeof(Smem) <= 64 * 1024, "LDS");
+static_assert(sizeof(SmemT<8>) <= 64 * 1024 && sizeof(SmemT<16>) <= 128 * 1024, "LDS");
 
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
@@ -128,16 +136,16 @@ __device__ __forceinline__ void poll_nap(const PollState& ps) {
 }
 
 // 8 quads idx(i): all loads in flight at once; while any of them is stale, all are read again
-template <class F>
-__device__ __forceinline__ void q_poll8(const Xch& x, F idx, unsigned tag, float (&out)[8][3], PollState& ps) {
-    u4v v[8];
+template <int N, class F>
+__device__ __forceinline__ void q_poll8(const Xch& x, F idx, unsigned tag, float (&out)[N][3], PollState& ps) {
+    u4v v[N];
     int spins = 0;
     for (;;) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(x.rs, idx(i) * 16, 0, AUX_SC1);
+        for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(x.rs, idx(i) * 16, 0, AUX_SC1);
         unsigned bad = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bad |= v[i].w ^ tag;
+        for (int i = 0; i < N; ++i) bad |= v[i].w ^ tag;
         if (bad == 0 || ps.dead) break;
         if (++spins > SPIN_LIMIT) {
             ps.dead = true;
@@ -147,7 +155,7 @@ __device__ __forceinline__ void q_poll8(const Xch& x, F idx, unsigned tag, float
         poll_nap(ps);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
         out[i][0] = __uint_as_float(v[i].x);
         out[i][1] = __uint_as_float(v[i].y);
         out[i][2] = __uint_as_float(v[i].z);
@@ -186,8 +194,9 @@ __device__ __forceinline__ float wsum8(const float (&s)[8], int lane) {
     return w;
 }
 
-// LayerNorm of 8 rows of 768 (thread: columns 3 tid .. 3 tid + 2), two-pass statistics
-__device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ g, const float* __restrict__ be, Smem& sm, int tid) {
+// LayerNorm of NR rows of 768 (thread: columns 3 tid .. 3 tid + 2), two-pass statistics; rows 8 h .. 8 h + 7 go through one wsum8 each
+template <int NR>
+__device__ __forceinline__ void ln8(float (&v)[NR][3], const float* __restrict__ g, const float* __restrict__ be, SmemT<NR>& sm, int tid) {
     const int lane = tid & 63, wave = (tid >> 6) & 3;
     float gg[3], bb[3];
 #pragma unroll
@@ -195,28 +204,35 @@ __device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ 
         gg[m] = GLOBAL_PTR(float, g)[3 * tid + m];
         bb[m] = GLOBAL_PTR(float, be)[3 * tid + m];
     }
-    float s[8];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) s[b] = (v[b][0] + v[b][1]) + v[b][2];
-    float w = wsum8(s, lane);
-    if ((lane & 7) == 0) sm.st1[(lane >> 3) & 7][wave] = w;
+    for (int h = 0; h < NR / 8; ++h) {
+        float s[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) s[b] = (v[8 * h + b][0] + v[8 * h + b][1]) + v[8 * h + b][2];
+        const float w = wsum8(s, lane);
+        if ((lane & 7) == 0) sm.st1[8 * h + ((lane >> 3) & 7)][wave] = w;
+    }
     __syncthreads();
-    float mean[8];
+    float mean[NR];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NR; ++b) {
         const float4 p = *reinterpret_cast<const float4*>(sm.st1[b]);
         mean[b] = ((p.x + p.y) + (p.z + p.w)) * (1.f / TC);
     }
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const float d0 = v[b][0] - mean[b], d1 = v[b][1] - mean[b], d2 = v[b][2] - mean[b];
-        s[b] = (d0 * d0 + d1 * d1) + d2 * d2;
+    for (int h = 0; h < NR / 8; ++h) {
+        float s[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const float d0 = v[8 * h + b][0] - mean[8 * h + b], d1 = v[8 * h + b][1] - mean[8 * h + b], d2 = v[8 * h + b][2] - mean[8 * h + b];
+            s[b] = (d0 * d0 + d1 * d1) + d2 * d2;
+        }
+        const float w = wsum8(s, lane);
+        if ((lane & 7) == 0) sm.st2[8 * h + ((lane >> 3) & 7)][wave] = w;
     }
-    w = wsum8(s, lane);
-    if ((lane & 7) == 0) sm.st2[(lane >> 3) & 7][wave] = w;
     __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NR; ++b) {
         const float4 p = *reinterpret_cast<const float4*>(sm.st2[b]);
         const float rstd = rsqrtf(((p.x + p.y) + (p.z + p.w)) * (1.f / TC) + 1e-5f);
 #pragma unroll
@@ -225,12 +241,13 @@ __device__ __forceinline__ void ln8(float (&v)[8][3], const float* __restrict__ 
 }
 
 // rows (thread: columns k = 3 tid + m) -> LDS activation tile
-__device__ __forceinline__ void rows_to_tile(const float (&v)[8][3], Smem& sm, int tid) {
+template <int NR>
+__device__ __forceinline__ void rows_to_tile(const float (&v)[NR][3], SmemT<NR>& sm, int tid) {
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const int k = 3 * tid + m;
-        sm.xs[0][k] = make_float4(v[0][m], v[1][m], v[2][m], v[3][m]);
-        sm.xs[1][k] = make_float4(v[4][m], v[5][m], v[6][m], v[7][m]);
+#pragma unroll
+        for (int q = 0; q < NR / 4; ++q) sm.xs[q][k] = make_float4(v[4 * q][m], v[4 * q + 1][m], v[4 * q + 2][m], v[4 * q + 3][m]);
     }
 }
 
@@ -253,50 +270,58 @@ __device__ __forceinline__ void wload(float4 (&wr)[KT / 2], const float4* base, 
 }
 
 // column GEMV on the LDS tile with the weight slice in registers (wr[i] = {W[k0][c], W[k0][c + 1], W[k1][c], W[k1][c + 1]},
-// k0 = kl + KL 2 i, k1 = k0 + KL, c = 2 q): returns out[b * NC + col] for o = b * NC + col = tid (< 8 NC)
-template <int PN, int KL, int KT>
-__device__ __forceinline__ float col_gemv(const float4 (&wr)[KT / 2], Smem& sm, int tid) {
-    constexpr int NC = 2 * PN;
-    static_assert(8 * NC <= 256 && KL * 8 * NC <= 6144 && KT % 2 == 0, "col_gemv");
+// k0 = kl + KL 2 i, k1 = k0 + KL, c = 2 q): out[j] = result o = tid + 256 j of the NR x NC outputs, o = b * NC + col
+template <int NR, int PN, int KL, int KT>
+__device__ __forceinline__ void col_gemv(const float4 (&wr)[KT / 2], SmemT<NR>& sm, int tid, float (&out)[(NR * 2 * PN + 255) / 256]) {
+    constexpr int NC = 2 * PN, NO = (NR * NC + 255) / 256;
+    static_assert(KL * NR * NC <= Geo<NR>::RED && KT % 2 == 0, "col_gemv");
     const int q = tid % PN, kl = tid / PN;
-    float acc[8][2];
+    float acc[NR][2];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[b][0] = acc[b][1] = 0.f;
+    for (int b = 0; b < NR; ++b) acc[b][0] = acc[b][1] = 0.f;
 #pragma unroll
     for (int i = 0; i < KT / 2; ++i) {
         const int k0 = kl + KL * 2 * i, k1 = k0 + KL;
-        const float4 xa = sm.xs[0][k0], xb = sm.xs[1][k0], ya = sm.xs[0][k1], yb = sm.xs[1][k1];
         const float4 w = wr[i];
-        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-        const float y[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            acc[b][0] += x[b] * w.x;
-            acc[b][1] += x[b] * w.y;
-            acc[b][0] += y[b] * w.z;
-            acc[b][1] += y[b] * w.w;
+        for (int rq = 0; rq < NR / 4; ++rq) {
+            const float4 xa = sm.xs[rq][k0], ya = sm.xs[rq][k1];
+            const float x[4] = {xa.x, xa.y, xa.z, xa.w};
+            const float y[4] = {ya.x, ya.y, ya.z, ya.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = 4 * rq + e;
+                acc[b][0] += x[e] * w.x;
+                acc[b][1] += x[e] * w.y;
+                acc[b][0] += y[e] * w.z;
+                acc[b][1] += y[e] * w.w;
+            }
         }
     }
     if (kl < KL) {
-        float* r = sm.red + kl * (8 * NC) + q * 2;
+        float* r = sm.red + kl * (NR * NC) + q * 2;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) *reinterpret_cast<float2*>(r + b * NC) = make_float2(acc[b][0], acc[b][1]);
+        for (int b = 0; b < NR; ++b) *reinterpret_cast<float2*>(r + b * NC) = make_float2(acc[b][0], acc[b][1]);
     }
     __syncthreads();
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (tid < 8 * NC) {
-        const float* r = sm.red + tid;
-        int i = 0;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int o = tid + 256 * j;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (o < NR * NC) {
+            const float* r = sm.red + o;
+            int i = 0;
 #pragma unroll 4
-        for (; i + 4 <= KL; i += 4) {
-            a0 += r[(i + 0) * (8 * NC)];
-            a1 += r[(i + 1) * (8 * NC)];
-            a2 += r[(i + 2) * (8 * NC)];
-            a3 += r[(i + 3) * (8 * NC)];
+            for (; i + 4 <= KL; i += 4) {
+                a0 += r[(i + 0) * (NR * NC)];
+                a1 += r[(i + 1) * (NR * NC)];
+                a2 += r[(i + 2) * (NR * NC)];
+                a3 += r[(i + 3) * (NR * NC)];
+            }
+            for (; i < KL; ++i) a0 += r[i * (NR * NC)];
         }
-        for (; i < KL; ++i) a0 += r[i * (8 * NC)];
+        out[j] = (a0 + a1) + (a2 + a3);
     }
-    return (a0 + a1) + (a2 + a3);
 }
 
 __device__ __forceinline__ float gelu_new(float v) {
@@ -304,7 +329,11 @@ __device__ __forceinline__ float gelu_new(float v) {
     return 0.5f * v * (1.f + tanhf(u));
 }
 
+template <int NR>
 __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) {
+    typedef Geo<NR> G;
+    typedef SmemT<NR> Smem;
+    constexpr int RS_PER = G::RS_PER, RS_Q = G::RS_Q;
 #ifndef DTTS_TOKEN_NO_SETPRIO                              // (diagnostic builds only: tools/diag_token_pk.py)
     if (p.prio) __builtin_amdgcn_s_setprio(3);                        // under the diffusion trunk: this latency chain's waves issue ahead of the resident conv waves
 #endif
@@ -316,22 +345,19 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
     const unsigned epoch = *p.epoch;
     const GptCtl* ctl = p.ctl;
     const int B = p.B;
-    const Xch xc{__builtin_amdgcn_make_buffer_rsrc(p.xch, (short)0, XCH_QUADS * 16, 0x00020000)};
-    constexpr int XB = X_OFF, QB = QKV_OFF, AB = AT_OFF, YB = Y_OFF, RB = RS_OFF;      // quad offsets of the buffers in the arena
+    const Xch xc{__builtin_amdgcn_make_buffer_rsrc(p.xch, (short)0, G::XCH_QUADS * 16, 0x00020000)};
+    constexpr int XB = G::X_OFF, QB = G::QKV_OFF, AB = G::AT_OFF, YB = G::Y_OFF, RB = G::RS_OFF;      // quad offsets of the buffers in the arena
 
     for (int k = TC + tid_k; k < KP; k += 256) {
-        sm.xs[0][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sm.xs[1][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < NR / 4; ++q) sm.xs[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // this workgroup's attention work item
-    const int ah = w >> 3, ab = w & 7;
-    const bool arow = ab < B;
-    const int an = arow ? ctl->lp[ab] + ctl->step[ab] : 1;        // keys including the new one
-    const int ncach = an - 1;
+    // this workgroup's attention work items: head w / 8, rows w % 8 (+ 8 for a 16-row session: two items, one after the other)
+    const int ah = w >> 3;
 
     float4 wq[Q_KT / 2];
     wload<Q_KT>(wq, p.L[0].wq + (size_t)w * (Q_KT / 2) * 256, tid_k);
-    if (tid_k < 16) {                                     // layer 0's input (the sampler's plain rows) enters the same exchange as every other layer's
+    if (tid_k < 2 * NR) {                                 // layer 0's input (the sampler's plain rows) enters the same exchange as every other layer's
         const int b = tid_k >> 1, h = tid_k & 1;
         const float* x = p.x_in + b * TC + NP * w + 3 * h;
         q_store(xc, XB + b * XQ + 2 * w + h, b < B ? x[0] : 0.f, b < B ? x[1] : 0.f, b < B ? x[2] : 0.f, epoch << 4);
@@ -347,19 +373,23 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         const unsigned tag = (epoch << 4) | (unsigned)l;
         // small per-thread constants of the layer, loaded BEFORE the bulk prefetches: vmcnt retires in order, so a bias load issued
         // behind a weight prefetch would wait for all of it
-        const float c_bq = tid < 8 * NQ ? GLOBAL_PTR(float, L.bq)[NQ * w + tid % NQ] : 0.f;
-        const float c_bf = tid < 8 * NF ? GLOBAL_PTR(float, L.bf)[NF * w + tid % NF] : 0.f;
+        constexpr int OQ = (NR * NQ + 255) / 256, OF = (NR * NF + 255) / 256;       // outputs per thread of the c_attn / c_fc GEMVs
+        float c_bq[OQ], c_bf[OF];
+#pragma unroll
+        for (int j = 0; j < OQ; ++j) c_bq[j] = tid + 256 * j < NR * NQ ? GLOBAL_PTR(float, L.bq)[NQ * w + (tid + 256 * j) % NQ] : 0.f;
+#pragma unroll
+        for (int j = 0; j < OF; ++j) c_bf[j] = tid + 256 * j < NR * NF ? GLOBAL_PTR(float, L.bf)[NF * w + (tid + 256 * j) % NF] : 0.f;
         const float c_bp = tid < RS_PER ? GLOBAL_PTR(float, L.bp)[NP * w + tid % NP] : 0.f;
         float c_b2[3];                                         // P5's output triples: thread (row tid / 2, columns 3 (tid % 2) .. + 2)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) c_b2[j] = tid < 16 ? GLOBAL_PTR(float, L.b2)[NP * w + 3 * (tid & 1) + j] : 0.f;
+        for (int j = 0; j < 3; ++j) c_b2[j] = tid < 2 * NR ? GLOBAL_PTR(float, L.b2)[NP * w + 3 * (tid & 1) + j] : 0.f;
         // ------------------------------------------------------------------------------------------------ P1: ln_1 + c_attn
-        float v[8][3];
+        float v[NR][3];
         q_poll8(xc, [&](int b) { return XB + b * XQ + tid; }, tag, v, ps);
         STAMP(0);
         if ((tid >> 1) == w) {                               // the 6 columns this workgroup owns: residual for P2b
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
+            for (int b = 0; b < NR; ++b)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) sm.own_x[b * NP + 3 * (tid & 1) + j] = v[b][j];
         }
@@ -367,15 +397,24 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         rows_to_tile(v, sm, tid);
         __syncthreads();
         STAMP(10);
-        const float rq = col_gemv<Q_PN, Q_KL, Q_KT>(wq, sm, tid);
+        float rq[OQ];
+        col_gemv<NR, Q_PN, Q_KL, Q_KT>(wq, sm, tid, rq);
         STAMP(11);
-        if (tid < 8 * NQ) sm.oq[tid] = rq + c_bq;
+#pragma unroll
+        for (int j = 0; j < OQ; ++j)
+            if (tid + 256 * j < NR * NQ) sm.oq[tid + 256 * j] = rq[j] + c_bq[j];
         __syncthreads();
-        if (tid < 8 * NQ / 3) {                               // 6 triples per row
+        if (tid < NR * NQ / 3) {                              // 6 triples per row
             const int b = tid / (NQ / 3), t3 = tid - b * (NQ / 3);
             const float* o = sm.oq + b * NQ + 3 * t3;
             q_store(xc, QB + b * (3 * XQ) + (NQ / 3) * w + t3, o[0], o[1], o[2], tag);
         }
+#pragma unroll 1
+        for (int it = 0; it < NR / 8; ++it) {                  // attention work item (head ah, row ab); a 16-row session has two per workgroup
+        const int ab = (w & 7) + 8 * it;
+        const bool arow = ab < B;
+        const int an = arow ? ctl->lp[ab] + ctl->step[ab] : 1;        // keys including the new one
+        const int ncach = an - 1;
         // prefetch for P2 / P2b: the cached keys of this (head, row), the c_proj slice.  K is channel-major with the keys contiguous:
         // thread (kq = tid / 4, cgp = tid % 4) holds channels [12 cgp, 12 cgp + 12) of the 4 consecutive keys 4 (kq + 64 u) .. + 3
         const float* cb = p.kv + (size_t)l * p.kv_layer + (size_t)ab * p.kv_bs;
@@ -540,6 +579,8 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         }
         __syncthreads();
         if (tid < TD / 3) q_store(xc, AB + ab * XQ + ah * (TD / 3) + tid, sm.oq[3 * tid], sm.oq[3 * tid + 1], sm.oq[3 * tid + 2], tag);
+        if (NR > 8) __syncthreads();                          // the item's LDS scratch (q / k / v, scores, PV partials, oq) is reused by the next one
+        }
         STAMP(3);
         // prefetch for P2b / P3: the c_proj and c_fc slices
         float4 wp[P_KT / 2];
@@ -552,10 +593,11 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         __syncthreads();                                       // the PV partials (aliasing the tile) have been consumed
         rows_to_tile(v, sm, tid);
         __syncthreads();
-        const float rp = col_gemv<P_PN, P_KL, P_KT>(wp, sm, tid);
-        if (tid < RS_PER) sm.own_y[tid] = rp + c_bp + sm.own_x[tid];
+        float rp[1];
+        col_gemv<NR, P_PN, P_KL, P_KT>(wp, sm, tid, rp);
+        if (tid < RS_PER) sm.own_y[tid] = rp[0] + c_bp + sm.own_x[tid];
         __syncthreads();
-        if (tid < 16) {
+        if (tid < 2 * NR) {
             const float* y = sm.own_y + (tid >> 1) * NP + 3 * (tid & 1);
             q_store(xc, YB + (tid >> 1) * XQ + 2 * w + (tid & 1), y[0], y[1], y[2], tag);
         }
@@ -567,7 +609,8 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         rows_to_tile(v, sm, tid);
         __syncthreads();
         STAMP(12);
-        const float rf = col_gemv<F_PN, F_KL, F_KT>(wf, sm, tid);
+        float rf[OF];
+        col_gemv<NR, F_PN, F_KL, F_KT>(wf, sm, tid, rf);
         STAMP(13);
         float w2[NF][3];                                        // rows [24 w, 24 w + 24) of the mlp c_proj, columns 3 tid .. 3 tid + 2 (12-byte loads)
         {
@@ -579,22 +622,30 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
                 w2[j][0] = t.x; w2[j][1] = t.y; w2[j][2] = t.z;
             }
         }
-        if (tid < 8 * NF) sm.hs[tid % NF][tid / NF] = gelu_new(rf + c_bf);
+#pragma unroll
+        for (int j = 0; j < OF; ++j) {
+            const int o = tid + 256 * j;
+            if (o < NR * NF) sm.hs[o % NF][o / NF] = gelu_new(rf[j] + c_bf[j]);
+        }
         __syncthreads();
         STAMP(14);
         {
-            float acc[8][3];
+            float acc[NR][3];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) acc[b][0] = acc[b][1] = acc[b][2] = 0.f;
+            for (int b = 0; b < NR; ++b) acc[b][0] = acc[b][1] = acc[b][2] = 0.f;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const float4 ha = *reinterpret_cast<const float4*>(&sm.hs[j][0]), hb = *reinterpret_cast<const float4*>(&sm.hs[j][4]);
-                const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    acc[b][0] += h[b] * w2[j][0];
-                    acc[b][1] += h[b] * w2[j][1];
-                    acc[b][2] += h[b] * w2[j][2];
+                for (int rq4 = 0; rq4 < NR / 4; ++rq4) {
+                    const float4 ha = *reinterpret_cast<const float4*>(&sm.hs[j][4 * rq4]);
+                    const float h[4] = {ha.x, ha.y, ha.z, ha.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int b = 4 * rq4 + e;
+                        acc[b][0] += h[e] * w2[j][0];
+                        acc[b][1] += h[e] * w2[j][1];
+                        acc[b][2] += h[e] * w2[j][2];
+                    }
                 }
             }
             STAMP(15);
@@ -602,16 +653,16 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             // that order for a fixed source), so that a wave's store instruction writes 64 consecutive 16-byte words: full 64-byte lines
             // (24 scattered 8-byte stores per thread cost 17 us per layer: every one a partial-line write-through).
             {
-                float* st = sm.red + 24 * tid;                 // columns 3 tid .. 3 tid + 2, 8 rows each
+                float* st = sm.red + 3 * NR * tid;             // columns 3 tid .. 3 tid + 2, NR rows each
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    *reinterpret_cast<float4*>(st + 8 * m) = make_float4(acc[0][m], acc[1][m], acc[2][m], acc[3][m]);
-                    *reinterpret_cast<float4*>(st + 8 * m + 4) = make_float4(acc[4][m], acc[5][m], acc[6][m], acc[7][m]);
-                }
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int rq4 = 0; rq4 < NR / 4; ++rq4)
+                        *reinterpret_cast<float4*>(st + NR * m + 4 * rq4) = make_float4(acc[4 * rq4][m], acc[4 * rq4 + 1][m], acc[4 * rq4 + 2][m], acc[4 * rq4 + 3][m]);
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int j = tid + 256 * i, owner = j / RS_Q;
                 const float* r = sm.red + 3 * j;
                 q_store(xc, RB + (owner * TG + w) * RS_Q + (j - owner * RS_Q), r[0], r[1], r[2], tag);
@@ -622,18 +673,18 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         STAMP(7);
         // ------------------------------------------------------------------------------------------------ P5: owner sum -> next X
         {
-            float f[8][3];
+            float f[NR][3];
             q_poll8(xc, [&](int i) { return RB + w * TG * RS_Q + tid + 256 * i; }, tag, f, ps);
             STAMP(8);
             __syncthreads();                                   // the transposed partials in `red` have been stored
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < NR; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) sm.red[3 * (tid + 256 * i) + j] = f[i][j];
         }
         __syncthreads();
-        if (tid < 4 * RS_PER) {                                // 4 groups of 32 sources, then the 4 group sums: a fixed order
-            const int o = tid % RS_PER, g = tid / RS_PER;
+        for (int og = tid; og < 4 * RS_PER; og += 256) {       // 4 groups of 32 sources, then the 4 group sums: a fixed order
+            const int o = og % RS_PER, g = og / RS_PER;
             const float* r = sm.red + (g * 32) * RS_PER + o;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 2
@@ -646,12 +697,12 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             sm.part[g][o] = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
-        if (tid < 16) {                                        // slot layout [column][row]; own_y is [row][column]
+        if (tid < 2 * NR) {                                    // slot layout [column][row]; own_y is [row][column]
             const int b = tid >> 1, h = tid & 1;
             float xn[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int c = 3 * h + j, o = c * 8 + b;
+                const int c = 3 * h + j, o = c * NR + b;
                 xn[j] = ((sm.part[0][o] + sm.part[1][o]) + (sm.part[2][o] + sm.part[3][o])) + c_b2[j] + sm.own_y[b * NP + c];
             }
             q_store(xc, XB + b * XQ + 2 * w + h, xn[0], xn[1], xn[2], ((epoch << 4) | (unsigned)(l + 1)));
@@ -664,14 +715,14 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         const int tid = tid_k, l = p.NL;
         float4 wh[H_KT / 2];
         wload<H_KT>(wh, p.wh + (size_t)(w * 3) * (H_KT / 2) * 256, tid);
-        float v[8][3];
+        float v[NR][3];
         q_poll8(xc, [&](int b) { return XB + b * XQ + tid; }, (epoch << 4) | (unsigned)p.NL, v, ps);
         STAMP(0);
         ln8(v, p.lnf_g, p.lnf_b, sm, tid);
         ln8(v, p.fin_g, p.fin_b, sm, tid);
         if (w == 0) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
+            for (int b = 0; b < NR; ++b)
                 if (b < B) {
                     const int step = ctl->step[b];
                     float* col = (ctl->latents && step < ctl->max_steps) ? ctl->latents + (long long)b * ctl->lat_bs + step : nullptr;
@@ -687,11 +738,17 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         __syncthreads();
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) {
-            const float rh = col_gemv<H_PN, H_KL, H_KT>(wh, sm, tid);
+            constexpr int OH = (NR * NH + 255) / 256;
+            float rh[OH];
+            col_gemv<NR, H_PN, H_KL, H_KT>(wh, sm, tid, rh);
             if (pass < 2) wload<H_KT>(wh, p.wh + (size_t)(w * 3 + pass + 1) * (H_KT / 2) * 256, tid);
-            if (tid < 8 * NH) {
-                const int b = tid / NH, c = 3 * NH * w + NH * pass + tid % NH;
-                if (b < B) p.logits[(size_t)b * p.Vs + c] = rh + p.bh[c];
+#pragma unroll
+            for (int j = 0; j < OH; ++j) {
+                const int o = tid + 256 * j;
+                if (o < NR * NH) {
+                    const int b = o / NH, c = 3 * NH * w + NH * pass + o % NH;
+                    if (b < B) p.logits[(size_t)b * p.Vs + c] = rh[j] + p.bh[c];
+                }
             }
             __syncthreads();                                   // `red` reads done before the next pass writes it
         }
@@ -735,18 +792,20 @@ bool gpt_token_supported(int C, int H, int F, int NL, int V) { return C == TC &&
 // into SPIN_LIMIT.  false -> the caller keeps the launch-per-GEMV chain.
 bool gpt_token_prepare() {
     if (!device_fits(TG, LDS_EXCLUSIVE)) return false;
+    int nb8 = 0, nb16 = 0;
     try {
-        lds_optin(reinterpret_cast<const void*>(gpt_token_kernel), LDS_EXCLUSIVE);
+        lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<8>), LDS_EXCLUSIVE);
+        lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<16>), LDS_EXCLUSIVE);
     } catch (const Error&) {
         (void)hipGetLastError();
         return false;
     }
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gpt_token_kernel), 256, LDS_EXCLUSIVE) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, reinterpret_cast<const void*>(gpt_token_kernel<8>), 256, LDS_EXCLUSIVE) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, reinterpret_cast<const void*>(gpt_token_kernel<16>), 256, LDS_EXCLUSIVE) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    return nb >= 1;
+    return nb8 >= 1 && nb16 >= 1;
 }
 
 size_t gpt_token_pack_floats(int which) {
@@ -769,9 +828,10 @@ void launch_gpt_token_pack(int which, const float* W, int N, int CoutP, float* o
 }
 
 void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
-    DTTS_REQUIRE(p.B >= 1 && p.B <= 8 && p.NL >= 1 && p.NL <= GPT_TOKEN_MAX_LAYERS && p.Vs == GPT_TOKEN_VS, "persistent decode token: shape");
+    DTTS_REQUIRE(p.B >= 1 && p.B <= GPT_TOKEN_ROWS && p.NL >= 1 && p.NL <= GPT_TOKEN_MAX_LAYERS && p.Vs == GPT_TOKEN_VS, "persistent decode token: shape");
     DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
-    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)sizeof(Smem);       // the attribute was raised by gpt_token_prepare (bind time)
+    const bool r16 = p.B > 8;                                                          // 9 .. 16 rows: the 16-row instantiation
+    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)(r16 ? sizeof(SmemT<16>) : sizeof(SmemT<8>));   // the attribute was raised by gpt_token_prepare (bind time)
     // DTTS_GPT_TOKEN_TRACE = n: the n-th launch records wall-clock stamps of workgroups 0 and 37 at every exchange and prints them
     static const int trace_at = []() { const char* v = getenv("DTTS_GPT_TOKEN_TRACE"); return v ? atoi(v) : 0; }();
     static int launches = 0;
@@ -784,7 +844,8 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
         DTTS_CHECK_HIP(hipMemsetAsync(d_trace, 0, sizeof(long long) * 2 * 16 * 16, s));
         q.trace = d_trace;
     }
-    hipLaunchKernelGGL(gpt_token_kernel, dim3(TG), dim3(256), lds_request, s, q);
+    if (r16) hipLaunchKernelGGL(gpt_token_kernel<16>, dim3(TG), dim3(256), lds_request, s, q);
+    else hipLaunchKernelGGL(gpt_token_kernel<8>, dim3(TG), dim3(256), lds_request, s, q);
     DTTS_CHECK_HIP(hipGetLastError());
     if (tracing) {
         long long h[2 * 16 * 16];

@@ -108,7 +108,8 @@ void Model::build_gpt(hipStream_t s) {
 // sessions of <= 8 rows decode a token with ONE persistent kernel (DTTS_GPT_TOKEN_KERNEL=0: the launch-per-GEMV chain)
 bool Model::gpt_use_token_kernel() const {
     static const bool env_on = []() { const char* v = getenv("DTTS_GPT_TOKEN_KERNEL"); return !(v && v[0] == '0'); }();
-    return env_on && opt_gpt_token_ && tok_ok_ && !tok_failed_ && gs_.B <= 8 && gs_.xch != nullptr;
+    static const int env_rows = []() { const char* v = getenv("DTTS_GPT_TOKEN_ROWS"); return v ? atoi(v) : GPT_TOKEN_ROWS; }();
+    return env_on && opt_gpt_token_ && tok_ok_ && !tok_failed_ && gs_.B <= std::min(env_rows, GPT_TOKEN_ROWS) && gs_.xch != nullptr;
 }
 
 // HF GPT-2 stack (without ln_f) over x [B, C, L] in place; optionally fills the KV cache.
@@ -207,7 +208,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     if (!replaying_) {                               // keep the call's inputs: a timed-out token kernel is replayed on the chain (gpt_finish)
         GptReplay& r = replay_;
         r.valid = false;
-        if (tok_ok_ && !tok_failed_ && B <= 8) {
+        if (tok_ok_ && !tok_failed_ && B <= GPT_TOKEN_ROWS) {
             const size_t nref = (size_t)B * cfg.mel_channels * Tr;
             gpt_replay_.ensure(sizeof(float) * nref + 256);
             DTTS_CHECK_HIP(hipMemcpyAsync(gpt_replay_.f32(nref), refer, sizeof(float) * nref, hipMemcpyDeviceToDevice, s));
@@ -246,7 +247,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     const long long kv_bs = (long long)2 * C * cap, kv_layer = kv_bs * B;
     const size_t need = sizeof(float) * ((size_t)NL * kv_layer + (size_t)B * (4 * C + cfg.gpt_heads * 8 * ATT_REC) + (size_t)2 * B * GEMV_PART_FLOATS + 2 * 64 * GEMV_MAXB * 2) +
                         (size_t)B * V + sizeof(int) * ((size_t)2 * B * G + 64) + sizeof(GptCtl) + 64 * 256 +
-                        (tok_ok_ && B <= 8 ? sizeof(unsigned long long) * GPT_TOKEN_XCH_WORDS + sizeof(float) * 8 * GPT_TOKEN_VS + 1024 : 0);
+                        (tok_ok_ && B <= GPT_TOKEN_ROWS ? sizeof(unsigned long long) * GPT_TOKEN_XCH_WORDS + sizeof(float) * GPT_TOKEN_ROWS * GPT_TOKEN_VS + 1024 : 0);
     if (need > gpt_state_.capacity() || gs_.B != B || gs_.cap != cap || gs_.G != G) {
         gpt_drop_graphs();
         gpt_state_.ensure(need);
@@ -268,9 +269,9 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
         n.codes = gpt_state_.i32((size_t)B * G);
         n.forced = gpt_state_.i32((size_t)B * G);
         n.ctl = static_cast<GptCtl*>(gpt_state_.raw(sizeof(GptCtl)));
-        if (tok_ok_ && B <= 8) {
+        if (tok_ok_ && B <= GPT_TOKEN_ROWS) {
             n.xch = static_cast<unsigned long long*>(gpt_state_.raw(sizeof(unsigned long long) * GPT_TOKEN_XCH_WORDS));
-            n.logits = gpt_state_.f32((size_t)8 * GPT_TOKEN_VS);
+            n.logits = gpt_state_.f32((size_t)GPT_TOKEN_ROWS * GPT_TOKEN_VS);
             n.tok_err = gpt_state_.i32(2);
             n.tok_epoch = reinterpret_cast<unsigned*>(n.tok_err + 1);
             // tags of a previous layout of this arena must not survive: all words 0 (no valid tag is 0), the launch counter restarts at 1

@@ -115,6 +115,28 @@ def test_sixteen_row_session_with_row_seeds_equals_two_eight_row_sessions(rt):
         rt.set_option("gpt_token_kernel", 1)
 
 
+def test_sixteen_row_token_kernel_session_equals_two_eight_row_token_sessions(rt):
+    """Round 4: the persistent token kernel has a 16-row instantiation (two requests of 8 utterances per weight pass).  Per row its
+    arithmetic and every summation order are those of the 8-row kernel, so codes AND latents of a 16-row session are bit-identical to
+    the two 8-row token-kernel sessions; a ragged 11-row session (rows 11 .. 15 empty) agrees with the launch-per-GEMV chain on the codes."""
+    rs = np.random.RandomState(61)
+    _sixteen_rows(rt, rs, 20, [])
+    rs = np.random.RandomState(62)
+    B, G = 11, 30
+    refer = (rs.randn(B, 128, 100) * 2 - 5).astype(np.float32)
+    rl = [100 - 4 * b for b in range(B)]
+    texts = [np.concatenate([rs.randint(3, 255, 5 + (b % 6)), [0]]).astype(np.int32) for b in range(B)]
+    args = (dev(refer), rl, texts, 99, list(range(70, 70 + B)))
+    c_tok, n_tok, l_tok = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+    rt.set_option("gpt_token_kernel", 0)
+    try:
+        c_ch, n_ch, l_ch = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+    finally:
+        rt.set_option("gpt_token_kernel", 1)
+    assert np.array_equal(c_tok, c_ch) and np.array_equal(n_tok, n_ch)
+    assert float((l_tok - l_ch).abs().max()) < 2e-5
+
+
 def _sixteen_rows(rt, rs, G, reqs):
     for i, Tr in enumerate((90, 140)):
         refer = (rs.randn(8, 128, Tr) * 2 - 5).astype(np.float32)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for rep in $(seq 1 $REPS); do
   for cfg in A B; do
     if [ $cfg = A ]; then E="$A"; else E="$B"; fi
-    env $E DTTS_BENCH_NO_EXTRA=1 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/ab_env_${cfg}_$rep.json 2> gpurun_out/ab_env_${cfg}_$rep.err
+    env $E DTTS_BENCH_NO_EXTRA=1 python bench.py --steps ${STEPS:-8} --warmup ${WARMUP:-3} --no-cpu-baseline > gpurun_out/ab_env_${cfg}_$rep.json 2> gpurun_out/ab_env_${cfg}_$rep.err
     python - "$cfg" "$rep" "$E" <<PY
 import json, sys
 c, r, e = sys.argv[1:]
