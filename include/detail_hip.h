@@ -236,9 +236,9 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *   "gpt_graph"   (default 0): 1 = dtts_gpt_decode replays captured hipGraphs (16-step chunks); 0 = the same launches issued
  *                 eagerly, 16 steps per call (measured faster on ROCm 7.2: a replayed kernel node costs ~0.8 us more than an eager
  *                 back-to-back launch and the host has nothing else to do); env DTTS_GPT_GRAPH overrides;
- *   "gpt_token_kernel" (default 1): decode sessions of <= 8 rows run a token as ONE persistent kernel (128 resident workgroups that
+ *   "gpt_token_kernel" (default 1): decode sessions (<= 16 rows) run a token as ONE persistent kernel (128 resident workgroups that
  *                 exchange activations through memory, csrc/gpt_token.hip) + the sampler; 0 = the chain of 5 launches per layer
- *                 (always used by 9..16-row sessions).  Same fp32 arithmetic, different summation order; env DTTS_GPT_TOKEN_KERNEL=0.
+ *                 (round 3: always used by 9..16-row sessions; DTTS_GPT_TOKEN_ROWS=8 restores that).  Same fp32 arithmetic, different summation order; env DTTS_GPT_TOKEN_KERNEL=0.
  *                 Bound only when the device can hold its 128 workgroups at once (>= 128 CUs, opt-in LDS); if an exchange of a
  *                 running session ever times out, dtts_gpt_finish replays that session on the chain (same codes as the chain) and the
  *                 handle stays on the chain until this option is set to 1 again;
