@@ -398,6 +398,17 @@ void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, con
         (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
         return;
     }
+    if (getenv("UB_BIG")) {        // round 4: 4 waves with 128 x 96 wave tiles (one wave per SIMD) against the product's tile, 3 LDS stages
+        for (int rep = 0; rep < 2; ++rep) {
+            run<NPL, 2, 2, 2, 3, 2, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 4w (64x96) st3", os);
+            run<NPL, 2, 2, 4, 3, 1, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4w (128x96) st3", os);
+            run<NPL, 2, 2, 4, 3, 1, 4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4w (128x96) st4", os);
+            run<NPL, 2, 2, 3, 3, 1, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "192x192 4w (96x96) st3", os);
+            run<NPL, 4, 2, 2, 3, 1, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8w (64x96) st3", os);
+        }
+        (void)hipFree(Wp); (void)hipFree(Xp); (void)hipFree(Y);
+        return;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         if (NPL == 2) { run_pp<3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); run_pp<4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); run_pp<5>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8 waves", os); }
         run<NPL, 2, 2, 2, 3, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 global_load_lds", os);
