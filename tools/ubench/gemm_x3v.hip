@@ -69,6 +69,26 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
             }
         }
     };
+    // BUF == 2 (round 4): VGPR staging instead of LDS-DMA - a piece is one global_load_dwordx4 into a register quad, stored to the LDS one
+    // K-step later with ds_write_b128 (LDS double buffer + one register stage: the same two steps of prefetch distance as 3 LDS stages)
+    auto g_addr = [&](int pp, int kstep) -> const uint4* {
+        const int p = pp % SPIECES, c16 = kstep;
+        if (p < APIECES) {
+            const int kind = p / (BM / 64), rh = p % (BM / 64), pl = kind >> 1, h = kind & 1;
+            return wbase + ((long long)(2 * c16 + h) * NPL + pl) * M + rh * 64;
+        }
+        const int q = p - APIECES, kind = q / (BN / 64), rh = q % (BN / 64), pl = kind >> 1, h = kind & 1;
+        return xbase + ((long long)(2 * c16 + h) * NPL + pl) * Tp + rh * 64;
+    };
+    auto l_off = [&](int pp, int stage) -> int {
+        const int p = pp % SPIECES;
+        if (p < APIECES) {
+            const int kind = p / (BM / 64), rh = p % (BM / 64);
+            return stage * STAGE + kind * (BM * 16) + rh * 1024 + lane * 16;
+        }
+        const int q = p - APIECES, kind = q / (BN / 64), rh = q % (BN / 64);
+        return stage * STAGE + ATILE + kind * (BN * 16) + rh * 1024 + lane * 16;
+    };
     const int wm0 = (wave / WGN) * (MI * 32), wn0 = (wave % WGN) * (NJ * 32);
     f16v acc[MI][NJ];
 #pragma unroll
@@ -78,6 +98,50 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int nkb = c16n / KB;
+    if constexpr (BUF == 2) {
+        static_assert(KB == 1 && NSTG == 2, "VGPR staging: LDS double buffer");
+        uint4 sreg[PPW];
+        auto pidx = [&](int i) { int p = wave + i * NW; return p >= PIECES ? wave : p; };
+        // prologue: step 0 -> registers -> LDS stage 0; step 1 -> registers
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) sreg[i] = *g_addr(pidx(i), 0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) *reinterpret_cast<uint4*>(smem + l_off(pidx(i), 0)) = sreg[i];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) sreg[i] = *g_addr(pidx(i), nkb > 1 ? 1 : 0);
+        for (int ks = 0; ks < nkb; ++ks) {
+            __syncthreads();                                   // the ds_writes of the previous step (stage ks % 2) are visible; stage (ks + 1) % 2 is free
+            const int cur = ks & 1, nst = cur ^ 1, kx = ks + 2 < nkb ? ks + 2 : nkb - 1;
+            const unsigned char* As = smem + cur * STAGE + lhi * (BM * 16);
+            const unsigned char* Bs = smem + cur * STAGE + ATILE + lhi * (BN * 16);
+            bf8 a[MI][NPL], bb[NJ][NPL];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i][p] = *reinterpret_cast<const bf8*>(As + p * (2 * BM * 16) + (wm0 + i * 32 + l31) * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bb[j][p] = *reinterpret_cast<const bf8*>(Bs + p * (2 * BN * 16) + (wn0 + j * 32 + l31) * 16);
+            }
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+            int mf = 0, piece = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[i][TA[t]]), __builtin_bit_cast(hf8, bb[j][TB[t]]), acc[i][j], 0, 0, 0);
+                        ++mf;
+                        if (piece < PPW && mf * PPW >= (piece + 1) * NMF) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            *reinterpret_cast<uint4*>(smem + l_off(pidx(piece), nst)) = sreg[piece];      // data of step ks + 1 -> LDS
+                            sreg[piece] = *g_addr(pidx(piece), kx);                                        // data of step ks + 2 -> registers
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++piece;
+                        }
+                    }
+        }
+    } else {
     // every wave issues exactly PPW load instructions per K-block (the ones past PIECES re-fetch piece 0 of the wave: harmless
     // duplicates), so a counted vmcnt is the same immediate for every wave
     auto issue_w = [&](int i, int kstep, int stage) { int p = wave + i * NW; if (p >= PIECES) p = wave; issue(p, kstep, stage); };
@@ -145,6 +209,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, MINW) void gemm_x3v(const uint4* __r
                         }
                     }
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* yb = Y + (long long)b * M * T;
@@ -401,6 +466,8 @@ void suite(int M, int C, int T, int B, int Tp, const std::vector<float>& hw, con
     if (getenv("UB_BIG")) {        // round 4: 4 waves with 128 x 96 wave tiles (one wave per SIMD) against the product's tile, 3 LDS stages
         for (int rep = 0; rep < 2; ++rep) {
             run<NPL, 2, 2, 2, 3, 2, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 4w (64x96) st3", os);
+            run<NPL, 2, 2, 2, 3, 2, 2, 1, 0, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "128x192 4w VGPR-staged", os);
+            run<NPL, 4, 2, 2, 3, 1, 2, 1, 0, 2>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 8w VGPR-staged", os);
             run<NPL, 2, 2, 4, 3, 1, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4w (128x96) st3", os);
             run<NPL, 2, 2, 4, 3, 1, 4>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "256x192 4w (128x96) st4", os);
             run<NPL, 2, 2, 3, 3, 1, 3>(Wp, Xp, Y, M, C, T, Tp, B, hw, hx, "192x192 4w (96x96) st3", os);
