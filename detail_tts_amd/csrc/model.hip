@@ -393,6 +393,11 @@ void Model::build_diffusion(hipStream_t s) {
     for (auto& l : integ_) add_layer(l);
     for (auto& l : layers_) add_layer(l);
     for (auto& r : tail_) { hot.push_back(&r.c1); hot.push_back(&r.c2); }
+    // round 4: the 1 x 1 convs of the conditioning encoders' AttentionBlocks too (contextual_embedder: 1536 channels, head dim 96 -
+    // fp32 attention between split-precision convs; latent_conditioner: 768 channels, the trunk's block): they run on stage B's stream
+    // in front of every request's sampler
+    for (auto& b : ctx_) { hot.push_back(&b.qkv); hot.push_back(&b.proj); }
+    for (auto& b : latcond_) { hot.push_back(&b.qkv); hot.push_back(&b.proj); }
     size_t total = 0;
     for (PackedConv* pc : hot) {
         DTTS_REQUIRE(pc->Cin == pc->CinP && pc->CoutP % 128 == 0, "trunk conv not eligible for the split-precision path");
@@ -530,7 +535,7 @@ void Model::attention_block(const AttnBlockW& w, const float* x, float* y, float
     if (planes) a.planes = qkv;
     // the proj conv's input planes come straight from the attention epilogue; xs still holds the zero halo / tail columns that
     // gn_split_planes wrote for the qkv conv (same B, T, lens), and the qkv conv has consumed the rest
-    const bool att_planes = a.x3 && T + 1 < x3_tp(T);
+    const bool att_planes = a.x3 && D == 48 && w.bias_tab && T + 1 < x3_tp(T);      // (other head dims: fp32 attention, its output is split below)
     DTTS_REQUIRE(!f || att_planes, "fused GroupNorm: the attention must write the proj conv's planes");
     void* xs_att = f ? f->xs_alt : xs;                  // fused: the proj conv reads xs_alt and its epilogue writes xs (the next block's input)
     if (att_planes) {
@@ -1037,7 +1042,8 @@ void Model::diff_conditioning(const float* refer, const int* lens_host, int B, i
         l2[b] = (l1[b] - 1) / 2 + 1;
     }
     const size_t act = (size_t)B * C2 * T2;
-    ws().ensure(sizeof(float) * ((size_t)B * C * T1 + 3 * act + 3 * act + (size_t)2 * B * C2) + 8192);
+    const bool x3c = use_x3() && !ctx_.empty() && ctx_[0].qkv.w3;
+    ws().ensure(sizeof(float) * ((size_t)B * C * T1 + 3 * act + qkv_floats(B, C2, T2) + (size_t)2 * B * C2) + (x3c ? x3_bytes(B, C2, T2) : 0) + 8192);
     const int* d0 = upload_ints(l0.data(), B, s);
     const int* d1 = upload_ints(l1.data(), B, s);
     const int* d2 = upload_ints(l2.data(), B, s);
@@ -1045,8 +1051,9 @@ void Model::diff_conditioning(const float* refer, const int* lens_host, int B, i
     float* a = ws().f32(act);
     float* bb = ws().f32(act);
     float* att = ws().f32(act);
-    float* qkv = ws().f32(3 * act);
+    float* qkv = ws().f32(qkv_floats(B, C2, T2));
     float* ab = ws().f32((size_t)2 * B * C2);
+    void* xsc = x3c ? ws().raw(x3_bytes(B, C2, T2)) : nullptr;
     ConvParams p;
     p.B = B;
     p.Tin = Tmax;
@@ -1080,7 +1087,7 @@ void Model::diff_conditioning(const float* refer, const int* lens_host, int B, i
     float* cur = a;
     float* nxt = bb;
     for (auto& blk : ctx_) {
-        attention_block(blk, cur, nxt, qkv, att, ab, d2, B, T2, T2, s);
+        attention_block(blk, cur, nxt, qkv, att, ab, d2, B, T2, T2, s, xsc);
         std::swap(cur, nxt);
     }
     launch_mean_time(cur, (long long)C2 * T2, T2, d2, T2, B, C2, cond_out, s);
@@ -1091,15 +1098,17 @@ void Model::diff_timestep_independent(const float* latent_cm, const int* lens_n_
     DTTS_REQUIRE(bound_, "weights not bound");
     const int C = cfg.diff_channels;
     const size_t act = (size_t)B * C * nmax;
-    ws().ensure(sizeof(float) * (3 * act + 3 * act + (size_t)2 * B * C) + 8192);
+    const bool x3l = use_x3() && !latcond_.empty() && latcond_[0].qkv.w3;
+    ws().ensure(sizeof(float) * (3 * act + qkv_floats(B, C, nmax) + (size_t)2 * B * C) + (x3l ? x3_bytes(B, C, nmax) : 0) + 8192);
     std::vector<int> ln(B);
     for (int b = 0; b < B; ++b) ln[b] = lens_n_host ? lens_n_host[b] : nmax;
     const int* dl = upload_ints(ln.data(), B, s);
     float* a = ws().f32(act);
     float* bb = ws().f32(act);
     float* att = ws().f32(act);
-    float* qkv = ws().f32(3 * act);
+    float* qkv = ws().f32(qkv_floats(B, C, nmax));
     float* ab = ws().f32((size_t)2 * B * C);
+    void* xsl = x3l ? ws().raw(x3_bytes(B, C, nmax)) : nullptr;
     const long long bs = (long long)C * nmax;
     ConvParams p;
     p.B = B;
@@ -1118,7 +1127,7 @@ void Model::diff_timestep_independent(const float* latent_cm, const int* lens_n_
     float* cur = a;
     float* nxt = bb;
     for (auto& blk : latcond_) {
-        attention_block(blk, cur, nxt, qkv, att, ab, dl, B, nmax, nmax, s);
+        attention_block(blk, cur, nxt, qkv, att, ab, dl, B, nmax, nmax, s, xsl);
         std::swap(cur, nxt);
     }
     int groups = 32;
