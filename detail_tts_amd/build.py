@@ -15,7 +15,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdetail_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# No packed fp32 VALU instructions (v_pk_{fma,mul,add}_f32) anywhere in the library: packed fp32 math in a wave that shares a SIMD with
+# waves issuing dense fp16 MFMAs returned wrong accumulators in the GPT token kernel (profiles/r04_token_pk_diag.txt: root cause
+# unknown, erratum or supply effect), every kernel here runs next to the split-precision trunk, and the build without them measured
+# 0.6 % FASTER on the bench (profiles/r05_nopk_ab.txt; MI355X_MICROARCH.md: packed fp32 beside MFMAs is an anti-lever).
+# tests/test_host_logic.py disassembles the shipped .so and fails on any such instruction.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", *NO_PACKED_FP32]
 
 
 def _sources():
@@ -92,6 +98,39 @@ def build_variant(name, token_flags):
     return lib
 
 
+def build_variant_all(name, extra_flags, only=None):
+    """Measurement builds (tools/round5_measure.sh): EVERY source (or those in `only`) compiled with `extra_flags` appended, as
+    libdetail_hip_<name>.so next to the product library (objects under csrc/build/variant_<name>/).  DTTS_LIB_PATH selects it."""
+    build(verbose=False)
+    vdir = os.path.join(CSRC, "build", "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+
+    def one(src):
+        if only is not None and src not in only:
+            return os.path.join(OBJ, src[:-4] + ".o")
+        obj = os.path.join(vdir, src[:-4] + ".o")
+        stamp = obj + ".sha1"
+        dig = _digest(src) + " ".join(extra_flags)
+        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            return obj
+        r = subprocess.run([HIPCC, *FLAGS, *_extra_flags(src), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        open(stamp, "w").write(dig)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, _sources()))
+    lib = os.path.join(HERE, f"libdetail_hip_{name}.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return lib
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":        # python -m detail_tts_amd.build --variant nopk -Xclang -target-feature ...
+        print(build_variant_all(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     build()
     sys.exit(0)

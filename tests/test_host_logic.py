@@ -328,26 +328,30 @@ def test_configs0_cpu_plumbing_on_bundled_prompt(weights):
     assert wav.shape == (3 * 1024,) and np.isfinite(wav).all() and float(np.abs(wav).max()) > 1e-4
 
 
-def test_token_kernel_object_has_no_packed_fp32_math():
-    """csrc/gpt_token.hip is built with -fno-slp-vectorize (build.py reads its `// hipcc-flags:` line): with packed fp32 math its
-    results were wrong when its workgroups shared CUs with the split-precision kernels (DESIGN.md par. 4).  The gfx950 code object of the
-    built library must not contain a packed fp32 instruction in gpt_token_kernel."""
-    import shutil
+def test_shipped_library_has_no_packed_fp32_math():
+    """The WHOLE library is built without packed fp32 VALU instructions (build.py: NO_PACKED_FP32; csrc/gpt_token.hip additionally with
+    -fno-slp-vectorize): with v_pk_{fma,mul,add}_f32 the GPT token kernel's results were wrong when its waves shared SIMDs with the
+    split-precision kernels' fp16 MFMAs (DESIGN.md par. 4, profiles/r04_token_pk_diag.txt), and every kernel of stages A / B / C runs next
+    to those kernels under SynthesizerTrn.infer_stream.  The SHIPPED .so is disassembled - the file the GPU box loads - not build/*.o."""
     import subprocess
+    import tempfile
     from detail_tts_amd import build as B
     assert "-fno-slp-vectorize" in B._extra_flags("gpt_token.hip")
+    assert "-packed-fp32-ops" in B.FLAGS
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    obj = os.path.join(B.OBJ, "gpt_token.o")
-    if not (os.path.exists(objdump) and os.path.exists(obj)):
-        pytest.skip("no object file / llvm-objdump here (the build directory does not travel)")
-    import tempfile
+    assert os.path.exists(objdump), "llvm-objdump is part of the ROCm image"
+    assert os.path.exists(B.LIB), "libdetail_hip.so must be built in-tree (python -m detail_tts_amd.build)"
+    import shutil
     with tempfile.TemporaryDirectory() as td:
-        o2 = os.path.join(td, "gpt_token.o")
-        shutil.copy(obj, o2)
-        subprocess.run([objdump, "--offloading", o2], check=True, capture_output=True, cwd=td)
+        so = os.path.join(td, "lib.so")
+        shutil.copy(B.LIB, so)
+        subprocess.run([objdump, "--offloading", so], check=True, capture_output=True, cwd=td)
         dev = [f for f in os.listdir(td) if "gfx950" in f]
         assert dev, os.listdir(td)
-        asm = subprocess.run([objdump, "-d", os.path.join(td, dev[0])], check=True, capture_output=True, text=True).stdout
-    assert "gpt_token_kernel" in asm and "v_fma_f32" in asm
+        asm = "".join(subprocess.run([objdump, "-d", os.path.join(td, f)], check=True, capture_output=True, text=True).stdout for f in dev)
+    for kernel in ("gpt_token_kernel", "conv_x3_kernel", "flash_attn_x3", "conv_x3d_kernel", "resblock1x3_fused", "gemv_block_kernel",
+                   "gn_split_planes", "conv_gemm_kernel"):
+        assert kernel in asm, kernel
+    assert "v_fma_f32" in asm and "v_mfma_f32_32x32x16_f16" in asm
     packed = [l for l in asm.splitlines() if "v_pk_fma_f32" in l or "v_pk_mul_f32" in l or "v_pk_add_f32" in l]
-    assert not packed, packed[:5]
+    assert not packed, (len(packed), packed[:5])
