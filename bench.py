@@ -75,6 +75,15 @@ def cpu_baseline(W, seed=1234):
         t0 = time.time()
         G.generate(W, refer, [T_REF], text, seed, [0], max_generate_length=N_CODES + 1, suppress_eos=True)
         t_gpt = time.time() - t0
+        # ... and the reference-faithful decode WITHOUT a KV cache (gpt/model.py:79-80, model_24k.py:602: every step re-runs the whole
+        # sequence; SURVEY 8d asks for both), bounded: 16 tokens measured, extrapolated to 235 with a per-step cost linear in the
+        # sequence length (prefix 65 + k tokens)
+        n_unc = 16
+        t0 = time.time()
+        G.generate(W, refer, [T_REF], text, seed, [0], max_generate_length=n_unc, suppress_eos=True, use_cache=False)
+        t_unc = time.time() - t0 - t_prefill
+        Lp = L_TEXT + 5
+        unc_total = t_prefill + max(t_unc, 0.0) * sum(Lp + k for k in range(N_CODES + 1)) / sum(Lp + k for k in range(n_unc))
         sched = D.make_schedule()
         code_emb = rs.randn(1, 768, 4 * N_CODES).astype(np.float32)
         x = rs.randn(1, 128, 4 * N_CODES).astype(np.float32)
@@ -99,6 +108,10 @@ def cpu_baseline(W, seed=1234):
     audio = N_CODES * 1024 / 24000.0
     return {"value": audio / total, "unit": "audio_s/s", "cores": int(cores), "kind": "port",
             "threads": {"os_cpu_count": os.cpu_count(), "used": NT, "blas_default": int(blas), "torch_default": int(torch_threads)},
+            "uncached_decode": {"value": round(audio / (unc_total + rest), 4), "unit": "audio_s/s", "measured_tokens": n_unc,
+                                "measured_s": round(max(t_unc, 0.0), 2), "extrapolated_decode_s_235_tokens": round(unc_total, 1),
+                                "note": "the same sample with the reference-faithful decode: NO KV cache (every step re-runs the whole sequence: "
+                                        "gpt/model.py:79-80), 16 tokens measured, extrapolated with a per-step cost linear in the sequence length"},
             "reference_in_build_container": {"value": round(audio / 86.3, 3), "unit": "audio_s/s", "cores": 8,
                                              "note": "the reference's OWN code on this utterance shape in the build container (8 vCPUs): its uncached HF sampling loop over 235 tokens 27.0 s + SynthesizerTrn.infer from the codes on 59.2 s (tests/golden/make_golden_e2e_fullsize.py log) = 86 s; not re-measured here: the reference cannot travel to the GPU box"},
             "sample": (f"1 utterance, T=936: GPT prefill + all 234 KV-cache decode steps {t_gpt:.1f}s ({(t_gpt - t_prefill) / N_CODES * 1e3:.0f} ms/token), "

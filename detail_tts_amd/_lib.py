@@ -79,6 +79,8 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "dtts_vocoder_stream": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_ulonglong, c_int_p, C.c_float, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p]),
+    "dtts_vocoder_ticket": (C.c_longlong, [C.c_void_p]),
+    "dtts_vocoder_check": (C.c_int, [C.c_void_p, C.c_longlong]),
     "dtts_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_mel_style": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_attention_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

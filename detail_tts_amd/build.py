@@ -98,7 +98,7 @@ def build_variant(name, token_flags):
     return lib
 
 
-def build_variant_all(name, extra_flags, only=None):
+def build_variant_all(name, extra_flags, only=None, drop_flags=()):
     """Measurement builds (tools/round5_measure.sh): EVERY source (or those in `only`) compiled with `extra_flags` appended, as
     libdetail_hip_<name>.so next to the product library (objects under csrc/build/variant_<name>/).  DTTS_LIB_PATH selects it."""
     build(verbose=False)
@@ -110,10 +110,11 @@ def build_variant_all(name, extra_flags, only=None):
             return os.path.join(OBJ, src[:-4] + ".o")
         obj = os.path.join(vdir, src[:-4] + ".o")
         stamp = obj + ".sha1"
-        dig = _digest(src) + " ".join(extra_flags)
+        dig = _digest(src) + " ".join(extra_flags) + "|" + " ".join(drop_flags)
         if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
             return obj
-        r = subprocess.run([HIPCC, *FLAGS, *_extra_flags(src), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        base = [f for f in FLAGS if f not in drop_flags]
+        r = subprocess.run([HIPCC, *base, *_extra_flags(src), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         open(stamp, "w").write(dig)
@@ -129,8 +130,11 @@ def build_variant_all(name, extra_flags, only=None):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--variant":        # python -m detail_tts_amd.build --variant nopk -Xclang -target-feature ...
-        print(build_variant_all(sys.argv[2], sys.argv[3:]))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":        # python -m detail_tts_amd.build --variant <name> <extra flags ...>
+        if sys.argv[2] == "pk":                                 # the round-4 flags: packed fp32 instructions allowed
+            print(build_variant_all("pk", sys.argv[3:], drop_flags=tuple(NO_PACKED_FP32)))
+        else:
+            print(build_variant_all(sys.argv[2], sys.argv[3:]))
         sys.exit(0)
     build()
     sys.exit(0)

@@ -48,7 +48,8 @@ struct AttnPlanes {
 
 void launch_flash_attention(const AttnParams& p, hipStream_t stream);
 void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3 (fp32 q, k, v)
-void launch_flash_attention_x3w(const AttnParams& p, hipStream_t stream);  // ... when the operands are AttnPlanes images
+void launch_flash_attention_x3w(const AttnParams& p, hipStream_t stream);  // ... when the operands are AttnPlanes images (round 2-4 kernel: DTTS_ATTN_KERNEL=w)
+void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream);  // ... the block-skewed kernel (default)
 
 // VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)
 //   relk[b,h,t,r] = scale * sum_c q[c,t] * Ek[r][c]

@@ -107,6 +107,14 @@ int dtts_set_option(dtts_handle* h, const char* key, int value) {
     DTTS_API_END(h)
 }
 
+long long dtts_vocoder_ticket(dtts_handle* h) { return h && h->m ? h->m->vocoder_ticket() : 0; }
+
+int dtts_vocoder_check(dtts_handle* h, long long ticket) {
+    DTTS_API_BEGIN
+    h->m->vocoder_check(ticket);
+    DTTS_API_END(h)
+}
+
 int dtts_profile_enable(int on) {
     dtts::Profiler::get().reset();
     dtts::Profiler::get().on = on != 0;

@@ -208,6 +208,7 @@ public:
         else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; if (value != 0) tok_failed_ = false; gpt_drop_graphs(); }
         else if (key == "gpt_token_exclusive_cu") { opt_tok_exclusive_ = value != 0; gpt_drop_graphs(); }
         else if (key == "gpt_token_fault") opt_tok_fault_ = value;       // test hook: the n-th token launch from now on times out
+        else if (key == "gpt_token_fault_eos") opt_tok_fault_eos_ = value;   // ... and leaves every row flagged finished (a spurious stop token)
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
@@ -328,6 +329,7 @@ private:
     bool opt_tok_exclusive_ = true;       // option "gpt_token_exclusive_cu": the token kernel asks for whole CUs
     bool tok_failed_ = false;             // an exchange timed out once: this handle stays on the chain (until the option is set again)
     int opt_tok_fault_ = 0;               // option "gpt_token_fault"
+    int opt_tok_fault_eos_ = 0;           // option "gpt_token_fault_eos"
     // what dtts_gpt_prefill was called with, kept so that a session whose token kernel timed out can be replayed on the chain
     struct GptReplay {
         bool valid = false;
@@ -352,11 +354,20 @@ private:
 
     bool opt_two_streams_ = true;
     bool opt_range_check_ = false;      // vocoder: detect activations beyond the split-precision planes' range (synchronises)
-    int* x3_sat_ = nullptr;             // host-mapped flag of the range check (raised by the kernels, read without synchronising)
-    int* x3_sat_dev_ = nullptr;         // its device address; null = check off
-    int* x3_sat_flag(hipStream_t s);    // device address of the flag (null when DTTS_X3_RANGE_CHECK=0); reports an earlier call's saturation
-    void x3_sat_report(bool this_call); // throws when the flag is up
+    // Range check of the generator's split-precision planes: a ring of host-mapped flags, one slot per vocoder / generator call
+    // ("ticket"), raised by the kernels and read without synchronising by vocoder_check(ticket) once the CALLER has waited for that
+    // call - so a saturation fails the request that saturated, not the next one.
+    static constexpr int X3_SAT_SLOTS = 8;
+    int* x3_sat_ = nullptr;             // host-mapped ring [X3_SAT_SLOTS]
+    int* x3_sat_ring_dev_ = nullptr;    // its device address
+    int* x3_sat_dev_ = nullptr;         // the current call's slot (device address); null = check off
+    long long x3_ticket_ = 0;           // ticket of the last vocoder / generator call (0: none yet)
+    int* x3_sat_flag(hipStream_t s);    // new ticket; device address of its flag (null when DTTS_X3_RANGE_CHECK=0)
     void x3_sat_check(hipStream_t s);   // option x3_range_check: synchronise and report this call's saturation
+public:
+    long long vocoder_ticket() const { return x3_ticket_; }
+    void vocoder_check(long long ticket);    // throws Error(-5) when call `ticket` saturated; the caller has waited for that call
+private:
     int opt_cfg_streams_ = 0;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into; 0 = by batch size
     bool opt_conv_x3_ = true;             // diffusion trunk convs on the 3 x bf16 split-precision path (conv_x3.h)
     Arena w3_;                            // split-precision weight copies

@@ -400,6 +400,10 @@ void Model::gpt_step_launches(hipStream_t s) {
         if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)
             const int one = 1;
             DTTS_CHECK_HIP(hipMemcpyAsync(gs_.tok_err, &one, sizeof(int), hipMemcpyHostToDevice, s));
+            if (opt_tok_fault_eos_) {        // ... and the sampler, drawing from the dead kernel's stale logits, "finishes" every row
+                const std::vector<int> fin(B, 1);
+                DTTS_CHECK_HIP(hipMemcpyAsync(gs_.finished, fin.data(), sizeof(int) * B, hipMemcpyHostToDevice, s));
+            }
             DTTS_CHECK_HIP(hipStreamSynchronize(s));
         }
         {
@@ -586,8 +590,14 @@ void Model::gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s) {
         // An exchange poll of the persistent token kernel gave up (its 128 workgroups were not all resident: CU mask, partition mode,
         // another process holding CUs).  The handle leaves the token kernel for good and THIS session is replayed from its prefill on
         // the launch-per-GEMV chain - same sampler, same Philox draws, so the codes are the ones the chain would have produced.
+        // Did the FAILED session look finished?  Once the kernel is dead the sampler draws from stale logits, so rows may have drawn the
+        // stop token spuriously and the caller's decode loop (gpt_all_finished) stopped on that: the replay must then go on past the
+        // failed session's step count until the chain's own rows have finished (silently truncated audio otherwise).
+        int fin[GEMV_MAXB];
+        DTTS_CHECK_HIP(hipMemcpyAsync(fin, gs_.finished, sizeof(int) * B, hipMemcpyDeviceToHost, s));
         DTTS_CHECK_HIP(hipMemsetAsync(gs_.tok_err, 0, sizeof(int), s));
         DTTS_CHECK_HIP(hipStreamSynchronize(s));
+        const bool failed_looked_finished = std::all_of(fin, fin + B, [](int f) { return f != 0; });
         gs_.active = false;
         tok_failed_ = true;
         gpt_drop_graphs();
@@ -610,6 +620,12 @@ void Model::gpt_finish(int* codes_host, int* ncodes_host, hipStream_t s) {
                         r.Lt_max, r.B, o, r.latents_cm, r.lat_stride, s);
             for (int i = 1; i < steps; ++i) gpt_step_launches(s);
             gs_.steps = steps;
+            if (!o.suppress_eos && failed_looked_finished)
+                while (gs_.steps < G && !gpt_all_finished(s)) {
+                    const int n = std::min(16, G - gs_.steps);
+                    for (int i = 0; i < n; ++i) gpt_step_launches(s);
+                    gs_.steps += n;
+                }
         } catch (...) {
             replaying_ = false;
             throw;

@@ -314,38 +314,52 @@ void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, cons
 
 // Range check of the split-precision operands of the generator's ResBlock1 convs (their inputs are UNNORMALISED activations: beyond
 // +-65504 / 16 = 4094 the fp16 planes saturate and the conv would be silently wrong).  ALWAYS ON since round 4: the
-// kernels raise a host-mapped flag, which costs no synchronisation - the flag is looked at when the next vocoder / generator call
-// of this handle starts (and reported then: "the previous call saturated").  dtts_set_option "x3_range_check" 1 / DTTS_X3_RANGE_CHECK=1
-// additionally reads it at the END of the generator, which synchronises the stream; DTTS_X3_RANGE_CHECK=0 switches the check off.
+// kernels raise a host-mapped flag, which costs no synchronisation.  Round 5: every vocoder / generator call takes a
+// TICKET (a slot of a ring of flags); dtts_vocoder_check(ticket), called by whoever has waited for that call's waveform
+// (SynthesizerTrn.infer / infer_stream do), fails THAT request - not the next call on the handle, and also the last request of a
+// stream.  A slot that is reused while still raised (a caller that never checked) is reported on stderr, nothing is aborted.
+// dtts_set_option "x3_range_check" 1 / DTTS_X3_RANGE_CHECK=1 additionally reads the flag at the END of the call, which synchronises
+// the stream; DTTS_X3_RANGE_CHECK=0 switches the check off.
+static const char* kSatMsg = "vocoder: an activation exceeds the range of the split-precision planes (|x| > 4094) - the ResBlock1 convs of this "
+                             "request saturated; rerun with dtts_set_option(\"conv_x3\", 0) or DTTS_VOC_X3=0 (exact fp32 kernels)";
+
 int* Model::x3_sat_flag(hipStream_t s) {
     static const int env = []() { const char* v = getenv("DTTS_X3_RANGE_CHECK"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
     (void)s;
+    ++x3_ticket_;
     if (env == 1) opt_range_check_ = true;
     if (env == 0 && !opt_range_check_) {
         x3_sat_dev_ = nullptr;
         return nullptr;
     }
     if (!x3_sat_) {
-        DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&x3_sat_), sizeof(int), hipHostMallocMapped));
-        *x3_sat_ = 0;
-        DTTS_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&x3_sat_dev_), x3_sat_, 0));
+        DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&x3_sat_), sizeof(int) * X3_SAT_SLOTS, hipHostMallocMapped));
+        for (int i = 0; i < X3_SAT_SLOTS; ++i) x3_sat_[i] = 0;
+        DTTS_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&x3_sat_ring_dev_), x3_sat_, 0));
     }
-    x3_sat_report(false);                   // a saturation of an EARLIER call (no synchronisation)
+    const int slot = (int)(x3_ticket_ % X3_SAT_SLOTS);
+    volatile int* f = x3_sat_ + slot;
+    if (*f) {        // call ticket - X3_SAT_SLOTS saturated and nobody asked: do not fail THIS call for it
+        fprintf(stderr, "[detail_hip] vocoder call %lld saturated its split-precision planes (|x| > 4094) and was never checked "
+                        "(dtts_vocoder_check); its waveform is wrong\n", x3_ticket_ - X3_SAT_SLOTS);
+        *f = 0;
+    }
+    x3_sat_dev_ = x3_sat_ring_dev_ + slot;
     return x3_sat_dev_;
 }
 
-void Model::x3_sat_report(bool this_call) {
-    if (!x3_sat_ || !*x3_sat_) return;
-    *x3_sat_ = 0;
-    throw Error(-5, std::string("vocoder: an activation exceeds the range of the split-precision planes (|x| > 4094) - the ResBlock1 convs of ") +
-                        (this_call ? "this call" : "the PREVIOUS vocoder call of this handle") +
-                        " saturated; rerun with dtts_set_option(\"conv_x3\", 0) or DTTS_VOC_X3=0 (exact fp32 kernels)");
+void Model::vocoder_check(long long ticket) {
+    if (!x3_sat_ || ticket <= 0 || ticket > x3_ticket_ || ticket + X3_SAT_SLOTS <= x3_ticket_) return;      // unknown / recycled ticket
+    volatile int* f = x3_sat_ + (int)(ticket % X3_SAT_SLOTS);
+    if (!*f) return;
+    *f = 0;
+    throw Error(-5, kSatMsg);
 }
 
 void Model::x3_sat_check(hipStream_t s) {
     if (!opt_range_check_ || !x3_sat_) return;
     DTTS_CHECK_HIP(hipStreamSynchronize(s));
-    x3_sat_report(true);
+    vocoder_check(x3_ticket_);
 }
 
 bool Model::vocoder_x3() const {

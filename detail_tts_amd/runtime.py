@@ -314,6 +314,15 @@ class Runtime:
                                        _ptr(noise_override), _ptr(wav), _ptr(z), self._stream()))
         return (wav, z) if return_z else wav
 
+    def vocoder_ticket(self):
+        """ticket of the last vocoder / generator call issued on this handle (dtts_vocoder_ticket)"""
+        return int(self.lib.dtts_vocoder_ticket(self.h))
+
+    def vocoder_check(self, ticket):
+        """dtts_vocoder_check: raises when stage-C call `ticket` saturated its split-precision planes.  Call it AFTER waiting for that
+        call (the waveform's stream / event), i.e. where the waveform is about to be read."""
+        self._rc(self.lib.dtts_vocoder_check(self.h, int(ticket)))
+
     def generator(self, z, g, lens=None):
         _check(z, "z"); _check(g, "g")
         B, _, T = z.shape

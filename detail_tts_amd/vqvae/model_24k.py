@@ -112,6 +112,7 @@ class SynthesizerTrn:
         self._a_pool = None           # ... and its issuing thread
         self.stream_trace = None      # set to [] to collect the per-request timeline of infer_stream()
         self.vocoder_done = None
+        self.vocoder_ticket = 0
 
     def eval(self):
         return self
@@ -124,13 +125,17 @@ class SynthesizerTrn:
     # ------------------------------------------------------------------------------------------------------------
     def infer(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
               forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False, return_lengths=False,
-              stream_vocoder=False, vocoder_chunk=256, wait=True):
+              stream_vocoder=False, vocoder_chunk=256, wait=True, check_range=True):
         """vqvae/model_24k.py:774-810.  Returns wav [B,1,1024*n_max] (B=1 unless batch=True).
 
         stream_vocoder: stage C runs on a second HIP stream, its generator window by window (`vocoder_chunk` mel frames + halo,
         dtts_vocoder_stream; 0 = one shot).  With wait=False the call returns while stage C is still running - `self.vocoder_done` is the event
         to wait on before reading the waveform - so the NEXT call's GPT decode and diffusion (first stream) overlap this call's
-        vocoder (BASELINE configs[4]: long-form batches, overlapped diffusion / vocoder streams)."""
+        vocoder (BASELINE configs[4]: long-form batches, overlapped diffusion / vocoder streams).
+
+        check_range (with wait=True): the call waits for its own waveform and raises if stage C's split-precision planes saturated on
+        THIS request (dtts_vocoder_check; the reference computes those convs in fp32).  With wait=False (or check_range=False) the call
+        stays asynchronous: wait on `self.vocoder_done`, then call `self.check_vocoder()` before reading the waveform."""
         text = torch.as_tensor(text)
         refer = torch.as_tensor(refer)
         tl = torch.as_tensor(text_length).reshape(-1).tolist()
@@ -203,6 +208,10 @@ class SynthesizerTrn:
                 cur.wait_event(self.vocoder_done)
         else:
             wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
+        self.vocoder_ticket = self.rt.vocoder_ticket()
+        if wait and check_range:
+            torch.cuda.current_stream(self.device).synchronize()
+            self.rt.vocoder_check(self.vocoder_ticket)
         mark("vocoder")
         if self.stage_ms is not None:
             torch.cuda.synchronize(self.device)
@@ -211,6 +220,10 @@ class SynthesizerTrn:
         if return_lengths:
             return wav, [1024 * v for v in n]
         return wav
+
+    def check_vocoder(self, ticket=None):
+        """raise if the stage-C call `ticket` (default: the last one issued) saturated; the caller has waited for its waveform"""
+        self.rt.vocoder_check(self.vocoder_ticket if ticket is None else ticket)
 
     # ------------------------------------------------------------------------------------------------------------
     def infer_stream(self, requests, noise_scale=NOISE_SCALE, *, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False,
@@ -350,6 +363,7 @@ class SynthesizerTrn:
                 if not serial_c:
                     sc.wait_event(ready)
                 wav = self.rt.vocoder(mel, st["seed"], st["sids"], lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
+                ticket = self.vocoder_ticket = self.rt.vocoder_ticket()
                 mel.record_stream(cur if serial_c else sc)
                 self.vocoder_done = torch.cuda.Event()
                 self.vocoder_done.record(cur if serial_c else sc)
@@ -357,7 +371,7 @@ class SynthesizerTrn:
                     tr["ev_c1"].record(cur if serial_c else sc)
                     tr["host_b1"] = time.perf_counter()
             wav.record_stream(cur)
-            return wav, [1024 * v for v in n], self.vocoder_done
+            return wav, [1024 * v for v in n], self.vocoder_done, ticket
 
         # Stage A is issued from its own host thread: a kernel-launch call blocks once its stream's hardware queue is full, so one
         # thread could not enqueue request i+1's decode (12 K launches) while it is still feeding request i's diffusion (10 K).  The
@@ -422,9 +436,11 @@ class SynthesizerTrn:
                     launched = out
                     if pending is not None:
                         pending[2].synchronize()
+                        self.rt.vocoder_check(pending[3])        # a saturated stage C fails THIS request (its waveform is complete now)
                         yield pending[0], pending[1]
                     pending = out
             pending[2].synchronize()
+            self.rt.vocoder_check(pending[3])
             yield pending[0], pending[1]
         finally:
             # closed early or failed: the decode session in flight must end before this handle's stage-A entry points are used again

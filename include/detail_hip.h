@@ -195,6 +195,16 @@ int dtts_vocoder(dtts_handle* h, const float* mel, const int* lens, int B, int T
 int dtts_vocoder_stream(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
                         float noise_scale, const float* noise_override, int chunk_frames, float* wav, void* stream);
 
+/* Range check of stage C's split-precision planes (the generator's ResBlock1 convs take UNNORMALISED activations: beyond |x| = 4094 the
+ * fp16 planes saturate).  Every dtts_vocoder / dtts_vocoder_stream / dtts_generator call takes a ticket; its kernels raise a
+ * host-mapped flag without synchronising.  dtts_vocoder_ticket: the ticket of the last such call issued on this handle.
+ * dtts_vocoder_check(ticket): call it once you have WAITED for that call (stream / event synchronised, as you must before reading the
+ * waveform): returns -5 (dtts_last_error explains) when that call saturated - the request that produced wrong audio fails, not the
+ * next one.  Tickets older than 8 calls are no longer known (0 = ok); a flag nobody checked is reported on stderr when its slot is
+ * reused.  The reference has no counterpart (it computes these convs in fp32: vqvae/modules/modules.py:315-328). */
+long long dtts_vocoder_ticket(dtts_handle* h);
+int dtts_vocoder_check(dtts_handle* h, long long ticket);
+
 /* Generator.forward (vqvae/model_24k.py:269-288): z [B,192,T], g [B,768] (NULL: `g is None`, no conditioning) -> wav [B,1,256*T] */
 int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* lens, int B, int T, float* wav, void* stream);
 
@@ -246,13 +256,15 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 0 = it shares CUs with whatever else runs.  A scheduling policy, not a correctness requirement (both settings are
  *                 stress-tested bit-identical under stage B / C loads); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
  *   "gpt_token_fault" (test hook, default 0): n > 0 makes the n-th token-kernel launch from now on behave like an exchange time-out;
+ *   "gpt_token_fault_eos" (test hook, default 0): 1 = that fault also leaves every row flagged finished (a spurious stop token);
  *   "gn_fuse" (default 0): 1 = in batches of >= 5 utterances at T <= 1152 every GroupNorm + activation + split of the diffusion trunk
  *                 runs in the epilogue of the conv in front of it (tiles exchange partial statistics through tagged words; 8 -> 5
  *                 launches per layer, csrc/conv_x3.h "fused GroupNorm").  Same values up to the summation order of the statistics.
  *                 Measured neutral alone and 1.6 % slower under the three-stream pipeline, hence off; env DTTS_GN_FUSE;
  *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
  *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
- *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1;
+ *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.
+ *                 Without it the check is still on, through dtts_vocoder_ticket / dtts_vocoder_check (no synchronisation);
  *   "conv_x3"     (default 1): diffusion-trunk convs and attention, and the generator's wide ResBlock1 convs, on the split-precision path (every fp32 operand as two
  *                 scaled fp16 planes, three fp16 MFMA products per fp32 product, fp32 accumulate: fp32-GEMM-class error);
  *                 0 = the exact fp32-MFMA kernels. */

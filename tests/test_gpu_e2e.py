@@ -410,3 +410,39 @@ def test_token_kernel_timeout_is_replayed_on_the_chain(model):
     rt.set_option("gpt_token_kernel", 1)             # setting the option again clears the latch
     c3, l3 = gen()
     assert np.array_equal(c3, c_tok) and torch.equal(l3, l_tok)
+
+
+def test_token_kernel_timeout_with_a_spurious_stop_is_replayed_to_the_true_end(model):
+    """once the token kernel is dead the sampler draws from stale logits, so with the stop token enabled every row may look
+    finished and the caller's loop (gpt_all_finished, as in SynthesizerTrn.infer) stops early.  dtts_gpt_finish must then replay PAST the
+    failed session's step count until the chain's own rows finish (here: never - all G codes), not hand out truncated codes.  The test
+    hook kills the 7th token launch and flags every row finished."""
+    rt = model.rt
+    rs = np.random.RandomState(12)
+    B, G = 2, 40
+    refer = torch.from_numpy((rs.randn(B, 128, 200) * 2 - 5).astype(np.float32)).cuda()
+    texts = [np.concatenate([rs.randint(3, 255, 10), [0]]).astype(np.int32) for _ in range(B)]
+
+    def run():
+        rt.gpt_prefill(refer, None, texts, 5, list(range(B)), max_generate_length=G, suppress_eos=False)
+        while rt.gpt_steps() < G:
+            if rt.gpt_all_finished():
+                break
+            rt.gpt_decode(16)
+        steps = rt.gpt_steps()
+        c, n, l = rt.gpt_finish()
+        return np.array(c), list(n), l.clone(), steps
+
+    rt.set_option("gpt_token_kernel", 0)
+    c_chain, n_chain, l_chain, _ = run()
+    assert n_chain == [G] * B                       # random weights never draw the stop token
+    rt.set_option("gpt_token_kernel", 1)
+    rt.set_option("gpt_token_fault_eos", 1)
+    rt.set_option("gpt_token_fault", 7)
+    try:
+        c1, n1, l1, steps = run()
+    finally:
+        rt.set_option("gpt_token_fault_eos", 0)
+        rt.set_option("gpt_token_kernel", 1)        # clears the latch
+    assert steps < G, "the failed session should have looked finished to the caller's loop"
+    assert n1 == n_chain and np.array_equal(c1, c_chain) and torch.equal(l1, l_chain)

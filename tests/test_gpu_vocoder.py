@@ -290,21 +290,37 @@ def test_unit_wn_vs_oracle(rt, weights, flow):
         assert np.all(out[b, :, L:] == 0)
 
 
-def test_range_check_is_on_by_default_and_reports_at_the_next_call(weights):
-    """Without any option the kernels still raise the (host-mapped) saturation flag; no synchronisation is added, so the error surfaces
-    when the NEXT vocoder-side call of the handle starts - a saturated conv can no longer pass silently."""
+def test_range_check_is_on_by_default_and_fails_the_request_that_saturated(weights):
+    """Without any option the kernels still raise a (host-mapped) saturation flag; no synchronisation is added.  Every stage-C call
+    takes a ticket, and dtts_vocoder_check(ticket) - called once the caller has waited for that call's output, as SynthesizerTrn.infer /
+    infer_stream do - fails THE REQUEST THAT SATURATED: not the innocent next call on the handle, and also the last call of a stream
+    (ADVICE r03 / r04)."""
     from detail_tts_amd.runtime import DttsError, Runtime
     rt2 = Runtime(weights, folded=True, parts=("vocoder",))
     rs = np.random.RandomState(71)
     x = (rs.randn(1, 200, 160) * 0.5).astype(np.float32)
     ok = host(rt2.op_resblock1(0, 1, dev(x)))
+    t_ok = rt2.vocoder_ticket()
     bad = x.copy()
     bad[0, 17, 40] = 5000.0
-    host(rt2.op_resblock1(0, 1, dev(bad)))             # saturates; returns (nothing synchronises on the flag here)
+    rt2.op_resblock1(0, 1, dev(bad))                   # saturates; returns (nothing synchronises on the flag here)
+    t_bad = rt2.vocoder_ticket()
+    assert t_bad == t_ok + 1
+    after = rt2.op_resblock1(0, 1, dev(x))             # the NEXT call is not aborted ...
+    t_after = rt2.vocoder_ticket()
     torch.cuda.synchronize()
-    with pytest.raises(DttsError, match="PREVIOUS vocoder call"):
+    assert np.array_equal(host(after), ok)             # ... and is unaffected
+    rt2.vocoder_check(t_ok)
+    rt2.vocoder_check(t_after)
+    with pytest.raises(DttsError, match="conv_x3"):
+        rt2.vocoder_check(t_bad)                       # the request that saturated fails, also when it is not the last one issued
+    rt2.vocoder_check(t_bad)                           # reported once
+    # a flag nobody checks is recycled (reported on stderr) when its slot comes round again: 8 calls later nothing raises
+    rt2.op_resblock1(0, 1, dev(bad))
+    for _ in range(9):
         rt2.op_resblock1(0, 1, dev(x))
-    assert np.array_equal(host(rt2.op_resblock1(0, 1, dev(x))), ok)      # the flag is cleared once reported
+    torch.cuda.synchronize()
+    rt2.vocoder_check(rt2.vocoder_ticket())
 
 
 def test_calls_from_many_short_lived_host_threads(rt):

@@ -224,20 +224,24 @@ def test_two_rank_gloo_weight_broadcast_and_sharding():
     assert res[0][3] == res[1][3] and len(sum(res[0][3], [])) == 6         # no data-path collective needed beyond this
 
 
-def test_bench_gpus_flag_launches_one_rank_per_gpu():
-    """SURVEY §8e / BASELINE configs[3]: `python bench.py --gpus 2` with no launcher around it re-execs itself as 2 ranks under
-    torch.distributed.run (127.0.0.1); DTTS_BENCH_LAUNCH_ONLY stops each rank after the rendezvous (gloo here: no GPU in this container)."""
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_gpus_flag_launches_one_rank_per_gpu(n):
+    """SURVEY §8e / BASELINE configs[3]: `python bench.py --gpus N` (2, and the node's 8) with no launcher around it re-execs itself as N
+    ranks under torch.distributed.run (127.0.0.1); DTTS_BENCH_LAUNCH_ONLY stops each rank after the rendezvous (gloo here: no GPU in this
+    container)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["DTTS_BENCH_LAUNCH_ONLY"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
-                       text=True, timeout=300, env=env, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line == {"launched_ranks": 2, "n_gpus": 2, "local_ranks_seen": 2}
+    assert line == {"launched_ranks": n, "n_gpus": n, "local_ranks_seen": n}
+    if n != 2:
+        return
     # a launcher whose world size contradicts --gpus is an error, not a silent 1-rank run
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env2, cwd=root)

@@ -24,7 +24,9 @@ if os.path.exists(kt):
     for r in csv.DictReader(open(kt)):
         k = clean(r["Kernel_Name"])
         dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
-lines = [f"{tag}: rocprofv3 --pmc <set> --kernel-trace -- python tools/bench_layer.py (one diffusion layer, B = " + os.environ.get("BB", "16") + " samples per launch, T = 936);",
+bbf = os.path.join(go, f"{tag}_pmc_bb.txt")
+bb = open(bbf).read().strip() if os.path.exists(bbf) else os.environ.get("BB", "?")      # written by tools/pmc_pipes.sh on the GPU box
+lines = [f"{tag}: rocprofv3 --pmc <set> --kernel-trace -- python tools/bench_layer.py (one diffusion layer, B = {bb} samples per launch, T = 936);",
          "means per dispatch.  SQ_* cycle counters (other than MFMA_BUSY) are quad-cycles summed over waves; MFMA busy % is quoted against",
          "1024 SIMDs x duration x 2.4 GHz (a lower bound: the clock under load is lower).  FETCH_SIZE doubled (gfx950 16 B/lane correction).", ""]
 for k, cs in sorted(val.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):

@@ -7,6 +7,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export BB=${BB:-16}
+echo $BB > $OUT/${TAG}_pmc_bb.txt      # the per-launch batch, for the summary header (tools/pmc_pipes.py)
 rocprofv3 -L > $OUT/${TAG}_counters_list.txt 2>&1
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
