@@ -1,25 +1,29 @@
 // hipcc-flags: -fno-honor-nans
 // (build.py reads the line above: no NaN canonicalisation in front of every v_max3_f32; infinities keep their meaning.)
-// Split-precision flash attention of the diffusion trunk, block-skewed form (head dim 48, T5 relative-position bias; operands = the
-// AttnPlanes images the qkv conv wrote; vqvae/utils/diff_util.py:136-215 AttentionBlock / QKVAttentionLegacy,
+// Split-precision flash attention of the diffusion trunk, software-pipelined over 32-key blocks (head dim 48, T5 relative-position bias;
+// operands = the AttnPlanes images the qkv conv wrote; vqvae/utils/diff_util.py:136-215 AttentionBlock / QKVAttentionLegacy,
 // vqvae/utils/xtransformers.py:146-186 RelativePositionBias).
 //
-// Arithmetic, layouts and the lane <-> key mapping are those of attention_x3w.hip (which this kernel replaces on the product path):
+// Arithmetic, layouts and the lane <-> key mapping are those of attention_x3w.hip (the round 2 - 4 kernel, kept behind
+// DTTS_ATTN_KERNEL=w for A/B runs):
 //   S^T[key 32, query 32] += K^T[key, c 16] Q[c 16, query]      3 channel steps x 3 split products   (v_mfma_f32_32x32x16_f16)
 //   O[c 32, query 32]     += V[c, key 16] P^T[key 16, query]    2 channel tiles x 2 key steps x 3 split products
 // a lane (query q = lane & 31, half hh = lane >> 5) holds the 16 keys (r & 3) + 8 (r >> 2) + 4 hh of its query per 32-key block, and
-// those registers are the B operand of the PV product.  What changed is the SCHEDULE (312 vector instructions
-// against 42 MFMAs per 64-key tile, matrix pipe busy 34 %):
-//   * the unit of work is a 32-key BLOCK, skewed by one block inside a wave: step b issues the 9 QK^T MFMAs of block b + 1 and the 12 PV
-//     MFMAs of block b in ONE basic block with the softmax of block b between them, so the vector work of a block sits in the shadow
-//     of 21 MFMAs of the same wave (the scheduler cannot move code across the old kernel's per-tile branches); only two 16-register
-//     score sets are live (the old form held two whole tiles: 64 registers, and copied one onto the other every tile);
-//   * a step is instantiated per block class, chosen by a scalar branch: FAR (every (key, query) pair of the wave's block beyond the
-//     bias window on one side: one bucket, no table look-up), FAR + tail mask, NEAR (bias from an LDS table extended to +-128 so the
-//     look-up is one ds_read at a constant offset from a per-lane base: no clamp, no address arithmetic per score);
-//   * the softmax numerators are split with v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16 (3 instructions per pair instead of 4);
-//   * K tiles are double-buffered, V travels in 32-key half tiles through a ring of four 6 KiB slots (step b needs K of block b + 1
-//     and V of block b: half a tile of skew), 24 LDS-DMA pieces per 64 keys as before, one barrier per 64 keys.
+// those registers are the B operand of the PV product.  What changed is the SCHEDULE and the vector-instruction count (VERDICT r04
+// item 1: 312 vector instructions against 42 MFMAs per 64-key tile, matrix pipe busy 34 %):
+//   * the unit of work is a 32-key BLOCK and a step is pipelined over three of them - QK^T of block b + 1, softmax of block b, PV of
+//     block b - 1 - so none of a step's 21 MFMAs depends on its vector work (attn_step below);
+//   * the accumulators are touched by ONE code path: every join at which they are live on both sides (block-class arms, a C++ rescale
+//     branch, `if (wave active)` inside the loop) cost a copy of 32 registers per block; the block classes run as separate loops;
+//   * FAR blocks (every (key, query) pair beyond the bias window on one side: one bucket) look nothing up; NEAR blocks read the bias
+//     from an LDS table extended to +-128, at constant offsets from a per-lane base (no clamp, no address arithmetic per score);
+//   * the softmax denominator comes out of the PV MFMAs (the 16 unused rows of the second channel tile read a "ones" fragment);
+//   * the numerators are split with v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16 (3 instructions per pair instead of 4);
+//   * K tiles are double-buffered, V travels in 32-key blocks through a ring of four 6 KiB slots one tile behind K, 24 LDS-DMA pieces
+//     and one barrier per 64 keys as before.
+// Vector instructions per launch 1.92e7 -> 1.51e7 (rocprofv3 SQ_INSTS_VALU, B = 8, T = 936), 102.6 -> 94.5 us alone
+// (profiles/r05_attn_ablate_pipelined.txt); under the bench the chip runs at its 1400 W power limit (profiles/r05_power_bench.txt:
+// 1340 - 1360 W, 1.97 GHz) and the step time does not move (DESIGN.md par. 4).
 #include <type_traits>
 
 #include "attention.h"
@@ -72,54 +76,98 @@ __device__ __forceinline__ void split_pair_mix(float x, float y, unsigned& w0, u
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], Bq[1], acc, 0, 0, 0);             \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], Bq[0], acc, 0, 0, 0);
 
-// The PV products accumulate IN PLACE through tied asm operands.  With the builtin the compiler picked the untied form (vdst != srcC)
-// on some paths and moved all 32 accumulator registers once per block (16 v_mov_b64 per step: 1 in 6 of the vector instructions of
-// the loop); tied, the accumulators live in one register tuple for the whole kernel.  The compiler does not know these are MFMAs:
-//   * operands written by VALU just before (the P planes): one wait state in front (s_nop 1 covers two);
-//   * results read by VALU (the rescale, the epilogue): 19 wait states, supplied there by hand (mfma_result_fence / the rescale);
-//   * the LDS fragments they read are ordinary register operands: the compiler's own s_waitcnt lgkmcnt covers them.
-__device__ __forceinline__ void pv_mfma3(f16v& acc, const hf8 (&a)[NPL], const hf8 (&b)[NPL]) {
-    asm("s_nop 1\n\t"
-        "v_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\t"
-        "v_mfma_f32_32x32x16_f16 %0, %2, %4, %0\n\t"
-        "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0"
-        : "+v"(acc)
-        : "v"(a[1]), "v"(a[0]), "v"(b[0]), "v"(b[1]));
-}
-__device__ __forceinline__ void mfma_result_fence(f16v& a, f16v& b) {
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b));
-}
-
 struct WaveState {
     hf8 qf[3][NPL];        // Q fragments (B operand of QK^T)
     f16v oacc[2];          // O accumulators: channels 0..31 | 32..47, row 48 (oacc[1][8]) = the denominator, 15 unused rows
     f16v s[2];             // score sets: s[b & 1] holds block b
+    hf8 pf[2][NPL];        // P planes of the block whose PV product is still to come (key step j: the lane's registers 8 j .. 8 j + 7)
     float m_run;
+    float alpha;           // pending rescale of the accumulators (decided by the last softmax, applied before the next PV product)
+    unsigned long long need;   // ... lanes mask: != 0 when some query of the wave raised its maximum
 };
 
-// One step of a wave: QK^T of block bq (into st.s[bq & 1]) and softmax + PV of block bs = bq - 1 (from st.s[bs & 1]).
-//   kb_addr: this lane's byte address of K chunk (plane 0, c8 = hh, key q) of the stage that holds block bq's tile (+ its kb half)
-//   v_addr0 / v_addr1: byte address of V chunk (plane 0, j 0, hh, channel vch0 / vch1) of block bs's ring slot; lanes q >= 16 pass the
-//   ones area as v_addr1
-//   mode: the block class of bs (wave-uniform).  Only the first part - exponent arguments and their maximum - depends on it and is
-//   branched; everything that touches the accumulators is ONE code path (a join with the accumulators live on both sides makes the
-//   compiler keep them in two register sets and move 32 registers per block).
-template <int PAR /* bs & 1 */, bool DO_QK, bool DO_SM, int ABL>
-__device__ __forceinline__ void attn_step(WaveState& st, const unsigned char* smem, unsigned kb_addr, unsigned v_addr0, unsigned v_addr1, int mode,
+// One step b of a wave, software-pipelined over THREE blocks so that none of its 21 MFMAs depends on anything computed in the step:
+//   QK^T of block b + 1 (9 MFMAs, into st.s[(b + 1) & 1]),  PV of block b - 1 (12 MFMAs, from st.pf = the planes the previous step made),
+//   softmax of block b (vector pipe: st.s[b & 1] -> st.pf), one MFMA : three to four vector instructions (sched_group_barrier).
+// Measured on the instruction mix alone (tools/ubench/attn_phase.hip): a wave that alternates QK^T -> softmax -> PV phases runs 1307
+// cycles per step at three waves per SIMD, this schedule 1188, the matrix pipe alone 987 (random operands: the power-limited clock).
+// The rescale a block's softmax decides (a query's maximum grew by more than 2^3) must reach the accumulators AFTER the PV product of
+// the block before it and BEFORE its own: it is applied at the top of the next step - by then the MFMAs it has to wait for are a whole
+// step old.  It is ONE asm statement with its own skip branch and tied operands: as a C++ branch it costs a copy of the 32 accumulator
+// registers per block on the path not taken.
+//   kb_addr: this lane's byte address of K chunk (plane 0, c8 = hh, key q) of the stage that holds block b + 1's tile (+ its half)
+//   v_addr0 / v_addr1: byte address of V chunk (plane 0, j 0, hh, channel vch0 / vch1) of block b - 1; lanes q >= 16 pass the ones area
+//   GENERAL: the block class of b is NEAR or FAR_MASK (bias from the extended table / tail mask); else FAR (one bias, no mask)
+template <int PAR /* b & 1 */, bool DO_QK, bool DO_PV, bool DO_SM, bool GENERAL, int ABL>
+__device__ __forceinline__ void attn_step(WaveState& st, const unsigned char* smem, unsigned kb_addr, unsigned v_addr0, unsigned v_addr1, bool near,
                                           const float* ext_lane, int lim, float bfar) {
     f16v& sq = st.s[PAR ^ 1];
     f16v& ss = st.s[PAR];
+    if (DO_PV) {
+        // The accumulators are pinned to v[200:231] HERE (physical-register constraints), so that the 32 multiplies can name their
+        // registers: with one tied operand per element the allocator scattered the two tuples over single registers and re-assembled
+        // them with ~40 moves in front of every group of MFMAs.  The copies to / from the pinned registers coalesce away when the
+        // allocator keeps the tuples there for the whole kernel, which it does (no v_mov in the loop: checked in the ISA).
+        asm volatile(
+            "s_cmp_eq_u64 %[need], 0\n\t"
+            "s_cbranch_scc1 .Lx3b_skip_%=\n\t"
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"       // an MFMA result needs 19 wait states before a VALU read (the hazard recognizer does not see asm)
+            "v_mul_f32 v200, %[al], v200\n\t"
+            "v_mul_f32 v201, %[al], v201\n\t"
+            "v_mul_f32 v202, %[al], v202\n\t"
+            "v_mul_f32 v203, %[al], v203\n\t"
+            "v_mul_f32 v204, %[al], v204\n\t"
+            "v_mul_f32 v205, %[al], v205\n\t"
+            "v_mul_f32 v206, %[al], v206\n\t"
+            "v_mul_f32 v207, %[al], v207\n\t"
+            "v_mul_f32 v208, %[al], v208\n\t"
+            "v_mul_f32 v209, %[al], v209\n\t"
+            "v_mul_f32 v210, %[al], v210\n\t"
+            "v_mul_f32 v211, %[al], v211\n\t"
+            "v_mul_f32 v212, %[al], v212\n\t"
+            "v_mul_f32 v213, %[al], v213\n\t"
+            "v_mul_f32 v214, %[al], v214\n\t"
+            "v_mul_f32 v215, %[al], v215\n\t"
+            "v_mul_f32 v216, %[al], v216\n\t"
+            "v_mul_f32 v217, %[al], v217\n\t"
+            "v_mul_f32 v218, %[al], v218\n\t"
+            "v_mul_f32 v219, %[al], v219\n\t"
+            "v_mul_f32 v220, %[al], v220\n\t"
+            "v_mul_f32 v221, %[al], v221\n\t"
+            "v_mul_f32 v222, %[al], v222\n\t"
+            "v_mul_f32 v223, %[al], v223\n\t"
+            "v_mul_f32 v224, %[al], v224\n\t"
+            "v_mul_f32 v225, %[al], v225\n\t"
+            "v_mul_f32 v226, %[al], v226\n\t"
+            "v_mul_f32 v227, %[al], v227\n\t"
+            "v_mul_f32 v228, %[al], v228\n\t"
+            "v_mul_f32 v229, %[al], v229\n\t"
+            "v_mul_f32 v230, %[al], v230\n\t"
+            "v_mul_f32 v231, %[al], v231\n\t"
+            "s_nop 3\n"
+            ".Lx3b_skip_%=:"
+            : "+{v[200:215]}"(st.oacc[0]), "+{v[216:231]}"(st.oacc[1])
+            : [al] "v"(st.alpha), [need] "s"(st.need)
+            : "scc");
+    }
+    // ---- LDS fragments, then the 21 MFMAs: they depend on registers of earlier steps only
     hf8 ka[3][NPL], va[2][2][NPL];                           // K fragments of the 3 channel steps; V fragments [key step][channel tile]
-    auto vfrag = [&](int j) {
+    if (DO_QK && !(ABL & 32)) {
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            va[j][0][pl] = as_hf(*reinterpret_cast<const uint4*>(smem + v_addr0 + pl * VHALF + j * (2 * D * 16)));
-            va[j][1][pl] = as_hf(*reinterpret_cast<const uint4*>(smem + v_addr1 + pl * VHALF + j * (2 * D * 16)));
-        }
-    };
-    // ABL (measurement builds only, DTTS_ATTN_ABLATE; results are garbage): 1 no LDS-DMA in the loop, 2 no barrier / DMA wait in the
-    // loop, 4 no softmax vector work, 8 no PV MFMAs, 16 no QK^T MFMAs, 32 no LDS fragment reads
-    if (ABL & 32) {
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) ka[s][pl] = as_hf(*reinterpret_cast<const uint4*>(smem + kb_addr + pl * (KCH * 16) + s * (2 * KT * 16)));
+    }
+    if (DO_PV && !(ABL & 32)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                va[j][0][pl] = as_hf(*reinterpret_cast<const uint4*>(smem + v_addr0 + pl * VHALF + j * (2 * D * 16)));
+                va[j][1][pl] = as_hf(*reinterpret_cast<const uint4*>(smem + v_addr1 + pl * VHALF + j * (2 * D * 16)));
+            }
+    }
+    if (ABL & 32) {          // measurement build: no fragment reads
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -129,37 +177,36 @@ __device__ __forceinline__ void attn_step(WaveState& st, const unsigned char* sm
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) va[j][0][pl] = va[j][1][pl] = st.qf[j][pl];
     }
-    if (DO_QK && !(ABL & 32)) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) ka[s][pl] = as_hf(*reinterpret_cast<const uint4*>(smem + kb_addr + pl * (KCH * 16) + s * (2 * KT * 16)));
-    }
-    if (DO_SM && !(ABL & 32)) vfrag(0);
-    if (DO_QK) {
+    if (DO_QK && !(ABL & 16)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sq[r] = 0.f;
-        if (!(ABL & 16)) { DTTS_X3B_MFMA(sq, ka[0], st.qf[0]) }
+        DTTS_X3B_MFMA(sq, ka[0], st.qf[0])
+        DTTS_X3B_MFMA(sq, ka[1], st.qf[1])
+        DTTS_X3B_MFMA(sq, ka[2], st.qf[2])
     }
-    // Two wave-uniform branch points on the block class, before and after the rescale.  Each arm only READS the scores and DEFINES
-    // fresh values (the maximum and, for NEAR / FAR_MASK, the exponent arguments e; then the P planes): a value that one arm changes in
-    // place and another leaves alone would be copied on the arm that leaves it alone (16 registers per block on the FAR path).
-    f16v e;                                                  // NEAR / FAR_MASK: exponent arguments (log2 domain), masked; FAR: unused
+    if (DO_PV && !(ABL & 8)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            DTTS_X3B_MFMA(st.oacc[0], va[j][0], st.pf[j])
+            DTTS_X3B_MFMA(st.oacc[1], va[j][1], st.pf[j])
+        }
+    }
+    // ---- softmax of block b: exponent arguments e = s + bias (log2 domain) of this lane's 16 keys and their maximum, the lazy running
+    // maximum (decided per query: both lanes of a query see the pair's maximum; P = exp2(e - m + 10) <= 8192 otherwise), the P planes
     if (DO_SM && !(ABL & 4)) {
+        f16v e;                                              // GENERAL only
         float mx;
-        if (mode == NEAR) {          // bias from the extended table, tail mask
+        if (GENERAL) {
+            if (near) {              // bias from the extended table
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = fmaf(ss[r], SU, ext_lane[roff(r)]);
-                e[r] = (roff(r) < lim) ? v : -INFINITY;
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaf(ss[r], SU, ext_lane[roff(r)]);
+                    e[r] = (roff(r) < lim) ? v : -INFINITY;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = (roff(r) < lim) ? fmaf(ss[r], SU, bfar) : -INFINITY;
             }
-            mx = fmaxf(fmaxf(e[0], e[1]), e[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, e[r]), e[r + 1]);
-            mx = fmaxf(mx, e[15]);
-        } else if (mode == FAR_MASK) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = (roff(r) < lim) ? fmaf(ss[r], SU, bfar) : -INFINITY;
             mx = fmaxf(fmaxf(e[0], e[1]), e[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, e[r]), e[r + 1]);
@@ -171,21 +218,14 @@ __device__ __forceinline__ void attn_step(WaveState& st, const unsigned char* sm
             r0 = fmaxf(r0, ss[15]);
             mx = fmaf(r0, SU, bfar);                         // SU > 0: the maximum commutes with the affine map
         }
-        // Lazy running maximum, decided per query (both lanes of a query see the pair's maximum): P = exp2(e - m + 10) <= 8192 otherwise.
-        // The whole conditional rescale is ONE asm statement with its own skip branch: as a C++ branch it made the compiler keep two
-        // copies of the 32 accumulator registers (a phi on the rare path) and move all of them on the path NOT taken.  Inside: the
-        // partner lane's maximum (v_permlane32_swap), m_new = the pair's maximum where it exceeds m_run + 2^3, alpha = exp2(m_run -
-        // m_new) (0 while m_run = -inf), the accumulators (row 48 = the denominator included) times alpha IN PLACE.  The PV MFMAs of
-        // the previous step may still be writing the accumulators: 24 wait states in front of the first multiply (a 32 x 32 MFMA
-        // result needs 19 before a VALU read).  Rare: the first block, and whenever a query's maximum grows by more than 2^3.
         {
-            const unsigned long long need = __builtin_amdgcn_ballot_w64(mx > st.m_run + M_SLACK);
-            float ta, tb;
-            f16v& o0 = st.oacc[0];
-            f16v& o1 = st.oacc[1];
+            // need != 0: the partner lane's maximum (v_permlane32_swap), m_new = the pair's maximum where it exceeds m_run + 2^3,
+            // alpha = exp2(m_run - m_new) (0 while m_run = -inf); the multiplication of the accumulators is the NEXT step's first act
+            st.need = __builtin_amdgcn_ballot_w64(mx > st.m_run + M_SLACK);
+            float tb;
             asm volatile(
                 "s_cmp_eq_u64 %[need], 0\n\t"
-                "s_cbranch_scc1 .Lx3b_skip_%=\n\t"
+                "s_cbranch_scc1 .Lx3b_skipm_%=\n\t"
                 "v_mov_b32 %[ta], %[mx]\n\t"
                 "v_mov_b32 %[tb], %[mx]\n\t"
                 "s_nop 1\n\t"
@@ -200,78 +240,48 @@ __device__ __forceinline__ void attn_step(WaveState& st, const unsigned char* sm
                 "v_sub_f32 %[ta], %[m], %[ta]\n\t"
                 "v_exp_f32 %[ta], %[ta]\n\t"                          // alpha
                 "v_mov_b32 %[m], %[tb]\n\t"
-                "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
-                "v_mul_f32 %0, %[ta], %0\n\tv_mul_f32 %1, %[ta], %1\n\tv_mul_f32 %2, %[ta], %2\n\tv_mul_f32 %3, %[ta], %3\n\t"
-                "v_mul_f32 %4, %[ta], %4\n\tv_mul_f32 %5, %[ta], %5\n\tv_mul_f32 %6, %[ta], %6\n\tv_mul_f32 %7, %[ta], %7\n\t"
-                "v_mul_f32 %8, %[ta], %8\n\tv_mul_f32 %9, %[ta], %9\n\tv_mul_f32 %10, %[ta], %10\n\tv_mul_f32 %11, %[ta], %11\n\t"
-                "v_mul_f32 %12, %[ta], %12\n\tv_mul_f32 %13, %[ta], %13\n\tv_mul_f32 %14, %[ta], %14\n\tv_mul_f32 %15, %[ta], %15\n\t"
-                "v_mul_f32 %16, %[ta], %16\n\tv_mul_f32 %17, %[ta], %17\n\tv_mul_f32 %18, %[ta], %18\n\tv_mul_f32 %19, %[ta], %19\n\t"
-                "v_mul_f32 %20, %[ta], %20\n\tv_mul_f32 %21, %[ta], %21\n\tv_mul_f32 %22, %[ta], %22\n\tv_mul_f32 %23, %[ta], %23\n\t"
-                "v_mul_f32 %24, %[ta], %24\n\tv_mul_f32 %25, %[ta], %25\n\tv_mul_f32 %26, %[ta], %26\n\tv_mul_f32 %27, %[ta], %27\n\t"
-                "v_mul_f32 %28, %[ta], %28\n\tv_mul_f32 %29, %[ta], %29\n\tv_mul_f32 %30, %[ta], %30\n\tv_mul_f32 %31, %[ta], %31\n\t"
-                "s_nop 3\n"
-                ".Lx3b_skip_%=:"
-                : "+v"(o0[0]), "+v"(o0[1]), "+v"(o0[2]), "+v"(o0[3]), "+v"(o0[4]), "+v"(o0[5]), "+v"(o0[6]), "+v"(o0[7]), "+v"(o0[8]), "+v"(o0[9]),
-                  "+v"(o0[10]), "+v"(o0[11]), "+v"(o0[12]), "+v"(o0[13]), "+v"(o0[14]), "+v"(o0[15]), "+v"(o1[0]), "+v"(o1[1]), "+v"(o1[2]),
-                  "+v"(o1[3]), "+v"(o1[4]), "+v"(o1[5]), "+v"(o1[6]), "+v"(o1[7]), "+v"(o1[8]), "+v"(o1[9]), "+v"(o1[10]), "+v"(o1[11]),
-                  "+v"(o1[12]), "+v"(o1[13]), "+v"(o1[14]), "+v"(o1[15]), [m] "+v"(st.m_run), [ta] "=&v"(ta), [tb] "=&v"(tb)
-                : [mx] "v"(mx), [need] "s"(need)
+                "s_nop 0\n"
+                ".Lx3b_skipm_%=:"
+                : [m] "+v"(st.m_run), [ta] "=&v"(st.alpha), [tb] "=&v"(tb)
+                : [mx] "v"(mx), [need] "s"(st.need)
                 : "vcc", "scc");
         }
-    }
-    if (DO_QK && !(ABL & 16)) {
-        DTTS_X3B_MFMA(sq, ka[1], st.qf[1])
-        DTTS_X3B_MFMA(sq, ka[2], st.qf[2])
-    }
-    if (DO_SM) {
         const float m_sub = ((st.m_run == -INFINITY) ? 0.f : st.m_run) - P_SHIFT;
-        hf8 pf[2][NPL];                                      // P planes of the two key steps (key step j: this lane's registers 8 j .. 8 j + 7)
-        auto split_step = [&](int j, const float (&pv)[8]) {
+        const float c0 = bfar - m_sub;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float pv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                pv[k] = __builtin_amdgcn_exp2f(GENERAL ? e[8 * j + k] - m_sub : fmaf(ss[8 * j + k], SU, c0));      // 1024 P: the scale is free in the exponent
             uint4 w0, w1;
             split_pair_mix(pv[0], pv[1], w0.x, w1.x);
             split_pair_mix(pv[2], pv[3], w0.y, w1.y);
             split_pair_mix(pv[4], pv[5], w0.z, w1.z);
             split_pair_mix(pv[6], pv[7], w0.w, w1.w);
-            pf[j][0] = as_hf(w0);
-            pf[j][1] = as_hf(w1);
-        };
-        if (ABL & 4) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) pf[j][pl] = st.qf[j][pl];
-        } else if (mode == FAR) {
-            const float c0 = bfar - m_sub;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float pv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pv[k] = __builtin_amdgcn_exp2f(fmaf(ss[8 * j + k], SU, c0));      // 1024 P: the scale is free in the exponent
-                split_step(j, pv);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float pv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pv[k] = __builtin_amdgcn_exp2f(e[8 * j + k] - m_sub);
-                split_step(j, pv);
-            }
-        }
-        if (!(ABL & 32)) vfrag(1);
-        if (!(ABL & 8)) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                pv_mfma3(st.oacc[0], va[j][0], pf[j]);
-                pv_mfma3(st.oacc[1], va[j][1], pf[j]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) asm volatile("" ::"v"(pf[j][pl]), "v"(va[j][0][pl]), "v"(va[j][1][pl]));
+            st.pf[j][0] = as_hf(w0);
+            st.pf[j][1] = as_hf(w1);
         }
     }
+    if (DO_SM && (ABL & 4)) st.need = 0;
+    if (DO_QK && DO_PV && DO_SM && !GENERAL && !(ABL & 28)) {
+        // the hot instantiation: one MFMA, then three or four vector / transcendental instructions (21 MFMAs : ~72)
+        constexpr int M_MFMA = 0x8, M_VALU = 0x2 | 0x400;
+#define DTTS_X3B_SGB2                                          \
+    __builtin_amdgcn_sched_group_barrier(M_MFMA, 1, 0);       \
+    __builtin_amdgcn_sched_group_barrier(M_VALU, 3, 0);       \
+    __builtin_amdgcn_sched_group_barrier(M_MFMA, 1, 0);       \
+    __builtin_amdgcn_sched_group_barrier(M_VALU, 4, 0);
+        DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2 DTTS_X3B_SGB2
+        __builtin_amdgcn_sched_group_barrier(M_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(M_VALU, 4, 0);
+#undef DTTS_X3B_SGB2
+    }
+}
+
+// VALU reads of MFMA results whose producers the compiler did not order for us (the rescale asm writes, then the epilogue reads): 24 wait states
+__device__ __forceinline__ void mfma_result_fence(f16v& a, f16v& b) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b));
 }
 
 template <int MINB, int ABL>
@@ -308,23 +318,23 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     const int ntiles = (len + KT - 1) / KT, nblk = 2 * ntiles;
     const bool wave_active = tq0 < len;
 
-    // LDS-DMA of the data step group j1 needs (issued one group ahead): K tile j1, V blocks 2 j1 - 1 and 2 j1: 24 pieces of 1 KiB, six
-    // per wave - K pieces wave, wave + 4, wave + 8 and the three pieces of plane (wave & 1) of V block 2 j1 - 1 + (wave >> 1).  Every
-    // piece is unconditionally live: a tile / block index beyond the sequence is clamped to the last one (the piece lands in a stage or
-    // slot nobody reads before it is overwritten: the stages and slots of groups j1 - 2 / blocks b - 4).
+    // LDS-DMA of what iteration j1 needs (issued one iteration ahead): K tile j1 and V tile j1 - 1 = blocks 2 j1 - 2, 2 j1 - 1 (the PV
+    // product runs two blocks behind QK^T): 24 pieces of 1 KiB, six per wave - K pieces wave, wave + 4, wave + 8 and the three pieces
+    // of plane (wave & 1) of V block 2 j1 - 2 + (wave >> 1).  K stage = tile parity; a V block lives in ring slot (block & 3) as
+    // [plane][j][hh][channel].  Every piece is unconditionally live: a tile index outside the sequence is clamped (the piece lands in
+    // a stage / slot nobody reads before it is overwritten).
     const unsigned lane16 = lane * 16;
     const unsigned char* lane_img = kvimg + lane16;
-    auto dma_group = [&](int j1) {
-        const int kt = j1 < ntiles ? j1 : ntiles - 1;
+    auto dma_group = [&](int j1) __attribute__((always_inline)) {
+        const int kt = j1 < ntiles ? j1 : ntiles - 1, vt = j1 < 1 ? 0 : j1 - 1;
         const unsigned char* ksrc = lane_img + (size_t)kt * AttnPlanes::TILE_BYTES + wave * 1024;
         const unsigned kdst = LDS_K + (j1 & 1) * KBYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + i * 4096),
                                              (__attribute__((address_space(3))) void*)(smem + kdst + i * 4096), 16, 0, 0);
-        const int blk = 2 * j1 - 1 + (wave >> 1), pl = wave & 1;
-        const int bc = blk < 0 ? 0 : (blk < nblk ? blk : nblk - 1);
-        const unsigned char* vsrc = lane_img + (size_t)(bc >> 1) * AttnPlanes::TILE_BYTES + KBYTES + pl * VPLANE_G + (bc & 1) * VHALF;
+        const int u = wave >> 1, pl = wave & 1, blk = 2 * j1 - 2 + u;
+        const unsigned char* vsrc = lane_img + (size_t)vt * AttnPlanes::TILE_BYTES + KBYTES + pl * VPLANE_G + u * VHALF;
         const unsigned vdst = LDS_V + (blk & 3) * VSLOT + pl * VHALF;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -346,33 +356,34 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.oacc[ct][r] = 0.f;
     st.m_run = -INFINITY;
+    st.alpha = 1.f;
+    st.need = 0;
 
     dma_group(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // per-lane LDS byte offsets: K chunk (plane 0, c8 = hh, key q); V chunks (plane 0, j 0, hh, channel vch): channel ct 32 + q, the
-    // padding rows 48..63 of channel tile 1 re-read valid chunks (their accumulator rows are never stored)
+    // per-lane LDS byte offsets: K chunk (plane 0, c8 = hh, key q); V chunks (plane 0, j 0, hh, channel vch) of a ring slot: channel
+    // ct 32 + q; lanes q >= 16 of the second channel tile (accumulator rows 48..63) read the ones area, whatever the slot: row 48 = sum of P
     const unsigned k_lane = LDS_K + (hh * KT + q) * 16;
     const int vch0 = q, vch1 = 32 + (q & 15);
-    // lanes q >= 16 of the second channel tile (accumulator rows 48..63) read the ones area, whatever the slot: row 48 = sum of P
     const unsigned v_lane0 = LDS_V + (hh * D + vch0) * 16, v_lane1 = q < 16 ? LDS_V + (hh * D + vch1) * 16 : LDS_ONES;
     const unsigned slot_mask1 = q < 16 ? ~0u : 0u;
 
-    // step b: QK^T of block b + 1, softmax + PV of block b; the block class of b (wave-uniform) goes in as `mode`
-    auto step = [&](int bs, auto par, auto do_qk, auto do_sm) {
+    // step b: QK^T of block b + 1, PV of block b - 1, softmax of block b with the FAR or the GENERAL code (gen)
+    auto step = [&](int bs, auto par, auto do_qk, auto do_pv, auto do_sm, auto gen) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
-        constexpr bool DQ = decltype(do_qk)::value, DS = decltype(do_sm)::value;
-        const int bq = bs + 1;
+        constexpr bool DQ = decltype(do_qk)::value, DP = decltype(do_pv)::value, DS = decltype(do_sm)::value, GEN = decltype(gen)::value;
+        const int bq = bs + 1, bv = bs - 1;
         const unsigned kb_addr = k_lane + ((bq >> 1) & 1) * KBYTES + (bq & 1) * (32 * 16);
-        const unsigned va0 = v_lane0 + (bs & 3) * VSLOT, va1 = v_lane1 + (((bs & 3) * VSLOT) & slot_mask1);
+        const unsigned voff = (bv & 3) * VSLOT;
+        const unsigned va0 = v_lane0 + voff, va1 = v_lane1 + (voff & slot_mask1);
         const int s0b = bs * 32;
         const bool far_hi = s0b - (tq0 + QPW - 1) >= BIAS_CLIP, far_lo = (s0b + 31) - tq0 <= -BIAS_CLIP;
-        const int mode = !(far_hi || far_lo) ? NEAR : (s0b + 32 > len ? FAR_MASK : FAR);
         const int lim = len - s0b - 4 * hh;                                  // key of register r is valid iff roff(r) < lim
         const float bfar = far_hi ? bias_hi : bias_lo;
-        const float* ext_lane = ext_s + (s0b + 4 * hh - t + EXT_HALF);       // NEAR only: in range there
-        attn_step<PAR, DQ, DS, ABL>(st, smem, kb_addr, va0, va1, mode, ext_lane, lim, bfar);
+        const float* ext_lane = ext_s + (s0b + 4 * hh - t + EXT_HALF);       // near blocks only: in range there
+        attn_step<PAR, DQ, DP, DS, GEN, ABL>(st, smem, kb_addr, va0, va1, !(far_hi || far_lo), ext_lane, lim, bfar);
     };
     using T1 = std::integral_constant<bool, true>;
     using T0 = std::integral_constant<bool, false>;
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     using P1 = std::integral_constant<int, 1>;
 
     // Waves whose 32 queries all lie beyond the length only stage their share of the tiles (same barriers); the active ones run the
-    // steps.  Two separate loops: a per-iteration `if (active)` is a join with the accumulators live on both sides (see attn_step).
+    // steps.  Two separate loops: a per-iteration `if (active)` is a join with the accumulators live on both sides.
     dma_group(1);
     if (!wave_active) {
         for (int j = 1; j <= ((ABL & 2) ? 1 : ntiles); ++j) {
@@ -390,23 +401,49 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
         }
         return;
     }
-    // group 0: QK^T of block 0 alone (block 0 goes to s[0]: "step -1" has odd parity), then step 0
-    step(-1, P1{}, T1{}, T0{});
-    step(0, P0{}, T1{}, T1{});
+    // iteration 0: QK^T of block 0 alone (block 0 goes to s[0]: "step -1" has odd parity), then step 0 (no PV yet)
+    step(-1, P1{}, T1{}, T0{}, T0{}, T1{});
+    step(0, P0{}, T1{}, T0{}, T1{}, T1{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int j = 1; j < ntiles; ++j) {
-        if (!(ABL & 1)) dma_group(j + 1);          // K(j + 1) into the stage K(j - 1) left, V(2 j + 1), V(2 j + 2) into the slots V(2 j - 3), V(2 j - 2) left
-        step(2 * j - 1, P1{}, T1{}, T1{});
-        step(2 * j, P0{}, T1{}, T1{});
+    // Iterations 1 .. ntiles - 1 = steps (2 j - 1, 2 j), whose softmax blocks are 2 j - 1 and 2 j.  An iteration is FAR when both blocks lie
+    // wholly beyond the bias window on one side and inside the length, else GENERAL; along j that is at most: FAR, GENERAL (the band
+    // around the wave's queries: ~4 iterations), FAR, GENERAL (a masked tail).  Each run is its own loop over ONE code path - choosing
+    // the path per iteration is a join that costs a copy of the accumulators every time.
+    auto iteration = [&](int j, auto gen) __attribute__((always_inline)) {
+        if (!(ABL & 1)) dma_group(j + 1);          // K(j + 1) into the stage K(j - 1) left, V(j) into the slots V(j - 2) left
+        step(2 * j - 1, P1{}, T1{}, T1{}, T1{}, gen);
+        step(2 * j, P0{}, T1{}, T1{}, T1{}, gen);
         if (!(ABL & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of group j + 1 have landed (the barrier covers the others')
             __syncthreads();
         }
+    };
+    {
+        // blocks b with 32 b + 31 - tq0 <= -64 are far below, with 32 b - (tq0 + 31) >= 64 far above; blocks >= bmask reach beyond len
+        const int b_lo_end = (tq0 - BIAS_CLIP - 31 >= 0) ? (tq0 - BIAS_CLIP - 31) / 32 + 1 : 0;      // first block that is not far below
+        const int b_hi_beg = (tq0 + QPW - 1 + BIAS_CLIP + 31) / 32;                                  // first block that is far above
+        const int bmask = len / 32;                                                                  // first block with a key >= len
+        auto clampj = [&](int v) { return v < 1 ? 1 : (v > ntiles ? ntiles : v); };
+        // iteration j is FAR-below iff 2 j < b_lo_end, FAR-above iff 2 j - 1 >= b_hi_beg; masked iff 2 j >= bmask
+        const int jA = clampj(b_lo_end / 2 + ((b_lo_end & 1) ? 1 : 0));            // first j with 2 j >= b_lo_end  (= ceil(b_lo_end / 2))
+        const int jB = clampj((b_hi_beg + 2) / 2);                                 // first j with 2 j - 1 >= b_hi_beg
+        const int jM = clampj((bmask + 1) / 2);                                    // first j with 2 j >= bmask
+        const int e1 = jA < jM ? jA : jM, e2 = (jB > e1 ? jB : e1) < jM ? (jB > e1 ? jB : e1) : jM;
+        for (int j = 1; j < e1; ++j) iteration(j, T0{});
+        for (int j = e1; j < e2; ++j) iteration(j, T1{});
+        for (int j = e2; j < jM; ++j) iteration(j, T0{});
+        for (int j = jM; j < ntiles; ++j) iteration(j, T1{});
     }
-    step(nblk - 1, P1{}, T0{}, T1{});
+    if (ABL & 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // V(ntiles - 1) arrived with the last group: the last softmax with the PV product before it, then the PV product of the last block
+    step(nblk - 1, P1{}, T0{}, T1{}, T1{}, T1{});
+    step(nblk, P0{}, T0{}, T1{}, T0{}, T1{});
 
-    mfma_result_fence(st.oacc[0], st.oacc[1]);          // the last PV products are asm: their results are about to be read by VALU
+    mfma_result_fence(st.oacc[0], st.oacc[1]);
     if (t >= len) return;
     const float inv = 1.f / st.oacc[1][8];              // acc = (1024 P)(16 V); row 48 = (1024 P)(16): the denominator at V's scale
     // lane (q, hh) holds channels ct 32 + 8 rg + 4 hh + (0..3) of query t: half hh of the 8-channel chunk ct 4 + rg
@@ -441,8 +478,8 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
 void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream) {
     DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out && p.planes, "attention_x3b covers head dim 48 with the T5 bias on operand images");
     constexpr int NW = 4;
-    // workgroups per CU: 2 (<= 256 registers; 1024 workgroups of the headline launch = exactly two rounds of 512) or, DTTS_ATTN_OCC=3, 3
-    static const int occ = []() { const char* v = getenv("DTTS_ATTN_OCC"); return v ? atoi(v) : 3; }();
+    // workgroups per CU: 2 (218 registers; 1024 workgroups of the headline launch = two full rounds of 512) or, DTTS_ATTN_OCC=3, 3 (spills)
+    static const int occ = []() { const char* v = getenv("DTTS_ATTN_OCC"); return v ? atoi(v) : 2; }();
     const dim3 grid(cdiv(p.T, NW * QPW) * p.H * p.B);
     static const int abl = []() { const char* v = getenv("DTTS_ATTN_ABLATE"); return v ? atoi(v) : 0; }();
     auto go = [&](auto kern) {
@@ -451,17 +488,17 @@ void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream) {
     };
     if (abl) {          // measurement builds (garbage results): which ingredient of the loop costs what (DESIGN.md par. 4)
         switch (abl) {
-            case 1: go(flash_attn_x3b_kernel<3, 1>); break;
-            case 2: go(flash_attn_x3b_kernel<3, 2>); break;
-            case 3: go(flash_attn_x3b_kernel<3, 3>); break;
-            case 4: go(flash_attn_x3b_kernel<3, 4>); break;
-            case 8: go(flash_attn_x3b_kernel<3, 8>); break;
-            case 16: go(flash_attn_x3b_kernel<3, 16>); break;
-            case 24: go(flash_attn_x3b_kernel<3, 24>); break;
-            case 28: go(flash_attn_x3b_kernel<3, 28>); break;
-            case 32: go(flash_attn_x3b_kernel<3, 32>); break;
-            case 35: go(flash_attn_x3b_kernel<3, 35>); break;
-            case 39: go(flash_attn_x3b_kernel<3, 39>); break;
+            case 1: go(flash_attn_x3b_kernel<2, 1>); break;
+            case 2: go(flash_attn_x3b_kernel<2, 2>); break;
+            case 3: go(flash_attn_x3b_kernel<2, 3>); break;
+            case 4: go(flash_attn_x3b_kernel<2, 4>); break;
+            case 8: go(flash_attn_x3b_kernel<2, 8>); break;
+            case 16: go(flash_attn_x3b_kernel<2, 16>); break;
+            case 24: go(flash_attn_x3b_kernel<2, 24>); break;
+            case 28: go(flash_attn_x3b_kernel<2, 28>); break;
+            case 32: go(flash_attn_x3b_kernel<2, 32>); break;
+            case 35: go(flash_attn_x3b_kernel<2, 35>); break;
+            case 39: go(flash_attn_x3b_kernel<2, 39>); break;
             default: DTTS_REQUIRE(false, "DTTS_ATTN_ABLATE: 1, 2, 3, 4, 8, 16, 24, 28, 32, 35 or 39");
         }
     } else if (occ == 2) {
