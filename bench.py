@@ -120,6 +120,62 @@ def cpu_baseline(W, seed=1234):
                        "which the reference's own decode does not have); oracle code on torch fp32 CPU kernels (oracle/ops.py::use_torch), not the reference's own code")}
 
 
+class PowerSampler:
+    """Board power and shader clock of THIS rank's GPU over the timed region, read from the amdgpu hwmon files every 50 ms by a host
+    thread (no GPU work, no rocm-smi process).  Stage B runs the chip at its power limit (profiles/r05_power_bench.txt: 1340 - 1360 W of
+    a 1400 W cap at 1.95 - 2.1 GHz instead of 2.4), which is what the kernels' rooflines have to be read against."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        import torch
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cand = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            self.dir = cand[0] if cand else None
+        except Exception:
+            self.dir = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((self._read("power1_input") * 1e-6, self._read("freq1_input") * 1e-6))
+            except Exception:
+                return
+            self._stop.wait(0.05)
+
+    def start(self):
+        if self.dir:
+            self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self.dir and self._th.is_alive():
+            self._th.join()
+        if not self.samples:
+            return None
+        w = [a for a, _ in self.samples]
+        f = [b for _, b in self.samples]
+        cap = None
+        try:
+            cap = self._read("power1_cap") * 1e-6
+        except Exception:
+            pass
+        return {"samples": len(w), "mean_W": round(sum(w) / len(w), 1), "max_W": round(max(w), 1), "cap_W": cap,
+                "mean_sclk_MHz": round(sum(f) / len(f)), "min_sclk_MHz": round(min(f)), "max_sclk_MHz": round(max(f)),
+                "source": "amdgpu hwmon power1_input / freq1_input, 50 ms period, over the timed region"}
+
+
 def decode_bytes_per_token(cfg, B, lp_mean, n_codes):
     """Algorithmic HBM bytes of ONE decode step: every GPT-2 weight matrix + the mel head once (fp32), + the KV cache
     of all rows at the mean cached length."""
@@ -290,6 +346,7 @@ def main():
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
+    power = PowerSampler(local).start()
     t0 = time.perf_counter()
     outs = run_steps(100, args.steps)
     wavs, lens = [o[0] for o in outs], outs[-1][1]
@@ -297,6 +354,7 @@ def main():
     if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
+    power = power.stop()
     prof = model.rt.profile_report()
     model.rt.profile_enable(False)
     model.rt.profile_sampling(1)
@@ -484,6 +542,7 @@ def main():
         "rank_ms_per_step": rank_ms, "weight_broadcast": bcast,
         "stage_ms": stage_ms,
         "pipelined_equals_blocking": pipelined_equals_blocking,
+        "power": power,
         **extra,
         "roofline": roof,
         "roofline_attention": roof_att,

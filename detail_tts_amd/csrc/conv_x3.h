@@ -43,8 +43,10 @@ void launch_conv_x3(const ConvParams& p, hipStream_t s);
 // normalises its accumulators where they sit.  Tiles of a fused launch are ordered (sample, M tile, N tile): a tile waits only for
 // tiles at most 2 N - 1 positions ahead of it in dispatch order, so at most that many workgroups per XCD can ever be waiting for an
 // undispatched one - with N <= GN_FUSE_MAX_NT that is far below the workgroup slots of an XCD even with a second fused launch on
-// another stream and the persistent GPT token kernel holding CUs.  Longer sequences and split-K launches keep the
-// separate gn_split_planes pass.
+// another stream and the persistent GPT token kernel holding CUs.  Longer sequences keep the separate gn_split_planes
+// pass.  Split-K launches (batches 1 - 2) carry it too (round 5): only a tile's reducing workgroup reaches the epilogue - built for
+// configs[1] (a batch-1 forward is a chain of ~125 launches of 10 - 40 us), measured SLOWER there as well (forward pair 2751 -> 2896 us:
+// the fused tails cost a conv ~10 us, the pass they replace ~5 us + a launch gap), so it stays an option (gn_fuse), default off.
 constexpr int GN_FUSE_MAX_NT = 6;
 size_t conv_x3_gn_xch_bytes(int B, int Cout, int T);
 // whether launch_conv_x3 can run p with the fused norm (else: conv to p.y, then launch_gn_split_planes)

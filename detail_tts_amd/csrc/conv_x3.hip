@@ -1154,8 +1154,11 @@ static long long split_tiles_max() {
 bool conv_x3_gn_fusable(int Cout, int CoutP, int Cin, int KW, int groups, int B, int T) {
     if (Cout != CoutP || Cout % BM || groups <= 0 || Cout % groups || Cout / groups != 24 || Cin % 16 || (KW != 1 && KW != 3)) return false;
     const int nt = cdiv(T, BN);
-    // split-K launches (<= 128 tiles: batch 1) and long sequences keep the separate pass (conv_x3.h)
-    return nt <= GN_FUSE_MAX_NT && (long long)(CoutP / BM) * nt * B > split_tiles_max();
+    // long sequences keep the separate pass (conv_x3.h).  Split-K launches (<= 128 tiles: batches 1 - 2) carry the fused norm since
+    // round 5: the tile's LAST workgroup to arrive reduces the slabs and runs the fused epilogue like any other tile (the others have
+    // left by then, so the tiles a reducer may wait for are never behind more workgroups than the launch has)
+    (void)B;
+    return nt <= GN_FUSE_MAX_NT;
 }
 
 void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
@@ -1191,7 +1194,7 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     const long long split_tiles = split_tiles_max();
     static const long long split_wgs = []() { const char* v = getenv("DTTS_CONV_KSPLIT_WGS"); return v ? atoll(v) : 256LL; }();
     if (ntile <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile), (p.Cin >> 4) / 8);
-    if (S < 1 || gn) S = 1;
+    if (S < 1) S = 1;
     p.ksplit = S;
     static const bool epi_vec_on = []() { const char* v = getenv("DTTS_X3_EPI_VEC"); return !(v && v[0] == '0'); }();
     auto al16 = [](const void* q, long long bs, int cs) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0 && (bs & 3) == 0 && (cs & 3) == 0; };

@@ -277,7 +277,7 @@ private:
     GnXch gn_xch_[GN_SLOTS];
     int* gn_err_host_ = nullptr;
     int* gn_err_dev_ = nullptr;
-    bool opt_gn_fuse_ = false;            // option "gn_fuse" (measured neutral-to-negative: DESIGN.md par. 4; DTTS_GN_FUSE=0/1 overrides)
+    bool opt_gn_fuse_ = false;            // option "gn_fuse" (measured neutral-to-negative at every batch size: DESIGN.md par. 4; DTTS_GN_FUSE=0/1 overrides)
     void gn_fill(ConvParams& p, int slot, size_t bytes, const GnNext& n, void* out3, int groups, hipStream_t s);
     void gn_check();                      // throws when a fused-GroupNorm poll timed out since the last check
     bool use_x3() const;

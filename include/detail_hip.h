@@ -257,10 +257,11 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 stress-tested bit-identical under stage B / C loads); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
  *   "gpt_token_fault" (test hook, default 0): n > 0 makes the n-th token-kernel launch from now on behave like an exchange time-out;
  *   "gpt_token_fault_eos" (test hook, default 0): 1 = that fault also leaves every row flagged finished (a spurious stop token);
- *   "gn_fuse" (default 0): 1 = in batches of >= 5 utterances at T <= 1152 every GroupNorm + activation + split of the diffusion trunk
- *                 runs in the epilogue of the conv in front of it (tiles exchange partial statistics through tagged words; 8 -> 5
- *                 launches per layer, csrc/conv_x3.h "fused GroupNorm").  Same values up to the summation order of the statistics.
- *                 Measured neutral alone and 1.6 % slower under the three-stream pipeline, hence off; env DTTS_GN_FUSE;
+ *   "gn_fuse" (default 0): 1 = every GroupNorm + activation + split of the diffusion trunk (T <= 1152) runs in the epilogue of the conv
+ *                 in front of it (tiles exchange partial statistics through tagged words; 8 -> 5 launches per layer, csrc/conv_x3.h
+ *                 "fused GroupNorm"; since round 5 also on the split-K launches of batches 1 - 2).  Same values up to the summation
+ *                 order of the statistics.  Measured neutral alone and 1.6 % slower under the three-stream pipeline at the headline
+ *                 batch, 5 % slower at batch 1, hence off; env DTTS_GN_FUSE;
  *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
  *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
  *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.

@@ -116,6 +116,30 @@ def test_fused_groupnorm_forward_B6_T936_vs_reference_and_unfused(rt, I, G):
     assert np.array_equal(again, outs[1][0]) and not np.array_equal(outs[1][0], outs[0][0])
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_fused_groupnorm_on_split_k_launches_vs_reference_and_unfused(rt, I, G, B):
+    """Batches 1 and 2 (launches of <= 128 tiles: split-K, 2 - 4 workgroups per tile): since round 5 the fused GroupNorm epilogue runs in
+    the tile's reducing workgroup (option gn_fuse; off by default: measured slower there too).  Row 0 against the reference's own
+    DiffusionTts.forward (vqvae/diff_model.py:262-322), every row (one ragged) against the separate passes."""
+    rs = np.random.RandomState(14)
+    lens = [T, 700][:B]
+    x = np.concatenate([I["x"], rs.randn(1, 128, T).astype(np.float32)])[:B]
+    ce = np.concatenate([I["code_emb"], (rs.randn(1, 768, T) * 0.5).astype(np.float32)])[:B]
+    outs = {}
+    for fuse in (1, 0):
+        rt.set_option("gn_fuse", fuse)
+        try:
+            outs[fuse] = (host(rt.diff_forward(dev(x), 47, dev(ce), lens=lens)), host(rt.diff_forward(dev(x), 47, cond_free=True, lens=lens)))
+        finally:
+            rt.set_option("gn_fuse", 0)
+    check_sub(outs[1][0][0], G, "fwd47_cond", 3e-4)
+    check_sub(outs[1][1][0], G, "fwd47_uncond", 3e-4)
+    for h in (0, 1):
+        for b, L in enumerate(lens):
+            tol(f"fused_gn_splitk_B{B}_vs_unfused_half{h}_row{b}", maxabs(outs[1][h][b, :, :L], outs[0][h][b, :, :L]), 5e-5)
+    assert not np.array_equal(outs[1][0], outs[0][0])
+
+
 def test_p_sample_T936_vs_reference(rt, I, G):
     """One GaussianDiffusion.p_sample (vqvae/utils/diffusion.py:445-485) at i = 49, T = 936, Philox noise on the device."""
     x1, x0 = rt.diff_p_sample(dev(I["x"]), dev(I["code_emb"]), 49, 1234, [2], return_x0=True)
