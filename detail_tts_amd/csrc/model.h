@@ -4,6 +4,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <atomic>
 #include <thread>
 #include <cstring>
 #include <memory>
@@ -407,8 +408,9 @@ private:
         std::vector<hipStream_t> users[SEGS];   // streams whose launches read tables of this segment (current lap)
         hipEvent_t ev = nullptr;
         unsigned long long last_use = 0;
+        std::shared_ptr<std::atomic<int>> owner_alive;      // 1 while the owning host thread lives (its thread_local guard clears it)
     };
-    static constexpr size_t MAX_INT_RINGS = 16;      // rings of host threads that are gone are recycled, not leaked
+    static constexpr size_t MAX_INT_RINGS = 16;      // rings of host threads that are GONE are recycled, not leaked
     unsigned long long ring_clock_ = 0;
     std::map<std::thread::id, std::unique_ptr<IntRing>> int_rings_;
     std::mutex ints_mu_;        // guards the map only; a ring is touched by its own thread

@@ -76,15 +76,28 @@ Model::~Model() {
         if (e) (void)hipEventDestroy(e);
 }
 
+namespace {
+// every ring a host thread owns (on any handle) is marked free when the thread exits
+struct RingOwnerGuard {
+    std::vector<std::shared_ptr<std::atomic<int>>> flags;
+    ~RingOwnerGuard() {
+        for (auto& f : flags) f->store(0);
+    }
+};
+thread_local RingOwnerGuard t_ring_guard;
+}  // namespace
+
 Model::IntRing& Model::int_ring() {
     std::lock_guard<std::mutex> lk(ints_mu_);
     const auto me = std::this_thread::get_id();
     auto it = int_rings_.find(me);
     if (it == int_rings_.end() && int_rings_.size() >= MAX_INT_RINGS) {
-        // hand the least recently used ring (most likely a finished thread's) to this thread: retire every segment of it first
-        auto lru = int_rings_.begin();
+        // hand on the least recently used ring of a thread that has EXITED (a live owner may be inside upload_ints holding a reference:
+        // rings are not locked - ADVICE r04), after retiring every segment of it; no such ring = more live threads than the contract allows
+        auto lru = int_rings_.end();
         for (auto j = int_rings_.begin(); j != int_rings_.end(); ++j)
-            if (j->second->last_use < lru->second->last_use) lru = j;
+            if (j->second->owner_alive->load() == 0 && (lru == int_rings_.end() || j->second->last_use < lru->second->last_use)) lru = j;
+        DTTS_REQUIRE(lru != int_rings_.end(), "more than 16 live host threads use this handle (include/detail_hip.h \"Threads\": two at a time)");
         std::unique_ptr<IntRing> r = std::move(lru->second);
         int_rings_.erase(lru);
         for (auto& us : r->users) {
@@ -96,17 +109,21 @@ Model::IntRing& Model::int_ring() {
         }
         r->off = 0;
         r->seg = 0;
+        r->owner_alive.reset();
         int_rings_[me] = std::move(r);
     }
     auto& slot = int_rings_[me];
-    if (slot) slot->last_use = ++ring_clock_;
     if (!slot) {
         slot.reset(new IntRing());
-        slot->last_use = ++ring_clock_;
         DTTS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&slot->dev), INT_RING_BYTES));
         DTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot->pinned), INT_RING_BYTES, hipHostMallocDefault));
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
     }
+    if (!slot->owner_alive || slot->owner_alive->load() == 0) {        // new ring, recycled ring, or a new thread that got an exited thread's id
+        slot->owner_alive = std::make_shared<std::atomic<int>>(1);
+        t_ring_guard.flags.push_back(slot->owner_alive);
+    }
+    slot->last_use = ++ring_clock_;
     return *slot;
 }
 
