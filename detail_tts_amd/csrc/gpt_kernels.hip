@@ -729,8 +729,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     const int top_k = ctl->top_k;
     const float top_p = ctl->top_p;
     int token;
-    if (ctl->forced_tokens) {
-        token = ctl->forced_tokens[(long long)b * ctl->f_stride + step];
+    // forced token of this (row, step), or -1: sample.  A row may be forced for a prefix only (UnifiedVoice.inference_speech_tortoise's
+    // input_tokens, gpt/model.py:533-537) - the choice is uniform over the workgroup (one row per workgroup)
+    const int forced = ctl->forced_tokens ? ctl->forced_tokens[(long long)b * ctl->f_stride + step] : -1;
+    if (forced >= 0) {
+        token = forced;
     } else {
         // 1. logits = head GEMV partials + bias (its finish), repetition penalty over every id in the row's input_ids, temperature
         const unsigned char* seen = p.seen + (long long)b * V;

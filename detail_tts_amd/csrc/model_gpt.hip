@@ -241,7 +241,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     }
     if (o.forced_codes)
         for (size_t i = 0; i < (size_t)B * G; ++i)
-            DTTS_REQUIRE(o.forced_codes[i] >= 0 && o.forced_codes[i] < V, "forced code outside the mel_embedding table");
+            DTTS_REQUIRE(o.forced_codes[i] >= -1 && o.forced_codes[i] < V, "forced code outside the mel_embedding table (-1 = sample at this step)");
     // ---- session storage.  The KV capacity is rounded up so that sessions of similar lengths share one arena layout (and graph).
     const int cap = round_up(Lp + G, 128);
     const long long kv_bs = (long long)2 * C * cap, kv_layer = kv_bs * B;

@@ -32,21 +32,47 @@ class UnifiedVoice:
                                   num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
                                   text_lengths=None, seed=0, sample_ids=None, suppress_eos=False, forced_uniforms=None,
                                   **hf_generate_kwargs):
-        """gpt/model.py:514-545.  hf_generate_kwargs understood: do_sample(True), top_p, top_k, temperature,
-        repetition_penalty, length_penalty (inert without beams).  Returns LongTensor [B, <=max] incl. the stop token."""
-        if input_tokens is not None or num_return_sequences != 1 or typical_sampling:
-            raise NotImplementedError("input_tokens / num_return_sequences>1 / typical sampling are not on the infer path")
-        if not hf_generate_kwargs.get("do_sample", True):
-            raise NotImplementedError("greedy decoding is not on the infer path")
+        """gpt/model.py:514-545.  hf_generate_kwargs understood: do_sample, top_p, top_k, temperature, repetition_penalty, length_penalty
+        (inert without beams).  Returns LongTensor [B * num_return_sequences, <=max] incl. the stop token (and input_tokens in front).
+
+        Off the `infer` path but part of the reference's surface: `do_sample=False` (HF greedy search: only the repetition penalty is a
+        logits processor there, argmax), `num_return_sequences = n` (HF repeats every row n times - repeat_interleave - and samples the
+        copies independently: `sample_ids` of length B * n name their noise streams, or of length B: copy r of row b draws from
+        sample_ids[b] + r), `input_tokens [B, k]` (mel tokens in front of the generated ones; with num_return_sequences == 1: the
+        reference tiles them AND lets HF expand the batch again, i.e. n * n rows per prompt - not reproduced).  `typical_sampling`
+        (TypicalLogitsWarper) is not built."""
+        if typical_sampling:
+            raise NotImplementedError("typical sampling (TypicalLogitsWarper) is not built: SynthesizerTrn.infer never asks for it")
+        nrs = int(num_return_sequences)
+        if nrs < 1 or (input_tokens is not None and nrs != 1):
+            raise NotImplementedError("input_tokens together with num_return_sequences > 1 (the reference multiplies the rows twice)")
+        do_sample = bool(hf_generate_kwargs.get("do_sample", True))
         refer = speech_conditioning_latent.float().contiguous()
         B = refer.shape[0]
         cl = None if cond_lengths is None else torch.as_tensor(cond_lengths).reshape(-1).tolist()
+        texts = self._texts(text_inputs, text_lengths)
+        ids = list(range(B * nrs)) if sample_ids is None else list(sample_ids)
+        if nrs > 1:
+            refer = refer.repeat_interleave(nrs, 0).contiguous()
+            cl = None if cl is None else [v for v in cl for _ in range(nrs)]
+            texts = [t for t in texts for _ in range(nrs)]
+            if len(ids) == B:
+                ids = [i + r for i in ids for r in range(nrs)]
+        assert len(ids) == B * nrs, "sample_ids: one per returned sequence (or one per prompt)"
         G = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
+        forced = None
+        if input_tokens is not None:
+            it = torch.as_tensor(input_tokens).cpu().numpy().astype(np.int32)
+            assert it.ndim == 2 and it.shape[0] == B and it.shape[1] <= G
+            forced = [row for row in it]
+        if do_sample:
+            samp = dict(top_k=hf_generate_kwargs.get("top_k", 50), top_p=hf_generate_kwargs.get("top_p", 1.0),
+                        temperature=hf_generate_kwargs.get("temperature", 1.0))
+        else:       # greedy search = the one largest logit after the repetition penalty: top-k 1 keeps exactly it (any draw picks it)
+            samp = dict(top_k=1, top_p=1.0, temperature=1.0)
         codes, ncodes, lat = self.rt.gpt_generate(
-            refer, cl, self._texts(text_inputs, text_lengths), seed, list(range(B)) if sample_ids is None else sample_ids,
-            max_generate_length=G, top_k=hf_generate_kwargs.get("top_k", 50), top_p=hf_generate_kwargs.get("top_p", 1.0),
-            temperature=hf_generate_kwargs.get("temperature", 1.0), repetition_penalty=hf_generate_kwargs.get("repetition_penalty", 1.0),
-            suppress_eos=suppress_eos, forced_uniforms=forced_uniforms)
+            refer, cl, texts, seed, ids, max_generate_length=G, repetition_penalty=hf_generate_kwargs.get("repetition_penalty", 1.0),
+            suppress_eos=suppress_eos, forced_uniforms=forced_uniforms, forced_codes=forced, forced_fill=-1, **samp)
         self.last_latents, self.last_ncodes = lat, ncodes
         n = int(ncodes.max())
         return torch.from_numpy(codes[:, :n].astype(np.int64)).to(refer.device)

@@ -101,7 +101,8 @@ typedef struct dtts_gpt_options {
     float top_p, temperature, repetition_penalty;
     int suppress_eos;               /* != 0: the stop token can never be drawn (benchmarks with random weights) */
     const float* forced_uniforms;   /* DEVICE [B][max_generate_length] uniforms replacing the Philox draw (tests), or NULL */
-    const int* forced_codes;        /* HOST [B][max_generate_length] teacher-forced tokens (no sampling), or NULL */
+    const int* forced_codes;        /* HOST [B][max_generate_length] teacher-forced tokens (no sampling there; -1 = sample at this step:
+                                     * a forced prefix = inference_speech_tortoise's input_tokens, gpt/model.py:533-537), or NULL */
     const unsigned long long* row_seeds;   /* HOST [B] per-row Philox seed (rows of different requests in one session), or NULL: `seed` */
 } dtts_gpt_options;
 

@@ -182,9 +182,12 @@ def draw_token(filtered, u):
 
 def generate(P, refer, refer_lengths, text, seed, sample_ids, max_generate_length=600, top_k=50,
              top_p=0.8, temperature=0.8, repetition_penalty=2.0, use_cache=True, forced_uniforms=None,
-             suppress_eos=False, return_latents=False):
+             suppress_eos=False, return_latents=False, input_tokens=None, do_sample=True):
     """UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF _sample.
-    Returns codes [B, <=max] including the stop token (finished rows padded with 8193)."""
+    Returns codes [B, <=max] including the stop token (finished rows padded with 8193).
+    input_tokens [B, k] (gpt/model.py:533-537): mel tokens in front of the generated ones - they are part of the returned codes and of the
+    repetition penalty's history, positions 1 .. k; the draw at mel position p uses noise counter p.  do_sample=False: HF greedy search -
+    only the repetition penalty is a logits PROCESSOR, temperature / top-k / top-p are sampling warpers and are not applied; argmax."""
     B = refer.shape[0]
     prefix = prefix_embeddings(P, refer, refer_lengths, text)
     Pn = prefix.shape[1]
@@ -209,10 +212,15 @@ def generate(P, refer, refer_lengths, text, seed, sample_ids, max_generate_lengt
             if suppress_eos:
                 sc[STOP_MEL] = -np.inf
             seen = [1, START_MEL] + mel_ids[b, 1:].tolist()     # fake prefix ids (gpt/model.py:528-530)
-            f = process_logits(sc, seen, repetition_penalty, temperature, top_k, top_p)
-            u = forced_uniforms[b][step] if forced_uniforms is not None else \
-                philox.uniform_scalar(seed, sample_ids[b], philox.STAGE_GPT_SAMPLE, step)
-            tok = draw_token(f, u)
+            if input_tokens is not None and step < np.asarray(input_tokens).shape[1]:
+                tok = int(np.asarray(input_tokens)[b, step])
+            elif not do_sample:
+                tok = int(np.argmax(process_logits(sc, seen, repetition_penalty, 1.0, None, 1.0)))
+            else:
+                f = process_logits(sc, seen, repetition_penalty, temperature, top_k, top_p)
+                u = forced_uniforms[b][step] if forced_uniforms is not None else \
+                    philox.uniform_scalar(seed, sample_ids[b], philox.STAGE_GPT_SAMPLE, step)
+                tok = draw_token(f, u)
             nxt[b] = STOP_MEL if finished[b] else tok
         mel_ids = np.concatenate([mel_ids, nxt[:, None]], 1)
         finished |= nxt == STOP_MEL

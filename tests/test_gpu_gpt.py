@@ -58,6 +58,31 @@ def test_generate_matches_reference_hf_loop(rt, golden):
     assert np.array_equal(codes[0], g["codes"][0]), (codes[0], g["codes"][0])
 
 
+def test_off_path_branches_of_inference_speech_tortoise_vs_reference(rt, golden):
+    """UnifiedVoice.inference_speech_tortoise beyond what SynthesizerTrn.infer asks of it (gpt/model.py:533-544; VERDICT r04 "missing" 3):
+    greedy search (do_sample=False), num_return_sequences = 2 and input_tokens, each against the codes the REFERENCE's own HF generate()
+    produced (tests/golden/make_golden_r5.py); typical sampling and the reference's n x n row multiplication stay refused."""
+    from detail_tts_amd.config import load_config
+    from detail_tts_amd.gpt.model import UnifiedVoice
+    g = golden("gpt_generate_branches")
+    uv = UnifiedVoice(rt, load_config()["gpt"])
+    refer = torch.from_numpy(g["refer"]).cuda()      # g["text"] ends with api.py's pad 0; the stop tokens are the decode session's
+    sid, seed = int(g["sample_id"]), int(g["seed"])
+    kw = dict(top_p=0.8, temperature=0.8, length_penalty=1.0, repetition_penalty=2.0, max_generate_length=10, seed=seed)
+    out = uv.inference_speech_tortoise(refer, None, g["text"], do_sample=False, num_return_sequences=1, length_penalty=1.0,
+                                       repetition_penalty=2.0, max_generate_length=10, seed=seed, sample_ids=[sid])
+    assert np.array_equal(out.cpu().numpy(), g["greedy"]), (out, g["greedy"])
+    out = uv.inference_speech_tortoise(refer, None, g["text"], do_sample=True, num_return_sequences=2, sample_ids=[sid], **kw)
+    assert np.array_equal(out.cpu().numpy(), g["nrs2"]), (out, g["nrs2"])
+    out = uv.inference_speech_tortoise(refer, None, g["text"], input_tokens=g["input_tokens"], do_sample=True, num_return_sequences=1,
+                                       sample_ids=[sid], **kw)
+    assert np.array_equal(out.cpu().numpy(), g["input_tokens_codes"]), (out, g["input_tokens_codes"])
+    with pytest.raises(NotImplementedError):
+        uv.inference_speech_tortoise(refer, None, g["text"], typical_sampling=True, **kw)
+    with pytest.raises(NotImplementedError):
+        uv.inference_speech_tortoise(refer, None, g["text"], input_tokens=g["input_tokens"], num_return_sequences=2, **kw)
+
+
 @pytest.mark.parametrize("top_k", [50, 0])
 def test_generate_batch_varlen_vs_oracle(rt, weights, top_k):
     from oracle import gpt as G

@@ -80,6 +80,20 @@ def test_generate_loop(weights, golden):
         assert np.array_equal(codes, g["codes"]), (cache, codes, g["codes"])
 
 
+def test_generate_off_path_branches(weights, golden):
+    """inference_speech_tortoise's branches SynthesizerTrn.infer never takes (gpt/model.py:533-544): greedy search, num_return_sequences = 2
+    (HF repeat_interleave: row r of the expanded batch draws from noise stream sample_id + r), input_tokens - against the reference's own
+    HF generate (tests/golden/make_golden_r5.py)."""
+    g = golden("gpt_generate_branches")
+    Tr, sid, seed = g["refer"].shape[2], int(g["sample_id"]), int(g["seed"])
+    codes = G.generate(weights, g["refer"], [Tr], g["text"], seed, [sid], max_generate_length=10, do_sample=False)
+    assert np.array_equal(codes, g["greedy"]), (codes, g["greedy"])
+    codes = G.generate(weights, np.repeat(g["refer"], 2, 0), [Tr, Tr], np.repeat(g["text"], 2, 0), seed, [sid, sid + 1], max_generate_length=10, top_k=50)
+    assert np.array_equal(codes, g["nrs2"]), (codes, g["nrs2"])
+    codes = G.generate(weights, g["refer"], [Tr], g["text"], seed, [sid], max_generate_length=10, top_k=50, input_tokens=g["input_tokens"])
+    assert np.array_equal(codes, g["input_tokens_codes"]), (codes, g["input_tokens_codes"])
+
+
 def test_diffusion_conditioning(weights, golden):
     g = golden("diff_cond")
     cond = D.get_conditioning(weights, g["refer"])
