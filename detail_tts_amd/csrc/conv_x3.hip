@@ -281,9 +281,21 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
     const int S = p.ksplit, L = Ls / S, z = Ls - L * S;                  // the splits of a tile are adjacent logical ids (one XCD)
     // EPI 3 (fused GroupNorm): (sample, M tile, N tile) order - a tile waits for statistics of tiles at most 2 N - 1 ids ahead (conv_x3.h)
     const bool mt_major = EPI == 3 && !(p.ablate & 16);
-    const int mt = mt_major ? (L / ntiles) % mtiles : L % mtiles;
-    const int b = mt_major ? L / (ntiles * mtiles) : (L / mtiles) / ntiles;
-    const int nti = mt_major ? L % ntiles : (L / mtiles) - b * ntiles;
+    int mt = mt_major ? (L / ntiles) % mtiles : L % mtiles;
+    int b = mt_major ? L / (ntiles * mtiles) : (L / mtiles) / ntiles;
+    int nti = mt_major ? L % ntiles : (L / mtiles) - b * ntiles;
+    if (EPI == 2 && mtiles > 6 && mtiles % 6 == 0 && !(p.ablate & 1024)) {
+        // Tall launches (the qkv conv: 18 M tiles): with the M tiles of an X tile adjacent, the ~30 workgroups an XCD runs at a time
+        // stream ALL 18 weight tiles (7 MB through a 4 MB L2) for 1.7 X tiles - and again in the next round: 138 MB fetched per launch
+        // for 30 MB of operands.  Order the ids of a block of 5 (sample, N tile) columns as [M group of 6][column][M tile in the group]
+        // instead: a round of 30 = 6 weight tiles (2.4 MB, each shared by 5 workgroups) x 5 X tiles (2.9 MB, each shared by 6).
+        const int nbn = ntiles * p.B, per_blk = 5 * mtiles, blk = L / per_blk, r = L - blk * per_blk;
+        const int bn0 = blk * 5, nb = min(5, nbn - bn0), per_grp = nb * 6, mg = r / per_grp, r2 = r - mg * per_grp, bnl = r2 / 6;
+        mt = mg * 6 + (r2 - bnl * 6);
+        const int bn = bn0 + bnl;
+        b = bn / ntiles;
+        nti = bn - b * ntiles;
+    }
     const int m0 = mt * BM, n0 = nti * BN;
     const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
     if (n0 >= nvalid) return;
