@@ -18,6 +18,7 @@ struct GptCtl {
     unsigned long long seed[GEMV_MAXB];     // Philox seed of the row (rows of two requests may share a session)
     float repetition_penalty, temperature, top_p;
     int top_k;                    // <= 0: disabled
+    float typical_mass;           // TypicalLogitsWarper mass (HF: between the repetition penalty and the temperature); <= 0 or >= 1: off
     int suppress_eos;
     int max_steps;                // tokens to generate at most: steps >= max_steps are no-ops (a replayed graph may over-run)
     const float* forced_u;        // optional [B][u_stride] uniforms replacing the Philox draw (tests)

@@ -739,15 +739,78 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         const unsigned char* seen = p.seen + (long long)b * V;
         const float rp = ctl->repetition_penalty, temp = ctl->temperature;
         const int eos_off = ctl->suppress_eos ? p.eos : -1;
+        const bool typical = ctl->typical_mass > 0.f && ctl->typical_mass < 1.f;
 #pragma unroll 4
         for (int v = tid; v < V; v += SAMP_THREADS) {
             float x = p.bias ? p.bias[v] : 0.f;
             x += sum_parts(p.parts, p.slices, (long long)p.B * p.Vs, (long long)b * p.Vs + v);
             if (v == eos_off) x = -INFINITY;
             if (seen[v]) x = x < 0.f ? x * rp : x / rp;
-            sv[v] = x / temp;
+            sv[v] = typical ? x : x / temp;
         }
         __syncthreads();
+        // 1b. HF TypicalLogitsWarper (inference_speech_tortoise(typical_sampling=True), gpt/model.py:539; it sits between the repetition
+        // penalty and the temperature): key = | -log p - H |, ascending sort of the whole vocabulary by it, keep the keys up to the
+        // first whose cumulative probability reaches the mass.  Off the infer path: the full 16 K-slot bitonic sort is fine here.
+        if (typical) {
+            float m0 = -INFINITY;
+            for (int v = tid; v < V; v += SAMP_THREADS) m0 = fmaxf(m0, sv[v]);
+            m0 = block_reduce_max(m0, red);
+            float z0 = 0.f;
+            for (int v = tid; v < V; v += SAMP_THREADS) z0 += expf(sv[v] - m0);
+            z0 = block_reduce_sum(z0, red);
+            const float lse = m0 + logf(z0);
+            float ent = 0.f;
+            for (int v = tid; v < V; v += SAMP_THREADS) {
+                const float lp = sv[v] - lse;
+                if (lp > -INFINITY) ent -= expf(lp) * lp;                   // nansum: p = 0 terms drop out
+            }
+            ent = block_reduce_sum(ent, red);
+            int n2 = 64;
+            while (n2 < V) n2 <<= 1;
+            for (int i = tid; i < n2; i += SAMP_THREADS) {
+                skey[i] = i < V ? fabsf(-(sv[i] - lse) - ent) : INFINITY;
+                sidx[i] = i < V ? (unsigned short)i : 0xffff;
+            }
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2; i += SAMP_THREADS) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const bool asc = (i & k) == 0;
+                            const float a = skey[i], c = skey[ixj];
+                            const unsigned short ia = sidx[i], ic = sidx[ixj];
+                            const bool gt = (a > c) || (a == c && ia > ic);      // total order: key, then id
+                            if (gt == asc) { skey[i] = c; skey[ixj] = a; sidx[i] = ic; sidx[ixj] = ia; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            // cumulative probability in key order; last = number of positions whose inclusive sum stays below the mass
+            const int per = n2 / SAMP_THREADS > 0 ? n2 / SAMP_THREADS : 1, i0 = tid * per;
+            float loc = 0.f;
+            for (int i = i0; i < i0 + per && i < V; ++i) loc += expf(sv[sidx[i]] - lse);
+            float tot;
+            float run = block_exclusive_scan(loc, red, &tot);
+            int cnt = 0;
+            for (int i = i0; i < i0 + per && i < V; ++i) {
+                run += expf(sv[sidx[i]] - lse);
+                cnt += run < ctl->typical_mass ? 1 : 0;
+            }
+            if (tid == 0) sh_i[0] = 0;
+            __syncthreads();
+            if (cnt) atomicAdd(&sh_i[0], cnt);
+            __syncthreads();
+            const int last = sh_i[0] < V - 1 ? sh_i[0] : V - 1;
+            const float thr = skey[last];
+            __syncthreads();
+            for (int v = tid; v < V; v += SAMP_THREADS) {
+                const float key = fabsf(-(sv[v] - lse) - ent);
+                sv[v] = key > thr ? -INFINITY : sv[v] / temp;
+            }
+            __syncthreads();
+        }
         // 2. top-k: threshold = k-th largest value (radix select on order-preserving keys)
         if (top_k > 0 && top_k < V) {
             unsigned prefix = 0, mask = 0;

@@ -310,6 +310,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     c.repetition_penalty = o.repetition_penalty;
     c.temperature = o.temperature;
     c.top_p = o.top_p;
+    c.typical_mass = o.typical_mass;
     c.top_k = o.top_k;
     c.suppress_eos = o.suppress_eos;
     c.max_steps = G;

@@ -39,10 +39,8 @@ class UnifiedVoice:
         logits processor there, argmax), `num_return_sequences = n` (HF repeats every row n times - repeat_interleave - and samples the
         copies independently: `sample_ids` of length B * n name their noise streams, or of length B: copy r of row b draws from
         sample_ids[b] + r), `input_tokens [B, k]` (mel tokens in front of the generated ones; with num_return_sequences == 1: the
-        reference tiles them AND lets HF expand the batch again, i.e. n * n rows per prompt - not reproduced).  `typical_sampling`
-        (TypicalLogitsWarper) is not built."""
-        if typical_sampling:
-            raise NotImplementedError("typical sampling (TypicalLogitsWarper) is not built: SynthesizerTrn.infer never asks for it")
+        reference tiles them AND lets HF expand the batch again, i.e. n * n rows per prompt - not reproduced), `typical_sampling`
+        (HF TypicalLogitsWarper(mass=typical_mass), which HF applies between the repetition penalty and the temperature)."""
         nrs = int(num_return_sequences)
         if nrs < 1 or (input_tokens is not None and nrs != 1):
             raise NotImplementedError("input_tokens together with num_return_sequences > 1 (the reference multiplies the rows twice)")
@@ -72,7 +70,8 @@ class UnifiedVoice:
             samp = dict(top_k=1, top_p=1.0, temperature=1.0)
         codes, ncodes, lat = self.rt.gpt_generate(
             refer, cl, texts, seed, ids, max_generate_length=G, repetition_penalty=hf_generate_kwargs.get("repetition_penalty", 1.0),
-            suppress_eos=suppress_eos, forced_uniforms=forced_uniforms, forced_codes=forced, forced_fill=-1, **samp)
+            suppress_eos=suppress_eos, forced_uniforms=forced_uniforms, forced_codes=forced, forced_fill=-1,
+            typical_mass=float(typical_mass) if typical_sampling else 0.0, **samp)
         self.last_latents, self.last_ncodes = lat, ncodes
         n = int(ncodes.max())
         return torch.from_numpy(codes[:, :n].astype(np.int64)).to(refer.device)

@@ -104,6 +104,8 @@ typedef struct dtts_gpt_options {
     const int* forced_codes;        /* HOST [B][max_generate_length] teacher-forced tokens (no sampling there; -1 = sample at this step:
                                      * a forced prefix = inference_speech_tortoise's input_tokens, gpt/model.py:533-537), or NULL */
     const unsigned long long* row_seeds;   /* HOST [B] per-row Philox seed (rows of different requests in one session), or NULL: `seed` */
+    float typical_mass;             /* inference_speech_tortoise(typical_sampling=True, typical_mass): HF TypicalLogitsWarper, applied between
+                                     * the repetition penalty and the temperature (gpt/model.py:539); <= 0 or >= 1: off */
 } dtts_gpt_options;
 
 /* UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF GenerationMixin._sample, with a real KV cache

@@ -146,7 +146,7 @@ def latents_teacher_forced(P, refer, refer_lengths, text, codes):
 # ----------------------------------------------------------------------------
 # HF GenerationMixin._sample logits processing
 # ----------------------------------------------------------------------------
-def process_logits(scores, seen_ids, repetition_penalty=2.0, temperature=0.8, top_k=50, top_p=0.8):
+def process_logits(scores, seen_ids, repetition_penalty=2.0, temperature=0.8, top_k=50, top_p=0.8, typical_mass=None):
     """scores [V] fp32 for one row; seen_ids: iterable of ids in the row's input_ids.
     Returns filtered scores (with -inf) ready for softmax.
 
@@ -159,6 +159,17 @@ def process_logits(scores, seen_ids, repetition_penalty=2.0, temperature=0.8, to
     ids = np.unique(np.asarray(list(seen_ids), np.int64))
     g = s[ids]
     s[ids] = np.where(g < 0, g * F32(repetition_penalty), g / F32(repetition_penalty))
+    if typical_mass is not None and 0 < typical_mass < 1:
+        # HF TypicalLogitsWarper (inference_speech_tortoise(typical_sampling=True), gpt/model.py:539): a custom processor, which HF
+        # places between the repetition penalty and the sampling warpers (measured: tests/golden/make_golden_r5.py)
+        lp = (s - (s.max() + np.log(np.sum(np.exp(s - s.max()), dtype=F32)))).astype(F32)
+        pr = np.exp(lp)
+        ent = -np.nansum(np.where(pr > 0, pr * lp, 0.0), dtype=F32)
+        key = np.abs(-lp - ent).astype(F32)
+        order = np.lexsort((np.arange(s.size), key))                      # ascending by key, then id
+        cum = np.cumsum(pr[order], dtype=F32)
+        last = min(int(np.sum(cum < F32(typical_mass))), s.size - 1)
+        s = np.where(key > key[order][last], -np.inf, s).astype(F32)
     s = s / F32(temperature)
     if top_k:
         kth = np.sort(s)[-min(top_k, s.size)]
@@ -182,7 +193,7 @@ def draw_token(filtered, u):
 
 def generate(P, refer, refer_lengths, text, seed, sample_ids, max_generate_length=600, top_k=50,
              top_p=0.8, temperature=0.8, repetition_penalty=2.0, use_cache=True, forced_uniforms=None,
-             suppress_eos=False, return_latents=False, input_tokens=None, do_sample=True):
+             suppress_eos=False, return_latents=False, input_tokens=None, do_sample=True, typical_mass=None):
     """UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF _sample.
     Returns codes [B, <=max] including the stop token (finished rows padded with 8193).
     input_tokens [B, k] (gpt/model.py:533-537): mel tokens in front of the generated ones - they are part of the returned codes and of the
@@ -215,9 +226,9 @@ def generate(P, refer, refer_lengths, text, seed, sample_ids, max_generate_lengt
             if input_tokens is not None and step < np.asarray(input_tokens).shape[1]:
                 tok = int(np.asarray(input_tokens)[b, step])
             elif not do_sample:
-                tok = int(np.argmax(process_logits(sc, seen, repetition_penalty, 1.0, None, 1.0)))
+                tok = int(np.argmax(process_logits(sc, seen, repetition_penalty, 1.0, None, 1.0, typical_mass)))
             else:
-                f = process_logits(sc, seen, repetition_penalty, temperature, top_k, top_p)
+                f = process_logits(sc, seen, repetition_penalty, temperature, top_k, top_p, typical_mass)
                 u = forced_uniforms[b][step] if forced_uniforms is not None else \
                     philox.uniform_scalar(seed, sample_ids[b], philox.STAGE_GPT_SAMPLE, step)
                 tok = draw_token(f, u)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Round-5 fixtures FROM THE REFERENCE ITSELF (build container only, CPU): the off-path branches of
 UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) that SynthesizerTrn.infer never takes and the mirror used to refuse -
-greedy decoding (do_sample=False), num_return_sequences > 1 (HF expands the batch by repeat_interleave) and input_tokens (mel tokens
-in front of the generated ones).  Same small inputs as make_golden.py's `gpt_generate`, the sampler's multinomial patched to the Philox
+greedy decoding (do_sample=False), num_return_sequences > 1 (HF expands the batch by repeat_interleave), input_tokens (mel tokens
+in front of the generated ones) and typical sampling (TypicalLogitsWarper: HF runs it between the repetition penalty and the temperature).  Same small inputs as make_golden.py's `gpt_generate`, the sampler's multinomial patched to the Philox
 spec (row b of the expanded batch draws from stream sample_id + b).  Stores inputs and the reference's codes only.
 
     python tests/golden/make_golden_r5.py
@@ -40,6 +40,9 @@ def main():
         st["gpt_step"] = input_tokens.shape[1]          # the noise spec keys a draw by its mel position (oracle/philox.py): forced positions draw nothing
         out["input_tokens_codes"] = g.inference_speech_tortoise(refer_t, rl, text_t, input_tokens=torch.from_numpy(input_tokens), do_sample=True,
                                                                 num_return_sequences=1, **kw).numpy()
+    with philox_rng(sample_id=7):
+        out["typical"] = g.inference_speech_tortoise(refer_t, rl, text_t, do_sample=True, num_return_sequences=1, typical_sampling=True,
+                                                     typical_mass=0.9, **kw).numpy()
     for k, v in out.items():
         print(k, v.shape, v.tolist())
     save("gpt_generate_branches", refer=refer, text=text, sample_id=np.array(7), seed=np.array(SEED_N), input_tokens=input_tokens, **out)

@@ -82,7 +82,7 @@ def test_generate_loop(weights, golden):
 
 def test_generate_off_path_branches(weights, golden):
     """inference_speech_tortoise's branches SynthesizerTrn.infer never takes (gpt/model.py:533-544): greedy search, num_return_sequences = 2
-    (HF repeat_interleave: row r of the expanded batch draws from noise stream sample_id + r), input_tokens - against the reference's own
+    (HF repeat_interleave: row r of the expanded batch draws from noise stream sample_id + r), input_tokens, typical sampling - against the reference's own
     HF generate (tests/golden/make_golden_r5.py)."""
     g = golden("gpt_generate_branches")
     Tr, sid, seed = g["refer"].shape[2], int(g["sample_id"]), int(g["seed"])
@@ -92,6 +92,8 @@ def test_generate_off_path_branches(weights, golden):
     assert np.array_equal(codes, g["nrs2"]), (codes, g["nrs2"])
     codes = G.generate(weights, g["refer"], [Tr], g["text"], seed, [sid], max_generate_length=10, top_k=50, input_tokens=g["input_tokens"])
     assert np.array_equal(codes, g["input_tokens_codes"]), (codes, g["input_tokens_codes"])
+    codes = G.generate(weights, g["refer"], [Tr], g["text"], seed, [sid], max_generate_length=10, top_k=50, typical_mass=0.9)
+    assert np.array_equal(codes, g["typical"]), (codes, g["typical"])
 
 
 def test_diffusion_conditioning(weights, golden):
