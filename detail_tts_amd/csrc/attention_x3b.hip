@@ -296,7 +296,10 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     const int nqb = (p.T + QPB - 1) / QPB;
     const int Lid = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = Lid % nqb, hb = Lid / nqb;
-    const int h = hb % p.H, b = hb / p.H;
+    // ids in (head, sample, query block) order: an XCD's contiguous share of the grid is two heads of EVERY sample.  In (sample, head, ...)
+    // order an XCD held ONE sample's 16 heads, so a ragged batch took as long as its longest row (attention work ~ len^2) while the
+    // other XCDs idled; the K / V image of a (sample, head) is still shared by adjacent ids (its query blocks).
+    const int b = hb % p.B, h = hb / p.B;
     const int len = p.lens ? p.lens[b] : p.T;
     const int q0 = qb * QPB;
     if (q0 >= len) return;
