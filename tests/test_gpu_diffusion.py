@@ -112,6 +112,25 @@ def test_attention_block(rt, weights, T, lens):
         assert maxabs(y[b, :, :L], ref) < 1e-4, (T, b)
 
 
+def test_attention_block_with_growing_scores_rescales_mid_sequence(rt, weights):
+    """The trunk attention's lazy running maximum: with keys whose scores grow along the sequence a query raises its maximum (and the
+    kernel rescales its accumulators - an asm block behind MFMA results, csrc/attention_x3b.hip) at many blocks, not only at the first
+    one where the accumulators are still zero (the only rescale the small random fixtures ever take).  A ragged batch (band, far and
+    masked-tail blocks in one launch) against the dense oracle.  (Round 5's first, block-skewed build read MFMA results too early in
+    that asm and failed only the T = 936 forward; in the shipped three-block pipeline the rescale runs a whole step after the MFMAs it
+    follows - a build with its wait states removed passes this test and the forward - so the padding there is belt and braces.)"""
+    from oracle import diffusion as D
+    rs = np.random.RandomState(5)
+    T, lens = 700, [700, 413, 90]
+    ramp = (0.3 + 2.7 * np.arange(T) / T).astype(np.float32)            # later frames are ~9 x larger: q.k grows ~80 x along the keys
+    x = (rs.randn(3, 768, T) * ramp[None, None, :]).astype(np.float32)
+    p = "diffusion.layers.5.attn"
+    y = host(rt.op_attention_block(p, dev(x), lens))
+    for b, L in enumerate(lens):
+        ref = D.attention_block(weights, p, x[b:b + 1, :, :L], 16)[0]
+        assert maxabs(y[b, :, :L], ref) < 2e-4 * max(1.0, float(np.abs(ref).max())), (b, maxabs(y[b, :, :L], ref), float(np.abs(ref).max()))
+
+
 def test_attention_block_1536(rt, weights):
     from oracle import diffusion as D
     rs = np.random.RandomState(4)
