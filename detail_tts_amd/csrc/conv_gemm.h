@@ -74,6 +74,11 @@ struct ConvParams {
     void* gn_xch = nullptr;            // exchange words (conv_x3_gn_xch_bytes), one buffer per launch stream
     unsigned gn_tag = 0;               // != 0, unique per launch on this buffer
     int* gn_err = nullptr;             // raised (system scope) when a poll gives up
+    // conv_x3 only, ragged batches: the launch's LIVE (sample, N tile) columns as a table (packed sample << 8 | N tile, samples counted
+    // from cols_b0), so that the grid holds no workgroup that would exit at once: with per-sample column ranges in the id space and the
+    // XCD-contiguous id order, the XCDs holding short samples ran out of tiles early (Model::register_cols builds it; null: all columns)
+    const int* cols = nullptr;
+    int ncols = 0, cols_b0 = 0;
     int ksplit = 1;
     int epi_vec = 0;               // conv_x3: y / res rows are 16-byte aligned -> LDS-staged epilogue with 16-byte stores (set by the launcher)
     float* kpart = nullptr;

@@ -284,17 +284,23 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
     int mt = mt_major ? (L / ntiles) % mtiles : L % mtiles;
     int b = mt_major ? L / (ntiles * mtiles) : (L / mtiles) / ntiles;
     int nti = mt_major ? L % ntiles : (L / mtiles) - b * ntiles;
+    int bn = L / mtiles;                                                 // (sample, N tile) column of this tile: index into p.cols
     if (EPI == 2 && mtiles > 6 && mtiles % 6 == 0 && !(p.ablate & 1024)) {
         // Tall launches (the qkv conv: 18 M tiles): with the M tiles of an X tile adjacent, the ~30 workgroups an XCD runs at a time
         // stream ALL 18 weight tiles (7 MB through a 4 MB L2) for 1.7 X tiles - and again in the next round: 138 MB fetched per launch
         // for 30 MB of operands.  Order the ids of a block of 5 (sample, N tile) columns as [M group of 6][column][M tile in the group]
         // instead: a round of 30 = 6 weight tiles (2.4 MB, each shared by 5 workgroups) x 5 X tiles (2.9 MB, each shared by 6).
-        const int nbn = ntiles * p.B, per_blk = 5 * mtiles, blk = L / per_blk, r = L - blk * per_blk;
+        const int nbn = p.cols ? p.ncols : ntiles * p.B, per_blk = 5 * mtiles, blk = L / per_blk, r = L - blk * per_blk;
         const int bn0 = blk * 5, nb = min(5, nbn - bn0), per_grp = nb * 6, mg = r / per_grp, r2 = r - mg * per_grp, bnl = r2 / 6;
         mt = mg * 6 + (r2 - bnl * 6);
-        const int bn = bn0 + bnl;
+        bn = bn0 + bnl;
         b = bn / ntiles;
         nti = bn - b * ntiles;
+    }
+    if (p.cols) {                                                        // ragged batch: live columns only (never with EPI 3)
+        const int pk = __builtin_amdgcn_readfirstlane(p.cols[bn]);
+        b = (pk >> 8) - p.cols_b0;
+        nti = pk & 255;
     }
     const int m0 = mt * BM, n0 = nti * BN;
     const int nvalid = p.len_out ? p.len_out[b] : p.Nout;
@@ -1198,14 +1204,18 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     static const int force_stg = []() { const char* v = getenv("DTTS_CONV_STAGES"); const int n = v ? atoi(v) : 0; return n >= 2 && n <= 4 ? n : 0; }();
     static const long long max3 = []() { const char* v = getenv("DTTS_CONV_STAGES3_MAXWG"); return v ? atoll(v) : 600LL; }();
     static const long long max4 = []() { const char* v = getenv("DTTS_CONV_STAGES4_MAXWG"); return v ? atoll(v) : 128LL; }();
-    const long long ntile = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
+    if (gn) p.cols = nullptr;                                            // the fused GroupNorm's id order is per sample
+    DTTS_REQUIRE(!p.cols || (p.ncols > 0 && p.ncols <= cdiv(p.Nout, BN) * p.B && cdiv(p.Nout, BN) < 256), "conv_x3: column table");
+    const long long ntile = (long long)(p.CoutP / BM) * (p.cols ? p.ncols : cdiv(p.Nout, BN) * p.B);
     // split-K: launches of at most 128 tiles (half the CUs: batch 1) divide the channel blocks among up to 4 workgroups per tile
     static const int max_split = []() { const char* v = getenv("DTTS_CONV_KSPLIT"); const int n = v ? atoi(v) : 4; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
     int S = 1;
     // (k = 3: 144 K-steps per tile; the 48 steps of a 1x1 conv barely pay for the exchange: at most 2 there)
     const long long split_tiles = split_tiles_max();
     static const long long split_wgs = []() { const char* v = getenv("DTTS_CONV_KSPLIT_WGS"); return v ? atoll(v) : 256LL; }();
-    if (ntile <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile), (p.Cin >> 4) / 8);
+    // (decided on the PADDED tile count: a column table must not change the summation order of a launch)
+    const long long ntile_pad = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
+    if (ntile_pad <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile_pad), (p.Cin >> 4) / 8);
     if (S < 1) S = 1;
     p.ksplit = S;
     static const bool epi_vec_on = []() { const char* v = getenv("DTTS_X3_EPI_VEC"); return !(v && v[0] == '0'); }();

@@ -212,6 +212,7 @@ public:
         else if (key == "gpt_token_fault_eos") opt_tok_fault_eos_ = value;   // ... and leaves every row flagged finished (a spurious stop token)
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
+        else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -245,6 +246,10 @@ private:
     ConvParams cp(const float* x, int cin, float* y, int cout, int B, int T, int Ta, const int* lens) const;
 
     const int* upload_ints(const int* host, int n, hipStream_t s);
+    // Ragged batches: build, upload and remember (per host thread, keyed by the device address of the lengths) the table of live
+    // (sample, N tile) columns of a stack of `nb` samples; cp() attaches the sub-range of the samples a launch covers to every trunk
+    // conv whose `lens` points into that array (conv_gemm.h ConvParams::cols).  No table when every sample fills all its tiles.
+    void register_cols(const int* lens_dev, const int* lens_host, int nb, int T, hipStream_t s);
 
     // building blocks on [B, C, T] buffers (all lens are device pointers)
     void run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const;
@@ -354,6 +359,7 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
+    bool opt_conv_cols_ = true;      // ragged batches: trunk convs launch their live (sample, N tile) columns only (register_cols)
     bool opt_range_check_ = false;      // vocoder: detect activations beyond the split-precision planes' range (synchronises)
     // Range check of the generator's split-precision planes: a ring of host-mapped flags, one slot per vocoder / generator call
     // ("ticket"), raised by the kernels and read without synchronising by vocoder_check(ticket) once the CALLER has waited for that

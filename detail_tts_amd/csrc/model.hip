@@ -77,6 +77,20 @@ Model::~Model() {
 }
 
 namespace {
+// live-column tables of the lengths arrays this host thread uploaded (Model::register_cols); an entry dies when upload_ints hands
+// the address range of its lengths (or of the table itself) out again
+struct ColTable {
+    const int* lens = nullptr;      // device lengths [nb]
+    const int* cols = nullptr;      // device table [prefix[nb]]
+    int nb = 0, T = 0;
+    std::vector<int> prefix;        // columns before sample b
+};
+thread_local std::vector<ColTable> t_col_tables;
+static bool col_tables_on() {
+    static const bool on = []() { const char* v = getenv("DTTS_CONV_COLS"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
 // every ring a host thread owns (on any handle) is marked free when the thread exits
 struct RingOwnerGuard {
     std::vector<std::shared_ptr<std::atomic<int>>> flags;
@@ -156,11 +170,38 @@ const int* Model::upload_ints(const int* host, int n, hipStream_t s) {
     int* dst = r.dev + r.off;
     int* stage = r.pinned + r.off;
     r.off += len;
+    for (size_t i = t_col_tables.size(); i-- > 0;) {                  // tables whose lengths (or own storage) lived here are stale now
+        const ColTable& e = t_col_tables[i];
+        auto hit = [&](const int* q, int m) { return q < dst + len && dst < q + m; };
+        if (hit(e.lens, e.nb) || hit(e.cols, e.prefix.back())) t_col_tables.erase(t_col_tables.begin() + (long)i);
+    }
     if (n > 0) {
         std::memcpy(stage, host, sizeof(int) * (size_t)n);
         DTTS_CHECK_HIP(hipMemcpyAsync(dst, stage, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
     }
     return dst;
+}
+
+void Model::register_cols(const int* lens_dev, const int* lens_host, int nb, int T, hipStream_t s) {
+    for (size_t i = t_col_tables.size(); i-- > 0;)                      // a new table for these lengths replaces the old one; nb = 0 only forgets it
+        if (t_col_tables[i].lens == lens_dev) t_col_tables.erase(t_col_tables.begin() + (long)i);
+    if (!col_tables_on() || !opt_conv_cols_ || !lens_dev || !lens_host || nb <= 0 || cdiv(T, X3_BN) >= 256) return;
+    const int nt = cdiv(T, X3_BN);
+    ColTable e;
+    e.prefix.assign(1, 0);
+    std::vector<int> tab;
+    for (int b = 0; b < nb; ++b) {
+        const int live = std::min(nt, cdiv(std::max(lens_host[b], 0), X3_BN));
+        for (int i = 0; i < live; ++i) tab.push_back(b << 8 | i);
+        e.prefix.push_back((int)tab.size());
+    }
+    if ((int)tab.size() == nt * nb || tab.empty()) return;            // every column is live (or none: the launches exit at once anyway)
+    e.cols = upload_ints(tab.data(), (int)tab.size(), s);            // (may retire older entries; never this one: not yet listed)
+    e.lens = lens_dev;
+    e.nb = nb;
+    e.T = T;
+    if (t_col_tables.size() >= 32) t_col_tables.erase(t_col_tables.begin());
+    t_col_tables.push_back(std::move(e));
 }
 
 const float* Model::Wopt(const std::string& name, size_t numel) const {
@@ -252,6 +293,21 @@ ConvParams Model::cp(const float* x, int cin, float* y, int cout, int B, int T, 
     return p;
 }
 
+// ragged batch: the live columns of the samples [b0, b0 + B) a split-precision trunk conv covers (register_cols)
+static void attach_cols(ConvParams& p) {
+    if (t_col_tables.empty() || !p.len_out || p.len_out != p.len_in || p.Nout != p.Tin || p.stride != 1 || p.phases != 1) return;
+    for (const ColTable& e : t_col_tables)
+        if (p.len_out >= e.lens && p.len_out + p.B <= e.lens + e.nb && p.Nout == e.T) {
+            const int b0 = (int)(p.len_out - e.lens), c0 = e.prefix[b0], c1 = e.prefix[b0 + p.B];
+            if (c1 > c0 && c1 - c0 < p.B * cdiv(p.Nout, X3_BN)) {
+                p.cols = e.cols + c0;
+                p.ncols = c1 - c0;
+                p.cols_b0 = b0;
+            }
+            return;
+        }
+}
+
 void Model::run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const {
     p.w = pc.w;
     if (!p.bias) p.bias = pc.b;
@@ -263,6 +319,7 @@ void Model::run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const {
     if (p.x3) {
         DTTS_REQUIRE(pc.w3, "conv has no split-precision weights");
         p.w3 = pc.w3;
+        attach_cols(p);
         launch_conv_x3(p, s);
         return;
     }
@@ -679,6 +736,8 @@ Model::PairPlan Model::plan_pair(const int* lens_host, int B, int T, hipStream_t
     pl.lens2 = upload_ints(l2.data(), 2 * B, s);
     pl.lens_i = upload_ints(li.data(), (int)li.size(), s);
     pl.umap = upload_ints(um.data(), 2 * B, s);
+    register_cols(pl.lens2, l2.data(), 2 * B, T, s);
+    register_cols(pl.lens_i, li.data(), (int)li.size(), T, s);
     return pl;
 }
 
@@ -910,6 +969,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
             }
         const int* dl = upload_ints(lv.data(), nb, L.st);
         const int* ds = upload_ints(sv.data(), nb, L.st);
+        register_cols(dl, lv.data(), nb, T, L.st);
         float* outp = integ_all + (size_t)k0 * Bi * ct;
         auto dlayer = [&](const DiffLayerW& l, const float* in, float* o) {
             res_block_fwd(l.rb, in, L.bufB, L.bufC, L.ab, dl, nb, T, T, 0, L.st, L.xs, ds);
@@ -918,6 +978,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         dlayer(integ_[0], vin, L.bufA);
         dlayer(integ_[1], L.bufA, L.bufA);
         dlayer(integ_[2], L.bufA, outp);
+        register_cols(dl, nullptr, 0, T, L.st);                        // enqueued: forget this chunk's table
     }
     if (two) {
         DTTS_CHECK_HIP(hipEventRecord(ev_joinx_[0], sx_[0]));

@@ -265,6 +265,10 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 "fused GroupNorm"; since round 5 also on the split-K launches of batches 1 - 2).  Same values up to the summation
  *                 order of the statistics.  Measured neutral alone and 1.6 % slower under the three-stream pipeline at the headline
  *                 batch, 5 % slower at batch 1, hence off; env DTTS_GN_FUSE;
+ *   "conv_cols" (default 1): ragged batches - the split-precision trunk convs launch one workgroup per LIVE (sample, N tile) column
+ *                 (a table built from the host lengths of the call) instead of a grid over the padded length whose surplus workgroups
+ *                 exit at once: the ids are dealt to the 8 XCDs in contiguous ranges, so the XCDs holding short samples used to run
+ *                 dry early.  Same tiles, same arithmetic: bit-identical output; env DTTS_CONV_COLS=0;
  *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
  *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
  *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.

@@ -226,6 +226,33 @@ def test_tiny_and_ragged_lengths(rt, weights):
         assert maxabs(out, ref) < 3e-4, T
 
 
+@pytest.mark.parametrize("lens", [[600, 192, 385, 40, 577, 384], [600, 100, 384], [192, 600]])
+def test_ragged_batch_launching_only_live_columns_is_bit_identical(rt, weights, lens):
+    """Option conv_cols (default on): the trunk convs of a ragged batch launch one workgroup per live (sample, N tile) column from a
+    table built of the host lengths, instead of a grid over the padded length.  Same tiles, same arithmetic: the sampler's output
+    (integrator precompute + 2 CFG steps, both chunkings of the cond | uncond stack) must not change by one bit - and short
+    samples that end exactly on a tile boundary (192, 384), inside the first tile (40) and one column past a boundary (385, 577)
+    must keep every live column."""
+    rs = np.random.RandomState(31)
+    B, T = len(lens), max(lens)
+    ce = dev(rs.randn(B, 768, T) * 0.5)
+    outs = {}
+    try:
+        for flag in (0, 1):
+            rt.set_option("conv_cols", flag)
+            outs[flag] = host(rt.diff_sample(ce, 5, list(range(B)), lens=lens, n_steps=2, denorm=True))
+    finally:
+        rt.set_option("conv_cols", 1)
+    for b, L in enumerate(lens):
+        assert np.isfinite(outs[1][b, :, :L]).all()
+        assert float(np.abs(outs[1][b, :, :L]).max()) > 0.1
+        assert np.array_equal(outs[0][b, :, :L], outs[1][b, :, :L]), b
+    # and against each sample alone (no table: a single sample has no dead column)
+    b = int(np.argmin(lens))
+    alone = host(rt.diff_sample(ce[b:b + 1, :, :lens[b]].contiguous(), 5, [b], n_steps=2, denorm=True))
+    assert maxabs(outs[1][b, :, :lens[b]], alone[0]) < 1e-4
+
+
 def test_errors_are_reported_not_crashes(rt):
     from detail_tts_amd.runtime import DttsError
     x = torch.zeros(1, 128, 8, device="cuda")

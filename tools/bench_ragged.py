@@ -13,10 +13,12 @@ rtext = np.zeros((B, 61), np.int32)
 for b in range(B): rtext[b, : rtl[b] - 1] = rsr.randint(3, 255, rtl[b] - 1)
 rcodes = [rsr.randint(0, 8192, size=rn[b]) for b in range(B)]
 rreq = dict(text=torch.from_numpy(rtext), text_length=torch.tensor(rtl), refer=rrefer, refer_lengths=torch.tensor(rrl), sample_ids=list(range(B)), forced_codes=rcodes)
-list(model.infer_stream((dict(rreq, seed=4300 + i) for i in range(2)), max_generate_length=235))
-torch.cuda.synchronize(); t = time.perf_counter()
-n = 6
-out = list(model.infer_stream((dict(rreq, seed=4310 + i) for i in range(n)), max_generate_length=235))
-torch.cuda.synchronize(); ms = (time.perf_counter() - t) / n * 1e3
 import hashlib
-print(f"ragged batch: {ms:.1f} ms per step, {sum(rn) * 1024 / 24000.0 / (ms * 1e-3):.1f} audio-s/s, wav sha {hashlib.sha256(out[-1][0].cpu().numpy().tobytes()).hexdigest()[:12]}")
+for cols in (0, 1, 0, 1):
+    model.rt.set_option("conv_cols", cols)
+    list(model.infer_stream((dict(rreq, seed=4300 + i) for i in range(2)), max_generate_length=235))
+    torch.cuda.synchronize(); t = time.perf_counter()
+    n = 6
+    out = list(model.infer_stream((dict(rreq, seed=4310 + i) for i in range(n)), max_generate_length=235))
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t) / n * 1e3
+    print(f"ragged batch, conv_cols = {cols}: {ms:.1f} ms per step, {sum(rn) * 1024 / 24000.0 / (ms * 1e-3):.1f} audio-s/s, wav sha {hashlib.sha256(out[-1][0].cpu().numpy().tobytes()).hexdigest()[:12]}")
