@@ -259,8 +259,9 @@ void launch_flash_attention(const AttnParams& p, hipStream_t stream) {
     const char* tag = p.D == 48 ? "flash_attn_kernel<48>" : p.D == 64 ? "flash_attn_kernel<64>" : p.D == 96 ? "flash_attn_kernel<96>" : "flash_attn_kernel<192>";
     const double pairs = (double)p.B * p.H * (double)p.T * p.T * (p.causal ? 0.5 : 1.0);
     if (p.x3 && p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out) {
-        ProfScope ps3(p.planes ? "flash_attn_x3w_kernel" : "flash_attn_x3_kernel<48>", 4.0 * pairs * p.D, 4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
         static const bool old_kernel = []() { const char* v = getenv("DTTS_ATTN_KERNEL"); return v && v[0] == 'w'; }();
+        ProfScope ps3(p.planes ? (old_kernel ? "flash_attn_x3w_kernel" : "flash_attn_x3b_kernel") : "flash_attn_x3_kernel<48>", 4.0 * pairs * p.D,
+                      4.0 * (double)p.B * p.H * p.D * p.T * 4.0, stream);
         if (p.planes && old_kernel) launch_flash_attention_x3w(p, stream);
         else if (p.planes) launch_flash_attention_x3b(p, stream);
         else launch_flash_attention_x3(p, stream);

@@ -38,15 +38,28 @@ class UnifiedVoice:
         Off the `infer` path but part of the reference's surface: `do_sample=False` (HF greedy search: only the repetition penalty is a
         logits processor there, argmax), `num_return_sequences = n` (HF repeats every row n times - repeat_interleave - and samples the
         copies independently: `sample_ids` of length B * n name their noise streams, or of length B: copy r of row b draws from
-        sample_ids[b] + r), `input_tokens [B, k]` (mel tokens in front of the generated ones; with num_return_sequences == 1: the
-        reference tiles them AND lets HF expand the batch again, i.e. n * n rows per prompt - not reproduced), `typical_sampling`
+        sample_ids[b] + r), `input_tokens [rows, k]` (mel tokens in front of the generated ones; with num_return_sequences = n > 1 the
+        reference tiles them AND lets HF expand the batch again: n * n rows of the single prompt, reproduced), `typical_sampling`
         (HF TypicalLogitsWarper(mass=typical_mass), which HF applies between the repetition penalty and the temperature)."""
         nrs = int(num_return_sequences)
-        if nrs < 1 or (input_tokens is not None and nrs != 1):
-            raise NotImplementedError("input_tokens together with num_return_sequences > 1 (the reference multiplies the rows twice)")
+        assert nrs >= 1
         do_sample = bool(hf_generate_kwargs.get("do_sample", True))
         refer = speech_conditioning_latent.float().contiguous()
         B = refer.shape[0]
+        it = None
+        if input_tokens is not None:
+            it = torch.as_tensor(input_tokens).cpu().numpy().astype(np.int32)
+            assert it.ndim == 2
+            if nrs > 1:
+                # gpt/model.py:533-537: the reference tiles the prompt's fake inputs n times and the prefixes n // rows times (its torch.cat
+                # needs n * B == n rows: ONE prompt), then HF's generate expands every row n times again (repeat_interleave): n * n returned
+                # rows, row r starting with input_tokens[(r // n) % rows] and sampling from its own stream
+                assert nrs % it.shape[0] == 0, "The number of return sequences must be divisible by the number of input sequences"
+                if B != 1:
+                    raise ValueError("input_tokens with num_return_sequences > 1: the reference concatenates num_return_sequences * B rows of "
+                                     "inputs with num_return_sequences rows of prefixes - a single prompt only")
+                it = np.stack([it[(r // nrs) % it.shape[0]] for r in range(nrs * nrs)])
+                nrs = nrs * nrs
         cl = None if cond_lengths is None else torch.as_tensor(cond_lengths).reshape(-1).tolist()
         texts = self._texts(text_inputs, text_lengths)
         ids = list(range(B * nrs)) if sample_ids is None else list(sample_ids)
@@ -59,9 +72,8 @@ class UnifiedVoice:
         assert len(ids) == B * nrs, "sample_ids: one per returned sequence (or one per prompt)"
         G = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         forced = None
-        if input_tokens is not None:
-            it = torch.as_tensor(input_tokens).cpu().numpy().astype(np.int32)
-            assert it.ndim == 2 and it.shape[0] == B and it.shape[1] <= G
+        if it is not None:
+            assert it.shape[0] == B * nrs and it.shape[1] <= G
             forced = [row for row in it]
         if do_sample:
             samp = dict(top_k=hf_generate_kwargs.get("top_k", 50), top_p=hf_generate_kwargs.get("top_p", 1.0),

@@ -40,12 +40,19 @@ def main():
         st["gpt_step"] = input_tokens.shape[1]          # the noise spec keys a draw by its mel position (oracle/philox.py): forced positions draw nothing
         out["input_tokens_codes"] = g.inference_speech_tortoise(refer_t, rl, text_t, input_tokens=torch.from_numpy(input_tokens), do_sample=True,
                                                                 num_return_sequences=1, **kw).numpy()
+    # input_tokens AND num_return_sequences = n (single prompt only: the reference's torch.cat needs n * B == n): the reference tiles
+    # the prefixes to n rows and HF expands every row n times again -> n * n rows, row r starts with input_tokens[(r // n) % rows]
+    input_tokens2 = np.array([[5, 77, 4001], [900, 13, 2]], np.int64)
+    with philox_rng(sample_id=7) as st:
+        st["gpt_step"] = input_tokens2.shape[1]
+        out["input_tokens_nrs2_codes"] = g.inference_speech_tortoise(refer_t, rl, text_t, input_tokens=torch.from_numpy(input_tokens2), do_sample=True,
+                                                                     num_return_sequences=2, **kw).numpy()
     with philox_rng(sample_id=7):
         out["typical"] = g.inference_speech_tortoise(refer_t, rl, text_t, do_sample=True, num_return_sequences=1, typical_sampling=True,
                                                      typical_mass=0.9, **kw).numpy()
     for k, v in out.items():
         print(k, v.shape, v.tolist())
-    save("gpt_generate_branches", refer=refer, text=text, sample_id=np.array(7), seed=np.array(SEED_N), input_tokens=input_tokens, **out)
+    save("gpt_generate_branches", refer=refer, text=text, sample_id=np.array(7), seed=np.array(SEED_N), input_tokens=input_tokens, input_tokens2=input_tokens2, **out)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,13 @@ def test_generate_off_path_branches(weights, golden):
     assert np.array_equal(codes, g["input_tokens_codes"]), (codes, g["input_tokens_codes"])
     codes = G.generate(weights, g["refer"], [Tr], g["text"], seed, [sid], max_generate_length=10, top_k=50, typical_mass=0.9)
     assert np.array_equal(codes, g["typical"]), (codes, g["typical"])
+    # input_tokens [2, k] with num_return_sequences = 2: the reference tiles the prefixes to n rows and HF expands each n times -> n * n
+    # rows of the ONE prompt, row r starting with input_tokens[(r // n) % 2] and drawing from stream sample_id + r (gpt/model.py:533-537)
+    it2 = g["input_tokens2"]
+    rows = np.stack([it2[(r // 2) % 2] for r in range(4)])
+    codes = G.generate(weights, np.repeat(g["refer"], 4, 0), [Tr] * 4, np.repeat(g["text"], 4, 0), seed, [sid + r for r in range(4)],
+                       max_generate_length=10, top_k=50, input_tokens=rows)
+    assert np.array_equal(codes, g["input_tokens_nrs2_codes"]), (codes, g["input_tokens_nrs2_codes"])
 
 
 def test_diffusion_conditioning(weights, golden):
