@@ -80,6 +80,7 @@ struct ConvParams {
     const int* cols = nullptr;
     int ncols = 0, cols_b0 = 0;
     int ksplit = 1;
+    int ksplit_max = 0;            // conv_x3: caller's cap on the split (0: the launcher's rule)
     int epi_vec = 0;               // conv_x3: y / res rows are 16-byte aligned -> LDS-staged epilogue with 16-byte stores (set by the launcher)
     float* kpart = nullptr;
     int* kcount = nullptr;

@@ -27,12 +27,18 @@ void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* ou
 // x [B][C][T] fp32 (strides) -> x3; v = act(a*x + d) with (a, d) = ab[b][c][0..1] (ab may be null); zero outside [0, len[b])
 void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* ab, int act, const int* lens, int T, int B, int C,
                          void* out, hipStream_t s);
+// the KW-tap expansion of x as planes [B][KW * C/8][2][x3_tp(T)][8 fp16] (chunk (tap, c8), column t = x[c][t + tap - pad], zero outside
+// [0, len)): a k = KW conv with "same" padding becomes a 1x1 conv_x3 launch over KW * C input channels on the SAME w3 image - the route
+// the flow's WaveNet in_layers (k = 5, gated) take onto conv_x3's small-launch pipeline.  sat as launch_split_planes_ex.
+void launch_split_planes_taps(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int KW, int pad, void* out,
+                              hipStream_t s, int* sat = nullptr);
 // GroupNorm (statistics + affine, optional AdaGN (1 + scale, shift) from `ada`) + activation + split in one pass; arguments as
 // launch_gn_coeffs (ops.h)
 void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int groups,
                             const float* gamma, const float* beta, float eps, const float* ada, int ada_stride, int ada_bs, int act,
                             void* out, hipStream_t s, const int* ada_idx = nullptr);
-// uses p.w3 / p.x3 / p.x3_tp (+ the epilogue fields of ConvParams); stride 1, dilation 1, pad <= X3_HALO, no gate / phases / badd
+// uses p.w3 / p.x3 / p.x3_tp (+ the epilogue fields of ConvParams); stride 1, dilation 1, pad <= X3_HALO, no phases; gate (tanh * sigmoid on packed row pairs) + badd only
+// as a 1x1 conv without residual (EPI 4: the WaveNet in_layers over launch_split_planes_taps planes)
 void launch_conv_x3(const ConvParams& p, hipStream_t s);
 
 // ---- fused GroupNorm (p.gn_out3): the norm + activation + split that FOLLOWS a trunk conv runs in that conv's epilogue.  A tile holds

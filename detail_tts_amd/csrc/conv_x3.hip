@@ -889,6 +889,35 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if (EPI == 4) {
+                // gated output (WN in_layers, modules.py:15-22): packed rows (2 r, 2 r + 1) -> channel r = tanh(a + g_a) * sigmoid(b + g_b),
+                // g = the per-sample conditioning rows (badd).  The round's 16 rows are 8 pairs x 24 float4 columns: 3 per lane.
+                const float* bad = p.badd ? p.badd + (long long)b * p.badd_bs : nullptr;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int idx = lane + 64 * k, pr = idx / 24, c4 = idx - pr * 24, rt = rowt0 + 2 * pr, row = m0 + rt, n = ncol0 + c4 * 4;
+                    const float4 a4 = *reinterpret_cast<const float4*>(st + (2 * pr) * EP_LD + c4 * 4);
+                    const float4 b4 = *reinterpret_cast<const float4*>(st + (2 * pr + 1) * EP_LD + c4 * 4);
+                    if (row + 1 < p.Cout && n < nvalid) {
+                        float ba = bias_s[rt], bb = bias_s[rt + 1];
+                        if (bad) { ba += bad[row]; bb += bad[row + 1]; }
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, gv[4] = {b4.x, b4.y, b4.z, b4.w};
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float ta = av[e] * XS_ACC_SCALE + ba, tb = gv[e] * XS_ACC_SCALE + bb;
+                            o[e] = tanhf(ta) * sigmoidf_(tb);                       // (as conv_gemm's gate: the two paths differ by the products only)
+                        }
+                        float* dst = yb + (long long)(row >> 1) * p.y_cs + n;
+                        if (n + 3 < nvalid) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        else
+                            for (int e = 0; e < 4 && n + e < nvalid; ++e) dst[e] = o[e];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const int idx = lane + 64 * k, rl = idx / 24, c4 = idx - rl * 24, row = m0 + rowt0 + rl, n = ncol0 + c4 * 4;
@@ -914,6 +943,7 @@ __global__ __launch_bounds__(256, (NSTG == 2 && EPI != 3) ? 3 : 2) void conv_x3_
         }
         return;
     }
+    if (EPI == 4) return;                                                // (gated: the launcher requires the staged epilogue above)
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // bias of this lane's 32 output rows from the LDS copy made at kernel start: no global latency here, no registers held
     // across the K loop
@@ -1066,6 +1096,48 @@ void launch_split_weights(const float* wp, int KW, int CinP, int CoutP, void* ou
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
+// x [B][C][T] fp32 -> the planes of the KW-tap expansion [B][KW * C/8][2][Tp][8 fp16]: chunk (tap, c8) at column t holds
+// x[c][t + tap - pad] (zero outside [0, len)), so that a k = KW "same" conv over C channels is a 1x1 conv over KW * C channels whose
+// weights are the same w3 image (launch_split_weights orders [tap][Cin/8]).  Columns outside [0, len) are zero chunks.
+template <int KW>
+__global__ __launch_bounds__(256) void split_planes_taps_kernel(const float* __restrict__ x, long long x_bs, int x_cs, const int* __restrict__ lens,
+                                                               int T, int C8, int pad, int Tp, uint4* __restrict__ out, int* __restrict__ sat) {
+    const int tp = blockIdx.x * 256 + threadIdx.x, c8 = blockIdx.y, b = blockIdx.z;
+    if (tp >= Tp) return;
+    const int t = tp - X3_HALO, len = lens ? lens[b] : T;
+    const bool live = t >= 0 && t < len;
+    const float* xr = x + (long long)b * x_bs + (long long)(c8 * 8) * x_cs;
+    bool over = false;
+#pragma unroll
+    for (int tap = 0; tap < KW; ++tap) {
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+        const int ts = t + tap - pad;
+        if (live && ts >= 0 && ts < len) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = xr[(long long)e * x_cs + ts] * XS_SCALE_X;
+                over |= !(fabsf(v[e]) <= 65504.f);
+            }
+            split8(v, q0, q1);
+        }
+        uint4* o = out + ((long long)((b * KW + tap) * C8 + c8) * NPL) * Tp + tp;
+        o[0] = q0;
+        o[Tp] = q1;
+    }
+    if (sat && over) *sat = 1;
+}
+
+void launch_split_planes_taps(const float* x, long long x_bs, int x_cs, const int* lens, int T, int B, int C, int KW, int pad, void* out,
+                              hipStream_t s, int* sat) {
+    DTTS_REQUIRE(C % 16 == 0 && KW == 5 && pad >= 0 && pad < KW, "split_planes_taps: 5 taps, channels a multiple of 16");
+    const int Tp = x3_tp(T);
+    ProfScope ps("split_planes_taps_kernel", 0.0, (double)B * C * T * 4.0 * (1 + KW), s);
+    hipLaunchKernelGGL((split_planes_taps_kernel<5>), dim3(cdiv(Tp, 256), C / 8, B), dim3(256), 0, s, x, x_bs, x_cs, lens, T, C / 8, pad, Tp,
+                       static_cast<uint4*>(out), sat);
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
 void launch_split_planes(const float* x, long long x_bs, int x_cs, const float* ab, int act, const int* lens, int T, int B, int C,
                          void* out, hipStream_t s) {
     DTTS_REQUIRE(C % 16 == 0, "split_planes: channels must be a multiple of 16");
@@ -1194,7 +1266,10 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     }
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
     DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % BM == 0, "conv_x3: channel padding");
-    DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd, "conv_x3: unsupported conv form");
+    const bool gated = p.gate == GATE_TANH_SIGMOID;         // WN in_layers as a 1x1 conv over the tap-expanded planes (launch_split_planes_taps)
+    DTTS_REQUIRE(p.stride == 1 && p.dil == 1 && p.phases == 1 && (p.gate == GATE_NONE ? !p.badd : gated), "conv_x3: unsupported conv form");
+    DTTS_REQUIRE(!gated || (p.KW == 1 && !gn && !p.qkv_planes && !p.res && p.epi_act == ACT_NONE && p.out_scale == 1.f && p.Cout % 2 == 0),
+                 "conv_x3 gated epilogue: 1x1 conv, no residual / activation");
     DTTS_REQUIRE((p.KW == 1 && p.pad == 0) || (p.KW == 3 && p.pad == 1), "conv_x3: k = 1 or k = 3 (same padding) only");
     DTTS_REQUIRE(round_up(p.Nout, BN) + 2 * X3_HALO <= p.x3_tp, "conv_x3: time padding");
     // LDS stages by launch size.  Small launches expose each workgroup's own dependency chain DMA -> barrier -> fragment reads -> MFMA,
@@ -1215,7 +1290,9 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     static const long long split_wgs = []() { const char* v = getenv("DTTS_CONV_KSPLIT_WGS"); return v ? atoll(v) : 256LL; }();
     // (decided on the PADDED tile count: a column table must not change the summation order of a launch)
     const long long ntile_pad = (long long)(p.CoutP / BM) * cdiv(p.Nout, BN) * p.B;
-    if (ntile_pad <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, 2), split_wgs / ntile_pad), (p.Cin >> 4) / 8);
+    static const int max_split_k1 = []() { const char* v = getenv("DTTS_CONV_KSPLIT_K1"); return v ? atoi(v) : 2; }();
+    if (ntile_pad <= split_tiles) S = (int)std::min<long long>(std::min<long long>(p.KW == 3 ? max_split : std::min(max_split, max_split_k1), split_wgs / ntile_pad), (p.Cin >> 4) / 8);
+    if (p.ksplit_max > 0) S = std::min(S, p.ksplit_max);
     if (S < 1) S = 1;
     p.ksplit = S;
     static const bool epi_vec_on = []() { const char* v = getenv("DTTS_X3_EPI_VEC"); return !(v && v[0] == '0'); }();
@@ -1250,6 +1327,9 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
         if (gn) {
             if (p.KW == 3) DTTS_LAUNCH_X3(3, true);
             else DTTS_LAUNCH_X3(3, false);
+        } else if (gated) {
+            DTTS_REQUIRE(p.epi_vec, "conv_x3 gated epilogue: rows of y must be 16-byte aligned");
+            DTTS_LAUNCH_X3(4, false);
         } else if (p.qkv_planes) {
             DTTS_REQUIRE(p.KW == 1 && !epi && !p.res && p.Cout % 144 == 0 && p.qkv_heads * 144 == p.Cout, "qkv planes epilogue: 48-channel heads, 1x1 conv");
             DTTS_LAUNCH_X3(2, false);

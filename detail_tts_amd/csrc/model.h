@@ -373,6 +373,18 @@ private:
     void x3_sat_check(hipStream_t s);   // option x3_range_check: synchronise and report this call's saturation
 public:
     long long vocoder_ticket() const { return x3_ticket_; }
+    // one ticket per TOP-LEVEL stage-C call: vocoder() opens the scope before the flow (whose WaveNet planes can saturate too) and the
+    // generator calls inside it - one per window when streamed - report into the same slot
+    int x3_sat_depth_ = 0;
+    struct SatScope {
+        Model* m;
+        hipStream_t s;
+        SatScope(Model* m_, hipStream_t s_) : m(m_), s(s_) { if (m->x3_sat_depth_++ == 0) m->x3_sat_flag(s); }
+        ~SatScope() { --m->x3_sat_depth_; }
+        void check() { if (m->x3_sat_depth_ == 1) m->x3_sat_check(s); }
+        SatScope(const SatScope&) = delete;
+        SatScope& operator=(const SatScope&) = delete;
+    };
     void vocoder_check(long long ticket);    // throws Error(-5) when call `ticket` saturated; the caller has waited for that call
 private:
     int opt_cfg_streams_ = 0;             // chunks (= streams) the 2B-sample cond | uncond stack of a diffusion forward is cut into; 0 = by batch size

@@ -94,6 +94,10 @@ void Model::build_vocoder(hipStream_t stream) {
             for (int j = 0; j < cfg.n_resblock_kernels; ++j)
                 if (g.rb[j].k == 3 || g.rb[j].k == 7 || g.rb[j].k == 11)
                     for (int l = 0; l < 3; ++l) { wide.push_back(&g.rb[j].c1[l]); wide.push_back(&g.rb[j].c2[l]); }
+    // ... of the flow's WaveNet in_layers (k = 5, gated: a 1x1 conv_x3 launch over the tap-expanded planes, wn_fwd)
+    for (auto& c : flows_)
+        for (int l = 0; l < 4; ++l)
+            if (c.in[l].CinP % 16 == 0 && c.in[l].CoutP % 128 == 0 && c.in[l].CoutP == c.in[l].Cout) wide.push_back(&c.in[l]);
     // ... and, in A-fragment order, of the NARROW stages' (<= 32 channels: the LDS-resident fused kernel, resblock1_fused.hip)
     std::vector<PackedConv*> narrow;
     for (auto& g : gen_)
@@ -411,7 +415,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     float* T1 = ws().f32(buf);
     float* T2 = ws().f32(buf);
     float* gc = ws().f32((size_t)B * dec_cond_.CoutP);
-    x3_sat_flag(s);
+    SatScope sat(this, s);
     void* planes = nullptr;                            // fp16 operand planes of the wide stages' ResBlock1 convs
     if (size_t pb = generator_planes_bytes(cfg, B, T)) planes = ws().raw(pb);
     std::vector<int> l(B);
@@ -482,7 +486,7 @@ void Model::generator(const float* z, const float* g, const int* lens_host, int 
     o.epi_act = ACT_TANH;
     run_conv(dec_post_, o, s);
     ws().rewind(mark);
-    x3_sat_check(s);
+    sat.check();
 }
 
 static size_t generator_ws(const dtts_config& cfg, int B, int T) {
@@ -536,14 +540,37 @@ void Model::wn_fwd(const CouplingW& c, float* h, const float* g, int gin, float*
     run_conv(c.cond, q, s);
     float* hc = h;
     float* hn = h2;
+    // Split-precision in_layers (round 5): the k = 5 conv as a 1x1 conv_x3 launch (its 3 / 4-stage small-launch pipeline + split-K) over
+    // the 5-tap expansion of h - same w3 image, gate + conditioning rows in the epilogue.  fp32-MFMA form when the rows of the
+    // activations are not 16-byte aligned (T % 4) or with conv_x3 = 0 / DTTS_VOC_X3 = 0 / DTTS_VOC_WN_X3 = 0.
+    static const bool env_wn = []() { const char* v = getenv("DTTS_VOC_WN_X3"); return !(v && v[0] == '0'); }();
+    const bool x3 = env_wn && vocoder_x3() && c.in[0].w3 && c.in[0].KW == 5 && T % 4 == 0 && hid % 16 == 0;
+    const size_t mark = ws().mark();
+    void* xs5 = x3 ? ws().raw(x3_bytes(B, 5 * hid, T)) : nullptr;
     for (int li = 0; li < 4; ++li) {
         // acts = tanh(a + g_l) * sigmoid(b + g_l), (a|b) = in_layer(h)   (modules.py:15-22, 212-221)
         ConvParams p = cp(hc, acts);
-        p.pad = 2;
         p.gate = GATE_TANH_SIGMOID;
         p.badd = Gc + (size_t)li * 2 * hid;
         p.badd_bs = c.cond.CoutP;
-        run_conv(c.in[li], p, s);
+        if (x3) {
+            const PackedConv& pc = c.in[li];
+            launch_split_planes_taps(hc, (long long)hid * T, T, dl, T, B, hid, 5, 2, xs5, s, x3_sat_dev_);
+            p.bias = pc.b;
+            p.Cin = p.CinP = 5 * pc.CinP;
+            p.Cout = pc.Cout;
+            p.CoutP = pc.CoutP;
+            p.KW = 1;
+            p.pad = 0;
+            p.w3 = pc.w3;
+            p.x3 = xs5;
+            p.x3_tp = x3_tp(T);
+            p.ksplit_max = 1;          // 120 tiles x 60 K-steps: the split-K exchange costs this launch more than it saves (82 vs 47 us measured)
+            launch_conv_x3(p, s);
+        } else {
+            p.pad = 2;
+            run_conv(c.in[li], p, s);
+        }
         if (li < 3) {
             p = cp(acts, hn);                      // x = (x + res_acts) * mask
             p.res = hc;
@@ -560,6 +587,7 @@ void Model::wn_fwd(const CouplingW& c, float* h, const float* g, int gin, float*
         run_conv(c.skip[li], p, s);
         if (li < 3) std::swap(hc, hn);
     }
+    ws().rewind(mark);
 }
 
 // unit entry point: flow.flows[2 * flow].enc on h [B,192,T] with g [B,gin] -> out [B,192,T]
@@ -569,7 +597,7 @@ void Model::op_wn(int flow, const float* h_in, const float* g, const int* lens_h
     ArenaUse use_stage_c_arena(ws_voc_);
     const int hid = cfg.hidden_channels, gin = cfg.gin_channels;
     const size_t a = (size_t)B * hid * T;
-    ws().ensure(sizeof(float) * (3 * a + (size_t)B * flows_[flow].cond.CoutP) + 8192);
+    ws().ensure(sizeof(float) * (3 * a + (size_t)B * flows_[flow].cond.CoutP) + x3_bytes(B, 5 * cfg.hidden_channels, T) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -577,8 +605,10 @@ void Model::op_wn(int flow, const float* h_in, const float* g, const int* lens_h
     float* acts = ws().f32(a);
     float* h2 = ws().f32(a);
     float* Gc = ws().f32((size_t)B * flows_[flow].cond.CoutP);
+    SatScope sat(this, s);
     DTTS_CHECK_HIP(hipMemcpyAsync(h, h_in, sizeof(float) * a, hipMemcpyDeviceToDevice, s));
     wn_fwd(flows_[flow], h, g, gin, Gc, acts, h2, out, dl, B, T, s);
+    sat.check();
 }
 
 // in_proj + SpecEncoder / enc_p (vqvae/model_24k.py:856-857, :71-107; vqvae/modules/attentions.py:73-107 Encoder, :161-303 windowed
@@ -679,8 +709,10 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     const int inter = cfg.inter_channels, hid = cfg.hidden_channels, filt = cfg.filter_channels, gin = cfg.gin_channels;
     const int H = cfg.enc_heads, dk = hid / H;
     const size_t a192 = (size_t)B * hid * T;
-    const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256;
+    const size_t front = sizeof(float) * (8 * a192 + (size_t)B * filt * T + (size_t)B * H * T * 11 + (size_t)B * (gin + 2048)) + 64 * 256 +
+                         x3_bytes(B, 5 * hid, T) + 256;       // (+ the tap-expanded planes of the WaveNet in_layers: wn_fwd)
     ws().ensure(std::max(front + mel_style_ws(B, 128, gin, T), front + generator_ws(cfg, B, Tg) + sizeof(float) * (size_t)B * 256 * Tg) + 8192);
+    SatScope sat(this, s);                                 // this call's range-check ticket (flow + every generator window)
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -734,6 +766,7 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
     DTTS_CHECK_HIP(hipMemsetAsync(wav, 0, sizeof(float) * (size_t)B * 256 * T, s));
     if (gen_chunk <= 0 || gen_chunk >= T) {
         generator(zc, g, l.data(), B, T, wav, s);
+        sat.check();
         return;
     }
     float* tmp = ws().f32((size_t)B * 256 * Tg);
@@ -751,6 +784,7 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
         DTTS_CHECK_HIP(hipMemcpy2DAsync(wav + (size_t)t0 * 256, sizeof(float) * (size_t)256 * T, tmp + (size_t)(t0 - a) * 256,
                                         sizeof(float) * (size_t)256 * W, sizeof(float) * (size_t)(t1 - t0) * 256, B, hipMemcpyDeviceToDevice, s));
     }
+    sat.check();
 }
 
 // ------------------------------------------------------------------------------------------ VQ decode path

@@ -323,6 +323,51 @@ def test_range_check_is_on_by_default_and_fails_the_request_that_saturated(weigh
     rt2.vocoder_check(rt2.vocoder_ticket())
 
 
+def test_wavenet_in_layers_on_the_split_precision_kernel_vs_fp32_path_and_range_ticket(weights):
+    """Round 5: the flow's gated k = 5 WaveNet in_layers run as 1x1 conv_x3 launches over the 5-tap expansion of h
+    (same w3 image, tanh * sigmoid + the conditioning rows in the epilogue).  Against the exact fp32-MFMA form (conv_x3 = 0) on ragged
+    lengths that end inside / on / just past a 192-column tile, and: an activation beyond the fp16 planes' range raises THIS call's
+    range-check ticket (the flow runs before the generator inside one vocoder call: one ticket per top-level call)."""
+    from detail_tts_amd.runtime import DttsError, Runtime
+    rt2 = Runtime(weights, folded=True, parts=("vocoder",))
+    rs = np.random.RandomState(73)
+    T = 388
+    lens = [388, 192, 196, 40]
+    h = (rs.randn(4, 192, T) * 0.7).astype(np.float32)
+    g = (rs.randn(4, 768) * 0.3).astype(np.float32)
+    outs = {}
+    try:
+        for flag in (1, 0):
+            rt2.set_option("conv_x3", flag)
+            outs[flag] = host(rt2.op_wn(1, dev(h), dev(g), lens))
+    finally:
+        rt2.set_option("conv_x3", 1)
+    for b, L in enumerate(lens):
+        a, r = outs[1][b, :, :L], outs[0][b, :, :L]
+        assert float(np.abs(r).max()) > 0.05
+        assert maxabs(a, r) < 1e-5 * max(1.0, float(np.abs(r).max())), (b, maxabs(a, r))
+        assert np.all(outs[1][b, :, L:] == 0)
+    t_ok = rt2.vocoder_ticket()
+    bad = h.copy()
+    bad[2, 50, 100] = 5000.0
+    rt2.op_wn(1, dev(bad), dev(g), lens)
+    t_bad = rt2.vocoder_ticket()
+    assert t_bad == t_ok + 1
+    rt2.op_wn(1, dev(h), dev(g), lens)
+    torch.cuda.synchronize()
+    rt2.vocoder_check(t_ok)
+    rt2.vocoder_check(rt2.vocoder_ticket())
+    with pytest.raises(DttsError, match="conv_x3"):
+        rt2.vocoder_check(t_bad)
+    # a streamed vocoder call (several generator windows) is ONE ticket
+    mel = dev((rs.randn(1, 128, 96) * 2 - 5).astype(np.float32))
+    t0 = rt2.vocoder_ticket()
+    rt2.vocoder(mel, 3, [0], stream_chunk=32)
+    assert rt2.vocoder_ticket() == t0 + 1
+    rt2.vocoder(mel, 3, [0])
+    assert rt2.vocoder_ticket() == t0 + 2
+
+
 def test_calls_from_many_short_lived_host_threads(rt):
     """Every host thread that calls in gets its own pinned upload ring; rings of threads that are gone are recycled (at most 16 per
     handle) instead of accumulating.  24 threads, one after the other, each with lengths to upload: same result every time."""

@@ -5,7 +5,7 @@ REPS=${REPS:-2}
 for rep in $(seq 1 $REPS); do
   i=0
   for E in "$@"; do
-    env $E DTTS_BENCH_NO_EXTRA=1 python bench.py --steps ${STEPS:-10} --warmup ${WARMUP:-3} --no-cpu-baseline > gpurun_out/sweep_${i}_$rep.json 2> gpurun_out/sweep_${i}_$rep.err
+    env $E DTTS_BENCH_NO_EXTRA=1 python bench.py --steps ${STEPS:-10} --warmup ${WARMUP:-3} --no-cpu-baseline ${ARGS:-} > gpurun_out/sweep_${i}_$rep.json 2> gpurun_out/sweep_${i}_$rep.err
     python - "$i" "$rep" "$E" <<PY
 import json, sys
 c, r, e = sys.argv[1:]
