@@ -198,9 +198,9 @@ int dtts_vocoder(dtts_handle* h, const float* mel, const int* lens, int B, int T
 int dtts_vocoder_stream(dtts_handle* h, const float* mel, const int* lens, int B, int T, unsigned long long seed, const int* sample_ids,
                         float noise_scale, const float* noise_override, int chunk_frames, float* wav, void* stream);
 
-/* Range check of stage C's split-precision planes (the generator's ResBlock1 convs take UNNORMALISED activations: beyond |x| = 4094 the
- * fp16 planes saturate).  Every dtts_vocoder / dtts_vocoder_stream / dtts_generator call takes a ticket; its kernels raise a
- * host-mapped flag without synchronising.  dtts_vocoder_ticket: the ticket of the last such call issued on this handle.
+/* Range check of stage C's split-precision planes (the generator's ResBlock1 convs and the flow's WaveNet in_layers take UNNORMALISED
+ * activations: beyond |x| = 4094 the fp16 planes saturate).  Every dtts_vocoder / dtts_vocoder_stream / dtts_generator call takes ONE
+ * ticket (the flow and every generator window of a call report into it); its kernels raise a host-mapped flag without synchronising.  dtts_vocoder_ticket: the ticket of the last such call issued on this handle.
  * dtts_vocoder_check(ticket): call it once you have WAITED for that call (stream / event synchronised, as you must before reading the
  * waveform): returns -5 (dtts_last_error explains) when that call saturated - the request that produced wrong audio fails, not the
  * next one.  Tickets older than 8 calls are no longer known (0 = ok); a flag nobody checked is reported on stderr when its slot is
@@ -269,11 +269,11 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 (a table built from the host lengths of the call) instead of a grid over the padded length whose surplus workgroups
  *                 exit at once: the ids are dealt to the 8 XCDs in contiguous ranges, so the XCDs holding short samples used to run
  *                 dry early.  Same tiles, same arithmetic: bit-identical output; env DTTS_CONV_COLS=0;
- *   "x3_range_check" (default 0): 1 = the generator checks that the inputs of its split-precision ResBlock1 convs (unnormalised
- *                 activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of saturating
- *                 silently.  Reads a flag back at the end of the generator (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.
+ *   "x3_range_check" (default 0): 1 = a stage-C call checks that the inputs of its split-precision convs (ResBlock1, WaveNet in_layers:
+ *                 unnormalised activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of
+ *                 saturating silently.  Reads a flag back at the end of the call (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.
  *                 Without it the check is still on, through dtts_vocoder_ticket / dtts_vocoder_check (no synchronisation);
- *   "conv_x3"     (default 1): diffusion-trunk convs and attention, and the generator's wide ResBlock1 convs, on the split-precision path (every fp32 operand as two
+ *   "conv_x3"     (default 1): diffusion-trunk convs and attention, the generator's wide ResBlock1 convs and the flow's WaveNet in_layers on the split-precision path (every fp32 operand as two
  *                 scaled fp16 planes, three fp16 MFMA products per fp32 product, fp32 accumulate: fp32-GEMM-class error);
  *                 0 = the exact fp32-MFMA kernels. */
 int dtts_set_option(dtts_handle* h, const char* key, int value);
