@@ -31,6 +31,19 @@ void launch_conv_gemm(const ConvParams& p_in, hipStream_t stream) {
     const int halo = (p.KW - 1) * p.dil;
     auto fits = [&](int bn) { return (bn - 1) * p.stride + halo + 1 <= XW_MAX; };
     const bool bk32 = (p.CinP % 32 == 0) && force_bk == 32 && p.KW * p.dil <= 3;   // measured slower than BK=16: opt-in only
+    // Small launches (GPT prefill, conditioning encoders, the WaveNets' 1x1 convs: a few dozen 128 x 128 tiles on 256 CUs): a tile's K loop
+    // is a serial chain of 64-cycle fp32 MFMAs, so the launch takes one tile's time however empty the chip is - 64 x 64 tiles cut that
+    // chain to a quarter per K-step on four times the workgroups (same k order per output: identical sums).  DTTS_CONV_SMALL_TILES = n:
+    // launches of at most n 128 x 128 tiles take the small tile (0: never).
+    static const int small_tiles = []() { const char* v = getenv("DTTS_CONV_SMALL_TILES"); return v ? atoi(v) : 384; }();
+    if (small_tiles > 0 && p.CoutP % 64 == 0 && fits(64) && (long long)cdiv(p.CoutP, 128) * cdiv(p.Nout, 128) * p.B <= small_tiles) {
+        // ... and a small launch is bound by one memory latency per K-step (two-stage pipeline): 32-channel steps halve their number
+        static const int small_bk = []() { const char* v = getenv("DTTS_CONV_SMALL_BK"); return v ? atoi(v) : 32; }();
+        // (64-channel steps: 66 KiB of LDS, measured slower again - prefill 6.4 vs 5.5 ms)
+        if (small_bk == 32 && p.CinP % 32 == 0 && p.KW * p.dil <= 3) launch_conv_tile<64, 64, 2, 2, 32>(p, stream, "conv_gemm_kernel<64,64,k32>");
+        else launch_conv_tile<64, 64, 2, 2, 16>(p, stream, "conv_gemm_kernel<64,64,k16>");
+        return;
+    }
     if (p.CoutP % 128 == 0) {
         // BN=128 has the better MFMA:staging ratio; take it unless the ragged tail wastes more than ~10 % of the columns
         const int pad128 = round_up(p.Nout, 128), pad64 = round_up(p.Nout, 64);
