@@ -79,6 +79,12 @@ struct ConvParams {
     // XCD-contiguous id order, the XCDs holding short samples ran out of tiles early (Model::register_cols builds it; null: all columns)
     const int* cols = nullptr;
     int ncols = 0, cols_b0 = 0;
+    // conv_x3d only: act(y) of this conv written ALSO (or, y == null, only) as the split-precision planes the NEXT conv reads
+    // ([B][next_c8][2][next_tp][8 fp16], next_halo zero columns on the left, live columns only: the consumer's zero margins are the caller's)
+    void* next3 = nullptr;
+    int next_c8 = 0, next_tp = 0, next_halo = 0, next_act = ACT_NONE;
+    float next_slope = 0.f;
+    int* next_sat = nullptr;       // raised when a scaled value leaves fp16's range (as launch_split_planes_ex)
     int ksplit = 1;
     int ksplit_max = 0;            // conv_x3: caller's cap on the split (0: the launcher's rule)
     int epi_vec = 0;               // conv_x3: y / res rows are 16-byte aligned -> LDS-staged epilogue with 16-byte stores (set by the launcher)

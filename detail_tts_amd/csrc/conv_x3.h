@@ -66,7 +66,9 @@ static inline size_t x3d_bytes(int B, int CP, int T) { return (size_t)B * (CP / 
 // sat (may be null): device flag set to 1 when a scaled value lies beyond fp16's range (the planes saturate there)
 void launch_split_planes_ex(const float* x, long long x_bs, int x_cs, int act, float slope, const int* lens, int T, int B, int C, int CP,
                             int halo, int Tp, void* out, hipStream_t s, int* sat = nullptr);
-// p.w3 / p.x3 / p.x3_tp / p.x3_halo, p.Cin = padded input channels; stride 1, no gate / phases / badd
+// p.w3 / p.x3 / p.x3_tp / p.x3_halo, p.Cin = padded input channels; stride 1, no gate / phases / badd.  p.next3: act(y) written also
+// (p.y == null: only) as the planes of the NEXT conv - live columns; the buffer's margins are zeroed by launch_zero_plane_margins
 void launch_conv_x3d(const ConvParams& p, hipStream_t s);
+void launch_zero_plane_margins(const int* lens, int T, int B, int CP, int halo, int Tp, void* out, hipStream_t s);
 
 }  // namespace dtts

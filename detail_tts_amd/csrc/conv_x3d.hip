@@ -23,8 +23,10 @@ constexpr int BN = X3_BN, XCOLS = 256;
 constexpr int XTILE = NK * XCOLS * 16;               // 16 KiB
 
 // MI: 32-row MFMA blocks per wave: M tile 128 (MI = 2) or 64 (MI = 1: 50-channel stage, CoutP = 64)
-template <int KW, int MI>
-__global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
+// NEXT: the epilogue writes the next conv's planes (ConvParams::next3) - its own instantiation: with both epilogues in one kernel the
+// 128-row form no longer fits the 168 registers three workgroups per CU leave (350 spills, 2.7 x slower)
+template <int KW, int MI, bool NEXT>
+__global__ __launch_bounds__(256, (NEXT && MI == 2 && KW > 3) ? 2 : 3) void conv_x3d_kernel(ConvParams p) {
     constexpr int BM = 64 * MI, WTILE = NK * BM * 16, XOFF = 2 * WTILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
@@ -122,6 +124,64 @@ __global__ __launch_bounds__(256, 3) void conv_x3d_kernel(ConvParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    if (NEXT) {
+        // The consumer's operand planes straight from the accumulators (as conv_x3.hip's fused-GroupNorm tail): a lane holds 4 + 4 rows of
+        // two 8-channel chunks of ONE column; one v_permlane32_swap per packed word pairs the lane halves so that lanes 0..31 own the even
+        // chunk, lanes 32..63 the odd one, 16 bytes per plane.  Columns of the tile beyond the length are written as zeros.  Eight
+        // accumulators at a time, bias from its LDS copy: the kernel's register budget (168: three workgroups per CU) is the K loop's.
+        float* ybn = p.y ? p.y + (long long)b * p.y_bs : nullptr;
+        const float* rbn = p.res ? p.res + (long long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs : nullptr;
+        const bool epin = p.epi_act != ACT_NONE || p.out_scale != 1.f;
+        unsigned char* ob = static_cast<unsigned char*>(p.next3) + (size_t)b * p.next_c8 * NPL * p.next_tp * 16;
+        bool over = false;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int n = n0 + wn0 + j * 32 + l31;
+                const bool ok = n < nvalid;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int r16 = wm0 + i * 32 + 16 * k2;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = m0 + r16 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                        v[e] = (rbn && ok) ? rbn[(long long)(row < p.Cout ? row : p.Cout - 1) * p.res_cs + n] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int rt = r16 + (e & 3) + 8 * (e >> 2) + 4 * lhi, row = m0 + rt;
+                        float u = acc[i][j][8 * k2 + e] * XS_ACC_SCALE + bias_s[rt];
+                        if (epin) u = act_apply(u, p.epi_act, p.epi_slope) * p.out_scale;
+                        u += p.res_scale * v[e];
+                        const bool live = ok && row < p.Cout;
+                        if (live && ybn) ybn[(long long)row * p.y_cs + n] = u;
+                        if (p.next_act == ACT_LRELU) u = u > 0.f ? u : u * p.next_slope;
+                        u *= XS_SCALE_X;
+                        over |= live && !(fabsf(u) <= 65504.f);
+                        v[e] = live ? u : 0.f;
+                    }
+                    unsigned we0[2], we1[2], wo0[2], wo1[2];
+                    split_pair(v[0], v[1], we0[0], we1[0]);
+                    split_pair(v[2], v[3], we0[1], we1[1]);
+                    split_pair(v[4], v[5], wo0[0], wo1[0]);
+                    split_pair(v[6], v[7], wo0[1], wo1[1]);
+                    const auto s00 = __builtin_amdgcn_permlane32_swap(we0[0], wo0[0], false, false);
+                    const auto s01 = __builtin_amdgcn_permlane32_swap(we0[1], wo0[1], false, false);
+                    const auto s10 = __builtin_amdgcn_permlane32_swap(we1[0], wo1[0], false, false);
+                    const auto s11 = __builtin_amdgcn_permlane32_swap(we1[1], wo1[1], false, false);
+                    const int c8 = ((m0 + r16) >> 3) + lhi;
+                    if (c8 < p.next_c8) {
+                        unsigned char* o = ob + ((size_t)c8 * NPL * p.next_tp + n + p.next_halo) * 16;
+                        *reinterpret_cast<uint4*>(o) = make_uint4(s00[0], s01[0], s00[1], s01[1]);
+                        *reinterpret_cast<uint4*>(o + (size_t)p.next_tp * 16) = make_uint4(s10[0], s11[0], s10[1], s11[1]);
+                    }
+                }
+            }
+        if (p.next_sat && over) *p.next_sat = 1;
+        return;
+    }
     // ---- epilogue (as conv_x3.hip, EPI 0 / 1): bias, activation / out_scale, residual, var-len masking
     float bv[MI][16];
 #pragma unroll
@@ -202,9 +262,27 @@ void launch_split_planes_ex(const float* x, long long x_bs, int x_cs, int act, f
     DTTS_CHECK_HIP(hipGetLastError());
 }
 
+namespace {
+// zero margins of a planes buffer that a conv epilogue fills (ConvParams::next3): columns [0, halo) and [halo + len, Tp) of every chunk row
+__global__ __launch_bounds__(256) void zero_plane_margins_kernel(const int* __restrict__ lens, int T, int C8P, int halo, int Tp, uint4* __restrict__ out) {
+    const int row = blockIdx.x, b = blockIdx.y;                    // row = chunk * NPL + plane
+    const int len = lens ? lens[b] : T, right = halo + len, nz = halo + (Tp - right);
+    uint4* o = out + ((long long)b * C8P * NPL + row) * Tp;
+    for (int i = threadIdx.x; i < nz; i += 256) o[i < halo ? i : right + (i - halo)] = make_uint4(0, 0, 0, 0);
+}
+}  // namespace
+
+void launch_zero_plane_margins(const int* lens, int T, int B, int CP, int halo, int Tp, void* out, hipStream_t s) {
+    DTTS_REQUIRE(CP % 8 == 0 && halo >= 0 && Tp >= T + halo, "zero_plane_margins: padding");
+    hipLaunchKernelGGL(zero_plane_margins_kernel, dim3(CP / 8 * NPL, B), dim3(256), 0, s, lens, T, CP / 8, halo, Tp, static_cast<uint4*>(out));
+    DTTS_CHECK_HIP(hipGetLastError());
+}
+
 // p.w3 / p.x3 / p.x3_tp / p.x3_halo; p.Cin = the PADDED input channels (multiple of 16); stride 1, no gate / phases / badd
 void launch_conv_x3d(const ConvParams& p, hipStream_t s) {
-    DTTS_REQUIRE(p.w3 && p.x3 && p.y && p.x3_tp > 0, "conv_x3d: operands");
+    DTTS_REQUIRE(p.w3 && p.x3 && (p.y || p.next3) && p.x3_tp > 0, "conv_x3d: operands");
+    DTTS_REQUIRE(!p.next3 || (p.next_c8 > 0 && p.next_halo >= 0 && round_up(p.Nout, BN) + p.next_halo <= p.next_tp &&
+                              (p.next_act == ACT_NONE || p.next_act == ACT_LRELU)), "conv_x3d: planes for the next conv");
     DTTS_REQUIRE(p.B > 0 && p.Nout > 0 && p.Cout > 0, "empty conv");
     DTTS_REQUIRE(p.Cin % 16 == 0 && p.CoutP % 64 == 0, "conv_x3d: channel padding");
     DTTS_REQUIRE(p.stride == 1 && p.phases == 1 && p.gate == GATE_NONE && !p.badd && p.dil >= 1, "conv_x3d: unsupported conv form");
@@ -220,8 +298,10 @@ void launch_conv_x3d(const ConvParams& p, hipStream_t s) {
                  4.0 * cols * p.Cin + 4.0 * cols * p.Cout * (p.res ? 2.0 : 1.0) + 4.0 * (double)p.Cout * p.Cin * p.KW, s);
 #define DTTS_LAUNCH_X3D(K)                                                                            \
     do {                                                                                              \
-        if (MI == 2) { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 2>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 2>), grid, dim3(256), lds, s, p); } \
-        else { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 1>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 1>), grid, dim3(256), lds, s, p); } \
+        if (MI == 2 && p.next3) { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 2, true>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 2, true>), grid, dim3(256), lds, s, p); } \
+        else if (MI == 2) { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 2, false>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 2, false>), grid, dim3(256), lds, s, p); } \
+        else if (p.next3) { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 1, true>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 1, true>), grid, dim3(256), lds, s, p); } \
+        else { lds_optin(reinterpret_cast<const void*>(conv_x3d_kernel<K, 1, false>), lmax); hipLaunchKernelGGL((conv_x3d_kernel<K, 1, false>), grid, dim3(256), lds, s, p); } \
     } while (0)
     if (p.KW == 3) DTTS_LAUNCH_X3D(3);
     else if (p.KW == 7) DTTS_LAUNCH_X3D(7);

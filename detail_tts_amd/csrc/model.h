@@ -213,6 +213,7 @@ public:
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
+        else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -359,6 +360,7 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
+    bool opt_voc_chain_ = true;      // ResBlock1 (wide generator stages): conv epilogues write the next conv's planes (resblock1_fwd)
     bool opt_conv_cols_ = true;      // ragged batches: trunk convs launch their live (sample, N tile) columns only (register_cols)
     bool opt_range_check_ = false;      // vocoder: detect activations beyond the split-precision planes' range (synchronises)
     // Range check of the generator's split-precision planes: a ring of host-mapped flags, one slot per vocoder / generator call

@@ -213,7 +213,7 @@ static size_t generator_planes_bytes(const dtts_config& cfg, int B, int T) {
         t *= cfg.upsample_rates[i];
         if (ch > 32) best = std::max(best, x3d_bytes(B, round_up(ch, 16), (int)t));
     }
-    return best ? best + 256 : 0;
+    return best ? 2 * (best + 256) : 0;          // two buffers: a conv reads one while its epilogue fills the other (resblock1_fwd)
 }
 
 // modules.ResBlock1.forward (vqvae/modules/modules.py:315-328): three times x = convs2[l](lrelu(convs1[l](lrelu(x)))) + x with
@@ -239,12 +239,34 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
     };
     // wide stages: leaky-relu + split into fp16 planes as one pass, then the dilated split-precision conv (conv_x3d.hip)
     const bool x3 = xs && rb.c1[0].w3 && rb.c1[0].CoutP % 64 == 0 && vocoder_x3();     // (narrow stages carry w3 in the fused kernel's fragment order)
-    auto conv3 = [&](const PackedConv& pc, ConvParams p, const float* in) {
-        const int Tp = x3d_tp(T);
-        launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, xs, s, x3_sat_dev_);
+    // Round 5: only the block's FIRST conv is fed by a split pass; every conv's epilogue writes lrelu(y) as the next conv's planes
+    // (ConvParams::next3) into the other of two plane buffers, convs1 without an fp32 output at all: 6 -> 1 split passes per ResBlock1.
+    // Option voc_chain_planes = 0 / DTTS_VOC_CHAIN_PLANES=0: a split pass in front of every conv (round 4) - the same planes, bit for bit.
+    static const bool chain_env = []() { const char* v = getenv("DTTS_VOC_CHAIN_PLANES"); return !(v && v[0] == '0'); }();
+    const int Tp = x3d_tp(T), CP = x3 ? rb.c1[0].CinP : 0;
+    bool chain = x3 && chain_env && opt_voc_chain_;
+    for (int li = 0; li < 3 && chain; ++li) chain = rb.c1[li].CinP == CP && rb.c2[li].CinP == CP && rb.c1[li].Cout == ch && rb.c2[li].Cout == ch;
+    void* pl[2] = {xs, x3 ? static_cast<unsigned char*>(xs) + round_up((long long)x3d_bytes(B, CP, T), 256LL) : nullptr};
+    if (chain) launch_zero_plane_margins(lens, T, B, CP, X3D_HALO, Tp, pl[1], s);      // pl[0]'s margins: the first conv's split pass
+    int cur_pl = 0;                                     // buffer holding the planes of the conv about to run
+    bool have_planes = false;
+    auto conv3 = [&](const PackedConv& pc, ConvParams p, const float* in, bool feed_next, bool keep_y) {
+        if (!have_planes) launch_split_planes_ex(in, (long long)ch * T, T, ACT_LRELU, 0.1f, lens, T, B, ch, pc.CinP, X3D_HALO, Tp, pl[cur_pl], s, x3_sat_dev_);
         p.w3 = pc.w3;
-        p.x3 = xs;
+        p.x3 = pl[cur_pl];
         p.x3_tp = Tp;
+        if (chain && feed_next) {
+            p.next3 = pl[cur_pl ^ 1];
+            p.next_c8 = CP / 8;
+            p.next_tp = Tp;
+            p.next_halo = X3D_HALO;
+            p.next_act = ACT_LRELU;
+            p.next_slope = 0.1f;
+            p.next_sat = x3_sat_dev_;
+            if (!keep_y) p.y = nullptr;
+            cur_pl ^= 1;
+            have_planes = true;
+        } else have_planes = false;
         p.x3_halo = X3D_HALO;
         p.bias = pc.b;
         p.Cin = pc.CinP;
@@ -261,14 +283,14 @@ void Model::resblock1_fwd(const ResBlock1W& rb, const float* x, float* tmp, floa
         ConvParams a = cp(cur, tmp);
         a.dil = d;
         a.pad = (rb.k * d - d) / 2;
-        if (x3) conv3(rb.c1[li], a, cur);
+        if (x3) conv3(rb.c1[li], a, cur, true, false);            // tmp = convs1(lrelu(cur)): only its planes are needed
         else run_conv(rb.c1[li], a, s);
         ConvParams c = cp(tmp, out);
         c.pad = (rb.k - 1) / 2;
         c.res = cur;
         c.res_bs = (long long)ch * T;
         c.res_cs = T;
-        if (x3) conv3(rb.c2[li], c, tmp);
+        if (x3) conv3(rb.c2[li], c, tmp, li < 2, true);
         else run_conv(rb.c2[li], c, s);
         cur = out;
     }
@@ -377,7 +399,7 @@ void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_
     DTTS_REQUIRE(stage >= 0 && stage < (int)gen_.size() && branch >= 0 && branch < cfg.n_resblock_kernels, "resblock index");
     ArenaUse use_stage_c_arena(ws_voc_);
     const int ch = gen_[stage].cout;
-    ws().ensure(sizeof(float) * (size_t)B * ch * T + x3d_bytes(B, round_up(ch, 16), T) + 8192);
+    ws().ensure(sizeof(float) * (size_t)B * ch * T + 2 * (x3d_bytes(B, round_up(ch, 16), T) + 256) + 8192);
     std::vector<int> l(B);
     for (int b = 0; b < B; ++b) l[b] = lens_host ? lens_host[b] : T;
     const int* dl = upload_ints(l.data(), B, s);
@@ -388,7 +410,7 @@ void Model::op_resblock1(int stage, int branch, const float* x, const int* lens_
         return;
     }
     float* tmp = ws().f32((size_t)B * ch * T);
-    void* xs = ws().raw(x3d_bytes(B, round_up(ch, 16), T));
+    void* xs = ws().raw(2 * (x3d_bytes(B, round_up(ch, 16), T) + 256));
     x3_sat_flag(s);
     resblock1_fwd(gen_[stage].rb[branch], x, tmp, y, ch, dl, B, T, s, xs);
     x3_sat_check(s);

@@ -269,6 +269,9 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 (a table built from the host lengths of the call) instead of a grid over the padded length whose surplus workgroups
  *                 exit at once: the ids are dealt to the 8 XCDs in contiguous ranges, so the XCDs holding short samples used to run
  *                 dry early.  Same tiles, same arithmetic: bit-identical output; env DTTS_CONV_COLS=0;
+ *   "voc_chain_planes" (default 1): HiFiGAN ResBlock1 of the wide generator stages - every split-precision conv's epilogue writes
+ *                 leaky_relu(y) as the NEXT conv's fp16 operand planes (convs1 without an fp32 output at all), one split pass per block
+ *                 instead of six; 0 = a split pass in front of every conv.  The same planes bit for bit; env DTTS_VOC_CHAIN_PLANES=0;
  *   "x3_range_check" (default 0): 1 = a stage-C call checks that the inputs of its split-precision convs (ResBlock1, WaveNet in_layers:
  *                 unnormalised activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of
  *                 saturating silently.  Reads a flag back at the end of the call (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.

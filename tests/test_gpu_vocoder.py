@@ -323,6 +323,38 @@ def test_range_check_is_on_by_default_and_fails_the_request_that_saturated(weigh
     rt2.vocoder_check(rt2.vocoder_ticket())
 
 
+@pytest.mark.parametrize("stage,branch", [(0, 0), (0, 2), (1, 1)])
+def test_resblock1_planes_chained_through_the_conv_epilogues_are_bit_identical(weights, stage, branch):
+    """Round 5: in the wide generator stages every split-precision conv of a ResBlock1 writes leaky_relu(y) as the next conv's operand
+    planes from its epilogue (option voc_chain_planes, default on) instead of storing fp32 and running a split pass: the same values
+    split the same way, so the block's output must not change by one bit - ragged lengths inside / on / past a 192-column tile, channel
+    counts that are not multiples of 8 (200, 100: zero chunk rows), and a saturating activation still fails its own ticket."""
+    from detail_tts_amd.runtime import DttsError, Runtime
+    rt2 = Runtime(weights, folded=True, parts=("vocoder",))
+    rs = np.random.RandomState(80 + stage)
+    ch = [200, 100][stage]
+    T = 600
+    lens = [600, 192, 385, 77]
+    x = (rs.randn(4, ch, T) * 0.5).astype(np.float32)
+    outs = {}
+    try:
+        for flag in (0, 1):
+            rt2.set_option("voc_chain_planes", flag)
+            outs[flag] = host(rt2.op_resblock1(stage, branch, dev(x), lens))
+    finally:
+        rt2.set_option("voc_chain_planes", 1)
+    for b, L in enumerate(lens):
+        assert float(np.abs(outs[1][b, :, :L]).max()) > 0.1
+        assert np.array_equal(outs[0][b, :, :L], outs[1][b, :, :L]), b
+    bad = x.copy()
+    bad[1, 7, 100] = 5000.0
+    rt2.op_resblock1(stage, branch, dev(bad), lens)
+    t_bad = rt2.vocoder_ticket()
+    torch.cuda.synchronize()
+    with pytest.raises(DttsError, match="conv_x3"):
+        rt2.vocoder_check(t_bad)
+
+
 def test_wavenet_in_layers_on_the_split_precision_kernel_vs_fp32_path_and_range_ticket(weights):
     """Round 5: the flow's gated k = 5 WaveNet in_layers run as 1x1 conv_x3 launches over the 5-tap expansion of h
     (same w3 image, tanh * sigmoid + the conditioning rows in the epilogue).  Against the exact fp32-MFMA form (conv_x3 = 0) on ragged
