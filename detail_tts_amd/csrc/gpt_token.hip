@@ -66,9 +66,11 @@ static_assert(255 / P_PN + P_KL * (P_KT - 1) < KP && 255 / Q_PN + Q_KL * (Q_KT -
                   255 / H_PN + H_KL * (H_KT - 1) < KP, "LDS activation tile");
 
 // exchange arena, in 16-byte words ("quads": 3 consecutive columns of one row + tag)
-// Everything below is written for NR rows per session, NR = 8 (round 3) or 16 (round 4: two requests of 8 utterances decoded as ONE
-// session - the weights stream once per token for both).  Per row the arithmetic and the order of every sum are the same in both
-// instantiations, so a row's latents do not depend on which one produced them.
+// Everything below is written for NR rows per session, NR = 8 (round 3), 16 (round 4: two requests of 8 utterances decoded as ONE
+// session - the weights stream once per token for both) or 4 (round 5: sessions of <= 4 rows, i.e. the batch-1 latency case - the
+// padded rows of an 8-row launch cost their share of every FMA loop, LayerNorm, regroup-and-store tail and exchange word).  Per row
+// the arithmetic and the order of every sum are the same in all instantiations, so a row's latents do not depend on which one
+// produced them.
 constexpr int XQ = TC / 3;                     // quads per row of a 768-wide buffer
 template <int NR>
 struct Geo {
@@ -76,9 +78,9 @@ struct Geo {
     static constexpr int RS_PER = NR * NP;        // values one source sends one owner: 6 columns x NR rows, [column][row]
     static constexpr int RS_Q = RS_PER / 3;       // 16 / 32 quads
     static constexpr int XCH_QUADS = RS_OFF + TG * TG * RS_Q;
-    static constexpr int RED = NR == 8 ? 6144 : 12288;      // floats of the `red` scratch
+    static constexpr int RED = NR <= 8 ? 6144 : 12288;      // floats of the `red` scratch (>= 768 NR; >= the KV capacity: attention scores)
 };
-static_assert(2 * Geo<16>::XCH_QUADS == GPT_TOKEN_XCH_WORDS && Geo<8>::XCH_QUADS < Geo<16>::XCH_QUADS, "exchange arena size");
+static_assert(2 * Geo<16>::XCH_QUADS == GPT_TOKEN_XCH_WORDS && Geo<8>::XCH_QUADS < Geo<16>::XCH_QUADS && Geo<4>::XCH_QUADS < Geo<8>::XCH_QUADS, "exchange arena size");
 
 template <int NR>
 struct SmemT {
@@ -105,7 +107,7 @@ static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials a
 // (option "gpt_token_exclusive_cu" / DTTS_GPT_TOKEN_EXCLUSIVE_CU, see DESIGN.md for the measured choice); the stress tests run both
 // settings next to LDS kernels, zero-LDS kernels and the vocoder (tests/test_gpu_e2e.py::test_token_kernel_under_concurrent_*).
 constexpr int LDS_EXCLUSIVE = 160 * 1024;
-static_assert(sizeof(SmemT<8>) <= 64 * 1024 && sizeof(SmemT<16>) <= 128 * 1024, "LDS");
+static_assert(sizeof(SmemT<4>) <= 64 * 1024 && sizeof(SmemT<8>) <= 64 * 1024 && sizeof(SmemT<16>) <= 128 * 1024, "LDS");
 
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
@@ -194,6 +196,41 @@ __device__ __forceinline__ float wsum8(const float (&s)[8], int lane) {
     return w;
 }
 
+// the 4-row form of wsum8 (7 shuffles): every lane gets the total of row (lane >> 4) & 3.  Per row the same tree as wsum8 - levels in the
+// order 32, 16, 8, 4, 2, 1, every level adds the same two partial sums, and a + b == b + a bit for bit - so a row's statistics do not
+// depend on the instantiation
+__device__ __forceinline__ float wsum4(const float (&s)[4], int lane) {
+    const bool h32 = lane & 32, h16 = lane & 16;
+    float t[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t[i] = (h32 ? s[2 + i] : s[i]) + __shfl_xor(h32 ? s[i] : s[2 + i], 32);
+    float w = (h16 ? t[1] : t[0]) + __shfl_xor(h16 ? t[0] : t[1], 16);
+    w += __shfl_xor(w, 8);
+    w += __shfl_xor(w, 4);
+    w += __shfl_xor(w, 2);
+    w += __shfl_xor(w, 1);
+    return w;
+}
+
+// the wave's row sums of s[NR] -> st[row][wave]
+template <int NR>
+__device__ __forceinline__ void wave_row_sums(const float (&s)[NR], float (*st)[4], int lane, int wave) {
+    if constexpr (NR % 8 == 0) {
+#pragma unroll
+        for (int h = 0; h < NR / 8; ++h) {
+            float s8[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) s8[b] = s[8 * h + b];
+            const float w = wsum8(s8, lane);
+            if ((lane & 7) == 0) st[8 * h + ((lane >> 3) & 7)][wave] = w;
+        }
+    } else {
+        static_assert(NR == 4, "row sums");
+        const float w = wsum4(s, lane);
+        if ((lane & 15) == 0) st[(lane >> 4) & 3][wave] = w;
+    }
+}
+
 // LayerNorm of NR rows of 768 (thread: columns 3 tid .. 3 tid + 2), two-pass statistics; rows 8 h .. 8 h + 7 go through one wsum8 each
 template <int NR>
 __device__ __forceinline__ void ln8(float (&v)[NR][3], const float* __restrict__ g, const float* __restrict__ be, SmemT<NR>& sm, int tid) {
@@ -204,13 +241,11 @@ __device__ __forceinline__ void ln8(float (&v)[NR][3], const float* __restrict__
         gg[m] = GLOBAL_PTR(float, g)[3 * tid + m];
         bb[m] = GLOBAL_PTR(float, be)[3 * tid + m];
     }
+    {
+        float s[NR];
 #pragma unroll
-    for (int h = 0; h < NR / 8; ++h) {
-        float s[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) s[b] = (v[8 * h + b][0] + v[8 * h + b][1]) + v[8 * h + b][2];
-        const float w = wsum8(s, lane);
-        if ((lane & 7) == 0) sm.st1[8 * h + ((lane >> 3) & 7)][wave] = w;
+        for (int b = 0; b < NR; ++b) s[b] = (v[b][0] + v[b][1]) + v[b][2];
+        wave_row_sums<NR>(s, sm.st1, lane, wave);
     }
     __syncthreads();
     float mean[NR];
@@ -219,16 +254,14 @@ __device__ __forceinline__ void ln8(float (&v)[NR][3], const float* __restrict__
         const float4 p = *reinterpret_cast<const float4*>(sm.st1[b]);
         mean[b] = ((p.x + p.y) + (p.z + p.w)) * (1.f / TC);
     }
+    {
+        float s[NR];
 #pragma unroll
-    for (int h = 0; h < NR / 8; ++h) {
-        float s[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const float d0 = v[8 * h + b][0] - mean[8 * h + b], d1 = v[8 * h + b][1] - mean[8 * h + b], d2 = v[8 * h + b][2] - mean[8 * h + b];
+        for (int b = 0; b < NR; ++b) {
+            const float d0 = v[b][0] - mean[b], d1 = v[b][1] - mean[b], d2 = v[b][2] - mean[b];
             s[b] = (d0 * d0 + d1 * d1) + d2 * d2;
         }
-        const float w = wsum8(s, lane);
-        if ((lane & 7) == 0) sm.st2[8 * h + ((lane >> 3) & 7)][wave] = w;
+        wave_row_sums<NR>(s, sm.st2, lane, wave);
     }
     __syncthreads();
 #pragma unroll
@@ -410,8 +443,9 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             q_store(xc, QB + b * (3 * XQ) + (NQ / 3) * w + t3, o[0], o[1], o[2], tag);
         }
 #pragma unroll 1
-        for (int it = 0; it < NR / 8; ++it) {                  // attention work item (head ah, row ab); a 16-row session has two per workgroup
+        for (int it = 0; it < (NR + 7) / 8; ++it) {            // attention work item (head ah, row ab); a 16-row session has two per workgroup
         const int ab = (w & 7) + 8 * it;
+        if (NR < 8 && ab >= NR) continue;                      // 4-row sessions: the workgroups of rows 4 .. 7 have none (workgroup-uniform)
         const bool arow = ab < B;
         const int an = arow ? ctl->lp[ab] + ctl->step[ab] : 1;        // keys including the new one
         const int ncach = an - 1;
@@ -792,20 +826,22 @@ bool gpt_token_supported(int C, int H, int F, int NL, int V) { return C == TC &&
 // into SPIN_LIMIT.  false -> the caller keeps the launch-per-GEMV chain.
 bool gpt_token_prepare() {
     if (!device_fits(TG, LDS_EXCLUSIVE)) return false;
-    int nb8 = 0, nb16 = 0;
+    int nb4 = 0, nb8 = 0, nb16 = 0;
     try {
+        lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<4>), LDS_EXCLUSIVE);
         lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<8>), LDS_EXCLUSIVE);
         lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<16>), LDS_EXCLUSIVE);
     } catch (const Error&) {
         (void)hipGetLastError();
         return false;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, reinterpret_cast<const void*>(gpt_token_kernel<8>), 256, LDS_EXCLUSIVE) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(gpt_token_kernel<4>), 256, LDS_EXCLUSIVE) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, reinterpret_cast<const void*>(gpt_token_kernel<8>), 256, LDS_EXCLUSIVE) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, reinterpret_cast<const void*>(gpt_token_kernel<16>), 256, LDS_EXCLUSIVE) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    return nb8 >= 1 && nb16 >= 1;
+    return nb4 >= 1 && nb8 >= 1 && nb16 >= 1;
 }
 
 size_t gpt_token_pack_floats(int which) {
@@ -831,7 +867,8 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.B >= 1 && p.B <= GPT_TOKEN_ROWS && p.NL >= 1 && p.NL <= GPT_TOKEN_MAX_LAYERS && p.Vs == GPT_TOKEN_VS, "persistent decode token: shape");
     DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
     const bool r16 = p.B > 8;                                                          // 9 .. 16 rows: the 16-row instantiation
-    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)(r16 ? sizeof(SmemT<16>) : sizeof(SmemT<8>));   // the attribute was raised by gpt_token_prepare (bind time)
+    const bool r4 = p.B <= 4 && p.min_rows <= 4;                                       // 1 .. 4 rows: the 4-row one (option gpt_token_min_rows = 8: off)
+    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)(r16 ? sizeof(SmemT<16>) : r4 ? sizeof(SmemT<4>) : sizeof(SmemT<8>));   // the attribute was raised by gpt_token_prepare (bind time)
     // DTTS_GPT_TOKEN_TRACE = n: the n-th launch records wall-clock stamps of workgroups 0 and 37 at every exchange and prints them
     static const int trace_at = []() { const char* v = getenv("DTTS_GPT_TOKEN_TRACE"); return v ? atoi(v) : 0; }();
     static int launches = 0;
@@ -845,6 +882,7 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
         q.trace = d_trace;
     }
     if (r16) hipLaunchKernelGGL(gpt_token_kernel<16>, dim3(TG), dim3(256), lds_request, s, q);
+    else if (r4) hipLaunchKernelGGL(gpt_token_kernel<4>, dim3(TG), dim3(256), lds_request, s, q);
     else hipLaunchKernelGGL(gpt_token_kernel<8>, dim3(TG), dim3(256), lds_request, s, q);
     DTTS_CHECK_HIP(hipGetLastError());
     if (tracing) {

@@ -208,10 +208,12 @@ public:
         else if (key == "x3_range_check") opt_range_check_ = value != 0;
         else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; if (value != 0) tok_failed_ = false; gpt_drop_graphs(); }
         else if (key == "gpt_token_exclusive_cu") { opt_tok_exclusive_ = value != 0; gpt_drop_graphs(); }
+        else if (key == "gpt_token_min_rows") { DTTS_REQUIRE(value == 4 || value == 8, "gpt_token_min_rows: 4 or 8"); opt_tok_min_rows_ = value; gpt_drop_graphs(); }
         else if (key == "gpt_token_fault") opt_tok_fault_ = value;       // test hook: the n-th token launch from now on times out
         else if (key == "gpt_token_fault_eos") opt_tok_fault_eos_ = value;   // ... and leaves every row flagged finished (a spurious stop token)
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
+        else if (key == "latency_mode") opt_latency_mode_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
@@ -284,6 +286,8 @@ private:
     GnXch gn_xch_[GN_SLOTS];
     int* gn_err_host_ = nullptr;
     int* gn_err_dev_ = nullptr;
+    bool opt_latency_mode_ = true;        // option "latency_mode": a single-chunk diffusion forward (batches <= 4) may assume the chip is its own (conv_x3: four LDS stages up to 256 workgroups)
+    mutable std::atomic<int> conv_alone_{0};
     bool opt_gn_fuse_ = false;            // option "gn_fuse" (measured neutral-to-negative at every batch size: DESIGN.md par. 4; DTTS_GN_FUSE=0/1 overrides)
     void gn_fill(ConvParams& p, int slot, size_t bytes, const GnNext& n, void* out3, int groups, hipStream_t s);
     void gn_check();                      // throws when a fused-GroupNorm poll timed out since the last check
@@ -334,6 +338,7 @@ private:
     bool tok_ok_ = false;                 // the model has the shape the token kernel is written for
     bool opt_gpt_token_ = true;           // option "gpt_token_kernel"
     bool opt_tok_exclusive_ = true;       // option "gpt_token_exclusive_cu": the token kernel asks for whole CUs
+    int opt_tok_min_rows_ = 4;            // option "gpt_token_min_rows": sessions of <= 4 rows take the 4-row token kernel (8: the 8-row one)
     bool tok_failed_ = false;             // an exchange timed out once: this handle stays on the chain (until the option is set again)
     int opt_tok_fault_ = 0;               // option "gpt_token_fault"
     int opt_tok_fault_eos_ = 0;           // option "gpt_token_fault_eos"

@@ -398,6 +398,8 @@ void Model::gpt_step_launches(hipStream_t s) {
         static const int env_nap = []() { const char* v = getenv("DTTS_GPT_TOKEN_NAP"); return v ? atoi(v) : 0; }();
         p.prio = env_prio;
         p.poll_nap = env_nap;
+        static const int env_min_rows = []() { const char* v = getenv("DTTS_GPT_TOKEN_MIN_ROWS"); return v ? atoi(v) : 0; }();
+        p.min_rows = env_min_rows ? env_min_rows : opt_tok_min_rows_;
         if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)
             const int one = 1;
             DTTS_CHECK_HIP(hipMemcpyAsync(gs_.tok_err, &one, sizeof(int), hipMemcpyHostToDevice, s));

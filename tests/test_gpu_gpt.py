@@ -218,6 +218,42 @@ def test_token_kernel_equals_the_launch_per_gemv_chain(rt):
     assert np.array_equal(c2[0], c3[0]) and np.array_equal(c2[1], c3[1])
 
 
+def test_four_row_token_kernel_equals_the_eight_row_token_kernel_bit_for_bit(rt):
+    """Round 5: sessions of <= 4 rows (the batch-1 latency case) run a 4-row instantiation of the persistent token kernel.  Per row its
+    arithmetic and every summation order are the 8-row kernel's (LayerNorm statistics by the same butterfly tree), so codes AND latents
+    are bit-identical to the same session on the 8-row kernel (option gpt_token_min_rows = 8); B = 1, 3, 4; free sampling with the stop
+    token allowed, and a teacher-forced session past 384 / 512 keys (the V / K rounds beyond the register-resident ones)."""
+    rs = np.random.RandomState(83)
+    for B, G in ((1, 40), (3, 30), (4, 30)):
+        refer = (rs.randn(B, 128, 110) * 2 - 5).astype(np.float32)
+        rl = [110 - 7 * b for b in range(B)]
+        texts = [np.concatenate([rs.randint(3, 255, 5 + 2 * b), [0]]).astype(np.int32) for b in range(B)]
+        args = (dev(refer), rl, texts, 31 + B, list(range(40, 40 + B)))
+        out4 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+        e4 = rt.gpt_generate(*args, max_generate_length=12)
+        rt.set_option("gpt_token_min_rows", 8)
+        try:
+            out8 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+            e8 = rt.gpt_generate(*args, max_generate_length=12)
+        finally:
+            rt.set_option("gpt_token_min_rows", 4)
+        assert np.array_equal(out4[0], out8[0]) and np.array_equal(out4[1], out8[1]), B
+        assert torch.equal(out4[2], out8[2]), B
+        assert np.array_equal(e4[0], e8[0]) and np.array_equal(e4[1], e8[1]), B
+    B, G = 2, 160
+    refer = (rs.randn(B, 128, 150) * 2 - 5).astype(np.float32)
+    texts = [np.concatenate([rs.randint(3, 255, 400 - 30 * b), [0]]).astype(np.int32) for b in range(B)]
+    forced = [rs.randint(0, 8192, G).astype(np.int32) for _ in range(B)]
+    args = (dev(refer), None, texts, 9, [3, 4])
+    l4 = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2].clone()
+    rt.set_option("gpt_token_min_rows", 8)
+    try:
+        l8 = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2].clone()
+    finally:
+        rt.set_option("gpt_token_min_rows", 4)
+    assert torch.equal(l4, l8)
+
+
 def test_token_kernel_long_session_equals_the_chain(rt):
     """Sessions whose key count passes 512 (the register-resident K rounds) and 384 (the V rounds) of the persistent token kernel: a
     400-token prompt + 200 teacher-forced tokens, latents against the launch-per-GEMV chain at every position; and free sampling at
