@@ -87,7 +87,6 @@ struct ConvParams {
     int* next_sat = nullptr;       // raised when a scaled value leaves fp16's range (as launch_split_planes_ex)
     int ksplit = 1;
     int ksplit_max = 0;            // conv_x3: caller's cap on the split (0: the launcher's rule)
-    int alone = 0;                 // conv_x3: the launch has the chip to itself (a single-chunk forward outside the request pipeline): <= 256 workgroups take four LDS stages
     int epi_vec = 0;               // conv_x3: y / res rows are 16-byte aligned -> LDS-staged epilogue with 16-byte stores (set by the launcher)
     float* kpart = nullptr;
     int* kcount = nullptr;

@@ -1305,12 +1305,7 @@ void launch_conv_x3(const ConvParams& p_in, hipStream_t s) {
     }
     const long long nwg = ntile * S;
     static const long long max4k3 = []() { const char* v = getenv("DTTS_CONV_STAGES4_MAXWG_K3"); return v ? atoll(v) : 128LL; }();
-    // (round 5) a launch that has the chip to itself (p.alone: the single-chunk forward of batches <= 4 in a blocking call) runs four
-    // stages at one workgroup per CU up to 256 workgroups: its time is one tile's dependency chain, not the chip's throughput
-    // (batch 1: diffusion 121.8 -> 119.3 ms; under the request pipeline, where other stages' kernels want the LDS, it costs 2 %)
-    static const long long max4_alone = []() { const char* v = getenv("DTTS_CONV_STAGES4_MAXWG_ALONE"); return v ? atoll(v) : 256LL; }();
-    const long long m4 = std::max<long long>(p.KW == 3 ? max4k3 : max4, p.alone ? max4_alone : 0LL);
-    const int nstg = force_stg ? force_stg : (nwg <= m4 ? 4 : (nwg <= max3 ? 3 : 2));
+    const int nstg = force_stg ? force_stg : (nwg <= (p.KW == 3 ? max4k3 : max4) ? 4 : (nwg <= max3 ? 3 : 2));
     const size_t lds = (size_t)nstg * (WTILE + XBUF) + BM * sizeof(float) + 16 + (gn ? 2 * BM * sizeof(float) : 0);
     const int l4 = 4 * (WTILE + XBUF) + 3 * BM * (int)sizeof(float) + 16;      // the attribute is a maximum: every instantiation gets the 4-stage size
     const dim3 grid((unsigned)nwg);

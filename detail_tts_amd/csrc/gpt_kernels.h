@@ -102,6 +102,7 @@ struct SamplerParams {
     const float* mel_pos;
     float* x_next;
     int C;
+    long long* trace = nullptr;   // debug: wall-clock stamps of row 0 (DTTS_SAMPLER_TRACE = n: the n-th launch), normally null
 };
 void launch_sampler(const SamplerParams& p, hipStream_t s);
 

@@ -723,6 +723,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     __shared__ int sh_i[4];
 
     const int tid = threadIdx.x, b = blockIdx.x, V = p.V;
+#define SSTAMP(k)                                                       \
+    do {                                                                \
+        if (p.trace && tid == 0 && b == 0) p.trace[k] = wall_clock64(); \
+    } while (0)
+    SSTAMP(0);
     GptCtl* ctl = p.ctl;
     const int step = ctl->step[b];
     if (step >= ctl->max_steps) return;                  // a replayed graph may run past the requested length: no-op
@@ -749,6 +754,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             sv[v] = typical ? x : x / temp;
         }
         __syncthreads();
+        SSTAMP(1);
         // 1b. HF TypicalLogitsWarper (inference_speech_tortoise(typical_sampling=True), gpt/model.py:539; it sits between the repetition
         // penalty and the temperature): key = | -log p - H |, ascending sort of the whole vocabulary by it, keep the keys up to the
         // first whose cumulative probability reaches the mass.  Off the infer path: the full 16 K-slot bitonic sort is fine here.
@@ -860,16 +866,19 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                 mask |= 255u << sh;
                 krem = sh_i[0];
                 __syncthreads();
+                SSTAMP(5 - pass);
             }
             const float thr = ord2f(prefix);
             for (int v = tid; v < V; v += SAMP_THREADS)
                 if (sv[v] < thr) sv[v] = -INFINITY;
             __syncthreads();
+            SSTAMP(6);
         }
         // 3. softmax statistics of the kept set
         float mx = -INFINITY;
         for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, sv[v]);
         mx = block_reduce_max(mx, red);
+        SSTAMP(7);
         // 4. top-p (nucleus): ascending sort of the kept candidates, drop the tail whose cumulative prob <= 1 - top_p
         if (top_p < 1.0f) {
             if (tid == 0) sh_i[1] = 0;
@@ -886,6 +895,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             while (n2 < M) n2 <<= 1;
             for (int i = M + tid; i < n2; i += SAMP_THREADS) { skey[i] = INFINITY; sidx[i] = 0xffff; }
             __syncthreads();
+            SSTAMP(8);
             if (n2 == 64) {
                 // top-k 50 leaves <= 64 candidates: one wave sorts them with no workgroup barriers (21 of them otherwise).  LDS
                 // operations of a wave complete in issue order; the wave barrier only pins the compiler's ordering.
@@ -923,10 +933,12 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                     __syncthreads();
                 }
             }
+            SSTAMP(9);
             // Z over the kept set, then inclusive cumulative prob in ascending order
             float z = 0.f;
             for (int i = tid; i < M; i += SAMP_THREADS) z += expf(skey[i] - mx);
             z = block_reduce_sum(z, red);
+            SSTAMP(10);
             const int per = (n2 + SAMP_THREADS - 1) / SAMP_THREADS;
             const int i0 = tid * per;
             float loc = 0.f;
@@ -939,6 +951,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                 if (run <= cut && i != M - 1) sv[sidx[i]] = -INFINITY;
             }
             __syncthreads();
+            SSTAMP(11);
         }
         // 5. inverse-CDF draw in vocabulary order
         const int per = (V + SAMP_THREADS - 1) / SAMP_THREADS;
@@ -947,6 +960,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         for (int v = v0; v < v0 + per && v < V; ++v) loc += (sv[v] > -INFINITY) ? expf(sv[v] - mx) : 0.f;
         float tot;
         float run = block_exclusive_scan(loc, red, &tot);
+        SSTAMP(12);
         float u;
         if (ctl->forced_u) u = ctl->forced_u[(long long)b * ctl->u_stride + step];
         else {
@@ -968,6 +982,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         if (last_kept >= 0) atomicMax(&sh_i[3], last_kept);
         __syncthreads();
         token = sh_i[2] < V ? sh_i[2] : sh_i[3];
+        SSTAMP(13);
     }
     const bool fin = p.finished[b] != 0;
     if (fin) token = p.eos;
@@ -982,14 +997,37 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     if (p.x_next)
         for (int c = tid; c < p.C; c += SAMP_THREADS)
             p.x_next[(long long)b * p.C + c] = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(step + 1) * p.C + c];
+    SSTAMP(14);
+#undef SSTAMP
 }
 
 void launch_sampler(const SamplerParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.V <= SORT_MAX && p.V < 65535, "vocabulary too large for the LDS sampler");
     const size_t lds = sizeof(float) * (size_t)(((p.V + 3) & ~3) + SORT_MAX) + sizeof(unsigned short) * SORT_MAX;
     lds_optin(reinterpret_cast<const void*>(sampler_kernel), 150 * 1024);
-    hipLaunchKernelGGL(sampler_kernel, dim3(p.B), dim3(SAMP_THREADS), lds, s, p);
+    // DTTS_SAMPLER_TRACE = n: the n-th launch records wall-clock stamps of row 0's phases and prints them (100 MHz clock)
+    static const int trace_at = []() { const char* v = getenv("DTTS_SAMPLER_TRACE"); return v ? atoi(v) : 0; }();
+    static int launches = 0;
+    static long long* d_trace = nullptr;
+    SamplerParams q = p;
+    q.trace = nullptr;
+    const bool tracing = trace_at > 0 && ++launches == trace_at;
+    if (tracing) {
+        if (!d_trace) DTTS_CHECK_HIP(hipMalloc(&d_trace, sizeof(long long) * 16));
+        DTTS_CHECK_HIP(hipMemsetAsync(d_trace, 0, sizeof(long long) * 16, s));
+        q.trace = d_trace;
+    }
+    hipLaunchKernelGGL(sampler_kernel, dim3(p.B), dim3(SAMP_THREADS), lds, s, q);
     DTTS_CHECK_HIP(hipGetLastError());
+    if (tracing) {
+        long long h[16];
+        DTTS_CHECK_HIP(hipMemcpyAsync(h, d_trace, sizeof(h), hipMemcpyDeviceToHost, s));
+        DTTS_CHECK_HIP(hipStreamSynchronize(s));
+        static const char* names[15] = {"start", "logits", "radix3", "radix2", "radix1", "radix0", "top-k cut", "max", "compact", "sort", "Z", "top-p", "cdf scan", "draw", "end"};
+        fprintf(stderr, "[sampler trace] row 0, us since the kernel's first instruction:");
+        for (int k = 1; k < 15; ++k) fprintf(stderr, " %s %.2f |", names[k], h[k] ? (h[k] - h[0]) * 0.01 : -1.0);
+        fprintf(stderr, "\n");
+    }
 }
 
 }  // namespace dtts

@@ -213,7 +213,6 @@ public:
         else if (key == "gpt_token_fault_eos") opt_tok_fault_eos_ = value;   // ... and leaves every row flagged finished (a spurious stop token)
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
-        else if (key == "latency_mode") opt_latency_mode_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
         else throw Error(-1, "unknown option '" + key + "'");
@@ -286,8 +285,6 @@ private:
     GnXch gn_xch_[GN_SLOTS];
     int* gn_err_host_ = nullptr;
     int* gn_err_dev_ = nullptr;
-    bool opt_latency_mode_ = true;        // option "latency_mode": a single-chunk diffusion forward (batches <= 4) may assume the chip is its own (conv_x3: four LDS stages up to 256 workgroups)
-    mutable std::atomic<int> conv_alone_{0};
     bool opt_gn_fuse_ = false;            // option "gn_fuse" (measured neutral-to-negative at every batch size: DESIGN.md par. 4; DTTS_GN_FUSE=0/1 overrides)
     void gn_fill(ConvParams& p, int slot, size_t bytes, const GnNext& n, void* out3, int groups, hipStream_t s);
     void gn_check();                      // throws when a fused-GroupNorm poll timed out since the last check

@@ -320,7 +320,6 @@ void Model::run_conv(const PackedConv& pc, ConvParams p, hipStream_t s) const {
         DTTS_REQUIRE(pc.w3, "conv has no split-precision weights");
         p.w3 = pc.w3;
         attach_cols(p);
-        if (conv_alone_.load(std::memory_order_relaxed)) p.alone = 1;      // a performance hint only: the stage count changes no output bit
         launch_conv_x3(p, s);
         return;
     }
@@ -827,13 +826,6 @@ void Model::diff_forward_pair(const float* x, const float* cbuf0, const int* len
         DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
         for (int k = 1; k < NS; ++k) DTTS_CHECK_HIP(hipStreamWaitEvent(sx_[k - 1], ev_fork_, 0));
     }
-    // one chunk on one stream and the caller says nothing else is running (option "latency_mode": blocking infer; infer_stream clears it)
-    struct AloneScope {
-        std::atomic<int>& f;
-        const bool on;
-        AloneScope(std::atomic<int>& f_, bool on_) : f(f_), on(on_) { if (on) f.fetch_add(1, std::memory_order_relaxed); }
-        ~AloneScope() { if (on) f.fetch_sub(1, std::memory_order_relaxed); }
-    } alone_scope(conv_alone_, NS == 1 && opt_latency_mode_);
     for (int k = 0; k < NS; ++k) {
         hipStream_t st = k ? sx_[k - 1] : s;
         const int b0 = k * n;                          // first sample of the chunk in the 2B stack

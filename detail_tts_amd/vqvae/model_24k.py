@@ -354,13 +354,7 @@ class SynthesizerTrn:
             cond = self.rt.diff_conditioning(refer, st["rl"])
             code_emb = self.rt.diff_timestep_independent(lat, cond, n)
             lens_t = [4 * v for v in n]
-            # under the pipeline other stages' kernels share the chip: no "the launch is alone" hint for the small-batch trunk convs
-            # (option latency_mode: blocking infer keeps it; the hint changes launch geometry only, never an output bit)
-            self.rt.set_option("latency_mode", 0)
-            try:
-                mel = self.rt.diff_sample(code_emb, st["seed"], st["sids"], lens=lens_t, denorm=True)
-            finally:
-                self.rt.set_option("latency_mode", 1)
+            mel = self.rt.diff_sample(code_emb, st["seed"], st["sids"], lens=lens_t, denorm=True)
             ready = torch.cuda.Event()
             ready.record(cur)
             if tr:

@@ -260,10 +260,6 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 stress-tested bit-identical under stage B / C loads); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
  *   "gpt_token_min_rows" (default 4): sessions of <= 4 rows run the 4-row instantiation of the token kernel (round 5: the batch-1
  *                 latency case; per row bit-identical to the 8-row one); 8 = they run the 8-row kernel; env DTTS_GPT_TOKEN_MIN_ROWS;
- *   "latency_mode" (default 1): a diffusion forward that runs as ONE chunk on one stream (batches <= 4) tells its trunk convs that
- *                 nothing else shares the chip: launches of <= 256 workgroups take four LDS stages at one workgroup per CU (batch 1:
- *                 diffusion 121.8 -> 119.3 ms).  SynthesizerTrn.infer_stream clears it around its diffusion calls (other stages' kernels
- *                 run underneath).  Launch geometry only: no output bit changes;
  *   "gpt_token_fault" (test hook, default 0): n > 0 makes the n-th token-kernel launch from now on behave like an exchange time-out;
  *   "gpt_token_fault_eos" (test hook, default 0): 1 = that fault also leaves every row flagged finished (a spurious stop token);
  *   "gn_fuse" (default 0): 1 = every GroupNorm + activation + split of the diffusion trunk (T <= 1152) runs in the epilogue of the conv

@@ -1,10 +1,10 @@
 #!/bin/bash
-# per-kernel durations of the decode step at 8 and 16 rows (rocprofv3 kernel trace of tools/bench_gpt.py)
+# per-kernel durations of the decode step at 1, 8 and 16 rows (ROWS="1 8 16") (rocprofv3 kernel trace of tools/bench_gpt.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for bb in 8 16; do
+for bb in ${ROWS:-1 8 16}; do
   rm -rf /tmp/gptrows_$bb
   BB=$bb timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/gptrows_$bb -o gpt -- python $R/tools/bench_gpt.py > /tmp/gptrows_$bb.log 2>&1
   DB=$(find /tmp/gptrows_$bb -name '*.db' | head -1)
