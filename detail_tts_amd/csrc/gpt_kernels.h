@@ -111,7 +111,7 @@ void launch_sampler(const SamplerParams& p, hipStream_t s);
 constexpr int GPT_TOKEN_WGS = 128;
 constexpr int GPT_TOKEN_MAX_LAYERS = 12;
 constexpr int GPT_TOKEN_VS = 66 * GPT_TOKEN_WGS;                     // logits row stride (mel_head columns padded to 66 per workgroup)
-constexpr int GPT_TOKEN_ROWS = 16;                                   // rows of a session the token kernel covers (three instantiations: 4, 8 and 16)
+constexpr int GPT_TOKEN_ROWS = 16;                                   // rows of a session the token kernel covers (four instantiations: 1, 4, 8 and 16)
 constexpr int GPT_TOKEN_XCH_WORDS = 2 * (16 * 256 * 6 + 128 * 128 * 32);     // exchange arena of a 16-row session in 8-byte units (addressed in 16-byte words)
 struct GptTokenLayer {
     const float4 *wq, *wp, *wf;      // c_attn / attention c_proj / c_fc repacked in register order (launch_gpt_token_pack 0 / 1 / 2)
@@ -140,7 +140,7 @@ struct GptTokenParams {
     int exclusive_cu;                // ask for a CU's whole LDS: one token workgroup per CU, no LDS-using workgroup next to it
     int prio;                        // s_setprio 3 for the kernel's waves (default 1)
     int poll_nap;                    // extra sleep rounds between two polls of an exchange word (default 0)
-    int min_rows;                    // smallest instantiation a session may take: 4 (default) or 8 (sessions of <= 4 rows run the 8-row kernel)
+    int min_rows;                    // smallest instantiation a session may take: 1 (default), 4 or 8 (e.g. 8: sessions of <= 4 rows run the 8-row kernel)
 };
 bool gpt_token_supported(int C, int H, int F, int NL, int V);
 bool gpt_token_prepare();            // device check + kernel attributes at bind time; false = use the chain

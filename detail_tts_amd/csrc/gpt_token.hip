@@ -67,8 +67,9 @@ static_assert(255 / P_PN + P_KL * (P_KT - 1) < KP && 255 / Q_PN + Q_KL * (Q_KT -
 
 // exchange arena, in 16-byte words ("quads": 3 consecutive columns of one row + tag)
 // Everything below is written for NR rows per session, NR = 8 (round 3), 16 (round 4: two requests of 8 utterances decoded as ONE
-// session - the weights stream once per token for both) or 4 (round 5: sessions of <= 4 rows, i.e. the batch-1 latency case - the
-// padded rows of an 8-row launch cost their share of every FMA loop, LayerNorm, regroup-and-store tail and exchange word).  Per row
+// session - the weights stream once per token for both), 4 (round 5: sessions of <= 4 rows - the padded rows of an 8-row launch cost
+// their share of every FMA loop, LayerNorm, regroup-and-store tail and exchange word) or 1 (round 5: the batch-1 latency case itself;
+// the LDS tile then holds scalars instead of row quads).  Per row
 // the arithmetic and the order of every sum are the same in all instantiations, so a row's latents do not depend on which one
 // produced them.
 constexpr int XQ = TC / 3;                     // quads per row of a 768-wide buffer
@@ -80,21 +81,24 @@ struct Geo {
     static constexpr int XCH_QUADS = RS_OFF + TG * TG * RS_Q;
     static constexpr int RED = NR <= 8 ? 6144 : 12288;      // floats of the `red` scratch (>= 768 NR; >= the KV capacity: attention scores)
 };
-static_assert(2 * Geo<16>::XCH_QUADS == GPT_TOKEN_XCH_WORDS && Geo<8>::XCH_QUADS < Geo<16>::XCH_QUADS && Geo<4>::XCH_QUADS < Geo<8>::XCH_QUADS, "exchange arena size");
+static_assert(2 * Geo<16>::XCH_QUADS == GPT_TOKEN_XCH_WORDS && Geo<8>::XCH_QUADS < Geo<16>::XCH_QUADS && Geo<4>::XCH_QUADS < Geo<8>::XCH_QUADS && Geo<1>::XCH_QUADS < Geo<4>::XCH_QUADS, "exchange arena size");
 
 template <int NR>
 struct SmemT {
-    float4 xs[NR / 4][KP];       // activation tile [row quad][k]: rows 4 q .. 4 q + 3 of input k   (P2: the PV partials)
-    float red[Geo<NR>::RED];     // k-lane partials of a column GEMV | gathered mlp partials | attention scores
-    float qkv[3][TD];
-    float hs[NF][NR];            // gelu(c_fc) of this workgroup's 24 columns, [column][row]
+    static constexpr int RV = NR >= 4 ? 4 : NR;                    // rows per tile element (a float4 of 4 rows; NR = 1: a scalar)
+    alignas(16) float xs[NR / RV][KP][RV];                         // activation tile [row quad][k][row]: rows 4 q .. 4 q + 3 of input k   (NR >= 4, P2: the PV partials)
+    alignas(16) float pvbuf[NR >= 4 ? 4 : 64 * TD];                // NR = 1: the PV partials' own buffer (the scalar tile is too small to alias)
+    alignas(16) float red[Geo<NR>::RED];     // k-lane partials of a column GEMV | gathered mlp partials | attention scores
+    alignas(16) float qkv[3][TD];
+    alignas(16) float hs[NF][NR];   // gelu(c_fc) of this workgroup's 24 columns, [column][row]
     float own_x[Geo<NR>::RS_PER], own_y[Geo<NR>::RS_PER];      // residual rows of the 6 columns this workgroup owns
-    float st1[NR][4], st2[NR][4];  // LayerNorm: per-row wave partials
+    alignas(16) float st1[NR][4];  // LayerNorm: per-row wave partials
+    alignas(16) float st2[NR][4];
     float part[4][Geo<NR>::RS_PER];
-    float oq[NR * NF];           // a phase's outputs, regrouped into triples before they are stored
+    float oq[NR * NF < 64 ? 64 : NR * NF];      // a phase's outputs, regrouped into triples before they are stored (>= 48: the attention's output row)
     float mred[4], lred[4];
 };
-static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials alias the activation tile");
+static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * KP, "PV partials alias the activation tile (NR >= 4)");
 // CU sharing.  Built with packed fp32 math (`v_pk_fma_f32`, the SLP vectoriser's default), token workgroups that shared a CU with the
 // diffusion trunk's split-precision conv / attention workgroups (stage B of the previous request under SynthesizerTrn.infer_stream)
 // gave WRONG results - deterministic alone, a few accumulators of some workgroups off by percents under that load, sampled codes
@@ -107,7 +111,7 @@ static_assert(sizeof(float) * 64 * TD <= sizeof(float4) * 2 * KP, "PV partials a
 // (option "gpt_token_exclusive_cu" / DTTS_GPT_TOKEN_EXCLUSIVE_CU, see DESIGN.md for the measured choice); the stress tests run both
 // settings next to LDS kernels, zero-LDS kernels and the vocoder (tests/test_gpu_e2e.py::test_token_kernel_under_concurrent_*).
 constexpr int LDS_EXCLUSIVE = 160 * 1024;
-static_assert(sizeof(SmemT<4>) <= 64 * 1024 && sizeof(SmemT<8>) <= 64 * 1024 && sizeof(SmemT<16>) <= 128 * 1024, "LDS");
+static_assert(sizeof(SmemT<1>) <= 64 * 1024 && sizeof(SmemT<4>) <= 64 * 1024 && sizeof(SmemT<8>) <= 64 * 1024 && sizeof(SmemT<16>) <= 128 * 1024, "LDS");
 
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
@@ -224,10 +228,15 @@ __device__ __forceinline__ void wave_row_sums(const float (&s)[NR], float (*st)[
             const float w = wsum8(s8, lane);
             if ((lane & 7) == 0) st[8 * h + ((lane >> 3) & 7)][wave] = w;
         }
-    } else {
-        static_assert(NR == 4, "row sums");
+    } else if constexpr (NR == 4) {
         const float w = wsum4(s, lane);
         if ((lane & 15) == 0) st[(lane >> 4) & 3][wave] = w;
+    } else {
+        static_assert(NR == 1, "row sums");
+        float w = s[0];                                          // the plain butterfly in the same order of levels: the same tree
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+        if (lane == 0) st[0][wave] = w;
     }
 }
 
@@ -279,8 +288,13 @@ __device__ __forceinline__ void rows_to_tile(const float (&v)[NR][3], SmemT<NR>&
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const int k = 3 * tid + m;
+        if constexpr (NR >= 4) {
 #pragma unroll
-        for (int q = 0; q < NR / 4; ++q) sm.xs[q][k] = make_float4(v[4 * q][m], v[4 * q + 1][m], v[4 * q + 2][m], v[4 * q + 3][m]);
+            for (int q = 0; q < NR / 4; ++q)
+                *reinterpret_cast<float4*>(sm.xs[q][k]) = make_float4(v[4 * q][m], v[4 * q + 1][m], v[4 * q + 2][m], v[4 * q + 3][m]);
+        } else {
+            sm.xs[0][k][0] = v[0][m];
+        }
     }
 }
 
@@ -316,19 +330,27 @@ __device__ __forceinline__ void col_gemv(const float4 (&wr)[KT / 2], SmemT<NR>& 
     for (int i = 0; i < KT / 2; ++i) {
         const int k0 = kl + KL * 2 * i, k1 = k0 + KL;
         const float4 w = wr[i];
+        if constexpr (NR >= 4) {
 #pragma unroll
-        for (int rq = 0; rq < NR / 4; ++rq) {
-            const float4 xa = sm.xs[rq][k0], ya = sm.xs[rq][k1];
-            const float x[4] = {xa.x, xa.y, xa.z, xa.w};
-            const float y[4] = {ya.x, ya.y, ya.z, ya.w};
+            for (int rq = 0; rq < NR / 4; ++rq) {
+                const float4 xa = *reinterpret_cast<const float4*>(sm.xs[rq][k0]), ya = *reinterpret_cast<const float4*>(sm.xs[rq][k1]);
+                const float x[4] = {xa.x, xa.y, xa.z, xa.w};
+                const float y[4] = {ya.x, ya.y, ya.z, ya.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int b = 4 * rq + e;
-                acc[b][0] += x[e] * w.x;
-                acc[b][1] += x[e] * w.y;
-                acc[b][0] += y[e] * w.z;
-                acc[b][1] += y[e] * w.w;
+                for (int e = 0; e < 4; ++e) {
+                    const int b = 4 * rq + e;
+                    acc[b][0] += x[e] * w.x;
+                    acc[b][1] += x[e] * w.y;
+                    acc[b][0] += y[e] * w.z;
+                    acc[b][1] += y[e] * w.w;
+                }
             }
+        } else {                                                 // one row: the same four FMAs per weight word, in the same order
+            const float x = sm.xs[0][k0][0], y = sm.xs[0][k1][0];
+            acc[0][0] += x * w.x;
+            acc[0][1] += x * w.y;
+            acc[0][0] += y * w.z;
+            acc[0][1] += y * w.w;
         }
     }
     if (kl < KL) {
@@ -383,7 +405,9 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
 
     for (int k = TC + tid_k; k < KP; k += 256) {
 #pragma unroll
-        for (int q = 0; q < NR / 4; ++q) sm.xs[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NR / Smem::RV; ++q)
+#pragma unroll
+            for (int e = 0; e < Smem::RV; ++e) sm.xs[q][k][e] = 0.f;
     }
     // this workgroup's attention work items: head w / 8, rows w % 8 (+ 8 for a 16-row session: two items, one after the other)
     const int ah = w >> 3;
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
                     for (int c = 0; c < 12; ++c) acc[c] += pr * src[c];
                 }
             }
-            float* pv = reinterpret_cast<float*>(&sm.xs[0][0]) + slot * TD + cg * 12;
+            float* pv = (NR >= 4 ? &sm.xs[0][0][0] : sm.pvbuf) + slot * TD + cg * 12;
 #pragma unroll
             for (int e = 0; e < 3; ++e) *reinterpret_cast<float4*>(pv + e * 4) = make_float4(acc[e * 4], acc[e * 4 + 1], acc[e * 4 + 2], acc[e * 4 + 3]);
         }
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         if (tid < TD) {
             float o = 0.f;
             if (arow) {
-                const float* pv = reinterpret_cast<const float*>(&sm.xs[0][0]) + tid;
+                const float* pv = (NR >= 4 ? &sm.xs[0][0][0] : sm.pvbuf) + tid;
                 float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 4
                 for (int q = 0; q < 64; q += 4) {
@@ -669,17 +693,24 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             for (int b = 0; b < NR; ++b) acc[b][0] = acc[b][1] = acc[b][2] = 0.f;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
+                if constexpr (NR >= 4) {
 #pragma unroll
-                for (int rq4 = 0; rq4 < NR / 4; ++rq4) {
-                    const float4 ha = *reinterpret_cast<const float4*>(&sm.hs[j][4 * rq4]);
-                    const float h[4] = {ha.x, ha.y, ha.z, ha.w};
+                    for (int rq4 = 0; rq4 < NR / 4; ++rq4) {
+                        const float4 ha = *reinterpret_cast<const float4*>(&sm.hs[j][4 * rq4]);
+                        const float h[4] = {ha.x, ha.y, ha.z, ha.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int b = 4 * rq4 + e;
-                        acc[b][0] += h[e] * w2[j][0];
-                        acc[b][1] += h[e] * w2[j][1];
-                        acc[b][2] += h[e] * w2[j][2];
+                        for (int e = 0; e < 4; ++e) {
+                            const int b = 4 * rq4 + e;
+                            acc[b][0] += h[e] * w2[j][0];
+                            acc[b][1] += h[e] * w2[j][1];
+                            acc[b][2] += h[e] * w2[j][2];
+                        }
                     }
+                } else {
+                    const float h = sm.hs[j][0];
+                    acc[0][0] += h * w2[j][0];
+                    acc[0][1] += h * w2[j][1];
+                    acc[0][2] += h * w2[j][2];
                 }
             }
             STAMP(15);
@@ -689,10 +720,15 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             {
                 float* st = sm.red + 3 * NR * tid;             // columns 3 tid .. 3 tid + 2, NR rows each
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+                for (int m = 0; m < 3; ++m) {
+                    if constexpr (NR >= 4) {
 #pragma unroll
-                    for (int rq4 = 0; rq4 < NR / 4; ++rq4)
-                        *reinterpret_cast<float4*>(st + NR * m + 4 * rq4) = make_float4(acc[4 * rq4][m], acc[4 * rq4 + 1][m], acc[4 * rq4 + 2][m], acc[4 * rq4 + 3][m]);
+                        for (int rq4 = 0; rq4 < NR / 4; ++rq4)
+                            *reinterpret_cast<float4*>(st + NR * m + 4 * rq4) = make_float4(acc[4 * rq4][m], acc[4 * rq4 + 1][m], acc[4 * rq4 + 2][m], acc[4 * rq4 + 3][m]);
+                    } else {
+                        st[m] = acc[0][m];
+                    }
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -826,8 +862,9 @@ bool gpt_token_supported(int C, int H, int F, int NL, int V) { return C == TC &&
 // into SPIN_LIMIT.  false -> the caller keeps the launch-per-GEMV chain.
 bool gpt_token_prepare() {
     if (!device_fits(TG, LDS_EXCLUSIVE)) return false;
-    int nb4 = 0, nb8 = 0, nb16 = 0;
+    int nb1 = 0, nb4 = 0, nb8 = 0, nb16 = 0;
     try {
+        lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<1>), LDS_EXCLUSIVE);
         lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<4>), LDS_EXCLUSIVE);
         lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<8>), LDS_EXCLUSIVE);
         lds_optin(reinterpret_cast<const void*>(gpt_token_kernel<16>), LDS_EXCLUSIVE);
@@ -835,13 +872,14 @@ bool gpt_token_prepare() {
         (void)hipGetLastError();
         return false;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(gpt_token_kernel<4>), 256, LDS_EXCLUSIVE) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(gpt_token_kernel<1>), 256, LDS_EXCLUSIVE) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(gpt_token_kernel<4>), 256, LDS_EXCLUSIVE) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, reinterpret_cast<const void*>(gpt_token_kernel<8>), 256, LDS_EXCLUSIVE) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, reinterpret_cast<const void*>(gpt_token_kernel<16>), 256, LDS_EXCLUSIVE) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    return nb4 >= 1 && nb8 >= 1 && nb16 >= 1;
+    return nb1 >= 1 && nb4 >= 1 && nb8 >= 1 && nb16 >= 1;
 }
 
 size_t gpt_token_pack_floats(int which) {
@@ -867,8 +905,9 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.B >= 1 && p.B <= GPT_TOKEN_ROWS && p.NL >= 1 && p.NL <= GPT_TOKEN_MAX_LAYERS && p.Vs == GPT_TOKEN_VS, "persistent decode token: shape");
     DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
     const bool r16 = p.B > 8;                                                          // 9 .. 16 rows: the 16-row instantiation
-    const bool r4 = p.B <= 4 && p.min_rows <= 4;                                       // 1 .. 4 rows: the 4-row one (option gpt_token_min_rows = 8: off)
-    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)(r16 ? sizeof(SmemT<16>) : r4 ? sizeof(SmemT<4>) : sizeof(SmemT<8>));   // the attribute was raised by gpt_token_prepare (bind time)
+    const bool r1 = p.B == 1 && p.min_rows <= 1;                                       // one row: its own instantiation (option gpt_token_min_rows = 4 / 8: off)
+    const bool r4 = !r1 && p.B <= 4 && p.min_rows <= 4;                                // 1 .. 4 rows: the 4-row one (option gpt_token_min_rows = 8: off)
+    const int lds_request = p.exclusive_cu ? LDS_EXCLUSIVE : (int)(r16 ? sizeof(SmemT<16>) : r1 ? sizeof(SmemT<1>) : r4 ? sizeof(SmemT<4>) : sizeof(SmemT<8>));   // the attribute was raised by gpt_token_prepare (bind time)
     // DTTS_GPT_TOKEN_TRACE = n: the n-th launch records wall-clock stamps of workgroups 0 and 37 at every exchange and prints them
     static const int trace_at = []() { const char* v = getenv("DTTS_GPT_TOKEN_TRACE"); return v ? atoi(v) : 0; }();
     static int launches = 0;
@@ -882,6 +921,7 @@ void launch_gpt_token(const GptTokenParams& p, hipStream_t s) {
         q.trace = d_trace;
     }
     if (r16) hipLaunchKernelGGL(gpt_token_kernel<16>, dim3(TG), dim3(256), lds_request, s, q);
+    else if (r1) hipLaunchKernelGGL(gpt_token_kernel<1>, dim3(TG), dim3(256), lds_request, s, q);
     else if (r4) hipLaunchKernelGGL(gpt_token_kernel<4>, dim3(TG), dim3(256), lds_request, s, q);
     else hipLaunchKernelGGL(gpt_token_kernel<8>, dim3(TG), dim3(256), lds_request, s, q);
     DTTS_CHECK_HIP(hipGetLastError());

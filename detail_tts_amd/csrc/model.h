@@ -208,7 +208,7 @@ public:
         else if (key == "x3_range_check") opt_range_check_ = value != 0;
         else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; if (value != 0) tok_failed_ = false; gpt_drop_graphs(); }
         else if (key == "gpt_token_exclusive_cu") { opt_tok_exclusive_ = value != 0; gpt_drop_graphs(); }
-        else if (key == "gpt_token_min_rows") { DTTS_REQUIRE(value == 4 || value == 8, "gpt_token_min_rows: 4 or 8"); opt_tok_min_rows_ = value; gpt_drop_graphs(); }
+        else if (key == "gpt_token_min_rows") { DTTS_REQUIRE(value == 1 || value == 4 || value == 8, "gpt_token_min_rows: 1, 4 or 8"); opt_tok_min_rows_ = value; gpt_drop_graphs(); }
         else if (key == "gpt_token_fault") opt_tok_fault_ = value;       // test hook: the n-th token launch from now on times out
         else if (key == "gpt_token_fault_eos") opt_tok_fault_eos_ = value;   // ... and leaves every row flagged finished (a spurious stop token)
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
@@ -335,7 +335,7 @@ private:
     bool tok_ok_ = false;                 // the model has the shape the token kernel is written for
     bool opt_gpt_token_ = true;           // option "gpt_token_kernel"
     bool opt_tok_exclusive_ = true;       // option "gpt_token_exclusive_cu": the token kernel asks for whole CUs
-    int opt_tok_min_rows_ = 4;            // option "gpt_token_min_rows": sessions of <= 4 rows take the 4-row token kernel (8: the 8-row one)
+    int opt_tok_min_rows_ = 1;            // option "gpt_token_min_rows": 1-row sessions take the 1-row token kernel, <= 4 rows the 4-row one (4 / 8: the smallest instantiation allowed)
     bool tok_failed_ = false;             // an exchange timed out once: this handle stays on the chain (until the option is set again)
     int opt_tok_fault_ = 0;               // option "gpt_token_fault"
     int opt_tok_fault_eos_ = 0;           // option "gpt_token_fault_eos"

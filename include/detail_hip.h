@@ -258,8 +258,9 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *   "gpt_token_exclusive_cu" (default 1): the token kernel asks for a CU's whole LDS, so no LDS-using workgroup shares its CUs;
  *                 0 = it shares CUs with whatever else runs.  A scheduling policy, not a correctness requirement (both settings are
  *                 stress-tested bit-identical under stage B / C loads); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
- *   "gpt_token_min_rows" (default 4): sessions of <= 4 rows run the 4-row instantiation of the token kernel (round 5: the batch-1
- *                 latency case; per row bit-identical to the 8-row one); 8 = they run the 8-row kernel; env DTTS_GPT_TOKEN_MIN_ROWS;
+ *   "gpt_token_min_rows" (default 1): the smallest instantiation of the token kernel a session may take: 1-row sessions run the
+ *                 1-row kernel, sessions of <= 4 rows the 4-row one (round 5: the batch-1 latency case; per row bit-identical to the
+ *                 8-row one); 4 / 8 = the smallest allowed is the 4- / 8-row kernel; env DTTS_GPT_TOKEN_MIN_ROWS;
  *   "gpt_token_fault" (test hook, default 0): n > 0 makes the n-th token-kernel launch from now on behave like an exchange time-out;
  *   "gpt_token_fault_eos" (test hook, default 0): 1 = that fault also leaves every row flagged finished (a spurious stop token);
  *   "gn_fuse" (default 0): 1 = every GroupNorm + activation + split of the diffusion trunk (T <= 1152) runs in the epilogue of the conv

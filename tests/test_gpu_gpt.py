@@ -218,8 +218,9 @@ def test_token_kernel_equals_the_launch_per_gemv_chain(rt):
     assert np.array_equal(c2[0], c3[0]) and np.array_equal(c2[1], c3[1])
 
 
-def test_four_row_token_kernel_equals_the_eight_row_token_kernel_bit_for_bit(rt):
-    """Round 5: sessions of <= 4 rows (the batch-1 latency case) run a 4-row instantiation of the persistent token kernel.  Per row its
+def test_one_and_four_row_token_kernels_equal_the_eight_row_token_kernel_bit_for_bit(rt):
+    """Round 5: sessions of <= 4 rows run a 4-row instantiation of the persistent token kernel, 1-row sessions (the batch-1 latency
+    case) a 1-row one.  Per row their
     arithmetic and every summation order are the 8-row kernel's (LayerNorm statistics by the same butterfly tree), so codes AND latents
     are bit-identical to the same session on the 8-row kernel (option gpt_token_min_rows = 8); B = 1, 3, 4; free sampling with the stop
     token allowed, and a teacher-forced session past 384 / 512 keys (the V / K rounds beyond the register-resident ones)."""
@@ -231,15 +232,16 @@ def test_four_row_token_kernel_equals_the_eight_row_token_kernel_bit_for_bit(rt)
         args = (dev(refer), rl, texts, 31 + B, list(range(40, 40 + B)))
         out4 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
         e4 = rt.gpt_generate(*args, max_generate_length=12)
-        rt.set_option("gpt_token_min_rows", 8)
-        try:
-            out8 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
-            e8 = rt.gpt_generate(*args, max_generate_length=12)
-        finally:
-            rt.set_option("gpt_token_min_rows", 4)
-        assert np.array_equal(out4[0], out8[0]) and np.array_equal(out4[1], out8[1]), B
-        assert torch.equal(out4[2], out8[2]), B
-        assert np.array_equal(e4[0], e8[0]) and np.array_equal(e4[1], e8[1]), B
+        for rows in (8, 4):                      # B = 1: the default is the 1-row kernel, compared with the 4-row and the 8-row one
+            rt.set_option("gpt_token_min_rows", rows)
+            try:
+                out8 = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+                e8 = rt.gpt_generate(*args, max_generate_length=12)
+            finally:
+                rt.set_option("gpt_token_min_rows", 1)
+            assert np.array_equal(out4[0], out8[0]) and np.array_equal(out4[1], out8[1]), (B, rows)
+            assert torch.equal(out4[2], out8[2]), (B, rows)
+            assert np.array_equal(e4[0], e8[0]) and np.array_equal(e4[1], e8[1]), (B, rows)
     B, G = 2, 160
     refer = (rs.randn(B, 128, 150) * 2 - 5).astype(np.float32)
     texts = [np.concatenate([rs.randint(3, 255, 400 - 30 * b), [0]]).astype(np.int32) for b in range(B)]
@@ -250,8 +252,17 @@ def test_four_row_token_kernel_equals_the_eight_row_token_kernel_bit_for_bit(rt)
     try:
         l8 = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2].clone()
     finally:
-        rt.set_option("gpt_token_min_rows", 4)
+        rt.set_option("gpt_token_min_rows", 1)
     assert torch.equal(l4, l8)
+    # ... and the 1-row kernel on a long session
+    args1 = (dev(refer[:1]), None, texts[:1], 9, [3])
+    l1 = rt.gpt_generate(*args1, max_generate_length=G + 1, forced_codes=forced[:1])[2].clone()
+    rt.set_option("gpt_token_min_rows", 8)
+    try:
+        l1_8 = rt.gpt_generate(*args1, max_generate_length=G + 1, forced_codes=forced[:1])[2].clone()
+    finally:
+        rt.set_option("gpt_token_min_rows", 1)
+    assert torch.equal(l1, l1_8)
 
 
 def test_token_kernel_long_session_equals_the_chain(rt):
