@@ -234,7 +234,7 @@ void launch_conv_tile(const ConvParams& p, hipStream_t stream, const char* tag);
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
             lds_attr = 160 * 1024;                                                                                        \
         }                                                                                                                 \
-        constexpr bool FASTPATH = (FAST) && EPI == 0 && PRO <= 2;                                                         \
+        constexpr bool FASTPATH = (FAST) && EPI <= (BM == 64 && BN == 64 ? 1 : 0) && PRO <= 2;   /* the small-launch tile also takes its activation epilogue (GPT c_fc) on the compile-time-tap path */                                                         \
         if (FASTPATH && p.stride == 1 && p.dil == 1 && p.KW == 1 && lds <= 64 * 1024)                                    \
             hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, PRO, EPI, FASTPATH ? 1 : 0>), grid, dim3(256), lds, stream, p); \
         else if (FASTPATH && p.stride == 1 && p.dil == 1 && p.KW == 3 && lds <= 64 * 1024)                               \
