@@ -343,9 +343,10 @@ def _load_zero_lds(rt):
     return go
 
 
+@pytest.mark.parametrize("rows", [8, 3, 1])          # the 8-row (headline), 4-row and 1-row instantiations of the token kernel
 @pytest.mark.parametrize("exclusive", [1, 0])
 @pytest.mark.parametrize("load", ["diffusion", "vocoder", "zero_lds"])
-def test_token_kernel_under_concurrent_load(model, load, exclusive):
+def test_token_kernel_under_concurrent_load(model, load, exclusive, rows):
     """Stage A's persistent token kernel runs under the previous request's stages B and C in SynthesizerTrn.infer_stream.  200 decode
     sessions repeated while another host thread keeps that load running on its own stream must give the same codes and latents bit
     for bit - with the token workgroups on CUs of their own (exclusive = 1) AND sharing CUs with the load (exclusive = 0: the round-3
@@ -353,7 +354,7 @@ def test_token_kernel_under_concurrent_load(model, load, exclusive):
     import threading
     import time
     rt = model.rt
-    gen = _token_session(rt)
+    gen = _token_session(rt, B=rows)
     rt.set_option("gpt_token_exclusive_cu", exclusive)
     try:
         c0, l0 = gen()
@@ -382,7 +383,7 @@ def test_token_kernel_under_concurrent_load(model, load, exclusive):
             for _ in range(200):
                 c1, l1 = gen()
                 bad += not (np.array_equal(c0, c1) and torch.equal(l0, l1))
-            assert bad == 0, f"{bad} of 200 sessions differ under the {load} load (exclusive_cu={exclusive})"
+            assert bad == 0, f"{bad} of 200 {rows}-row sessions differ under the {load} load (exclusive_cu={exclusive})"
         finally:
             stop.set()
             th.join()
