@@ -215,6 +215,7 @@ public:
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
+        else if (key == "integ_pipeline") opt_integ_pipeline_ = value;      // -1: by batch size (on up to batch 4), 0 / 1
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -295,8 +296,9 @@ private:
                            int T, int step, float* out2, hipStream_t s, const float* integ = nullptr);
     // The integrator sees (code embedding | unconditioned embedding, timestep) only - never x_t - so its output for every sampling
     // step is known before the loop starts: steps are evaluated J at a time as one batch of J*(B+Nu) samples, each at its own step.
+    // ready != null: only the first chunk runs on s, the later ones on si_; (first step, event) per later chunk is appended to *ready
     void precompute_integrator(const float* cbuf0, const int* lens_i_host, int B, int Nu, int T, const std::vector<int>& steps,
-                               float* integ_all, hipStream_t s);
+                               float* integ_all, hipStream_t s, std::vector<std::pair<int, hipEvent_t>>* ready = nullptr);
     struct PairPlan { const int *lens2, *lens_i, *umap; int Nu; std::vector<int> ulen; };
     PairPlan plan_pair(const int* lens_host, int B, int T, hipStream_t s);
 
@@ -398,6 +400,9 @@ private:
     static constexpr int MAX_CFG_STREAMS = 4;
     hipStream_t sx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};   // extra streams of the diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_joinx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};
+    int opt_integ_pipeline_ = -1;         // option "integ_pipeline": the integrator's later step chunks under the first sampling steps
+    hipStream_t si_ = nullptr;            // their low-priority stream
+    std::vector<hipEvent_t> ev_integ_;    // one per chunk
 
     // prompt front-end
     bool has_frontend_ = false;

@@ -70,8 +70,9 @@ Model::~Model() {
         if (r.pinned) (void)hipHostFree(r.pinned);
         if (r.ev) (void)hipEventDestroy(r.ev);
     }
-    for (hipStream_t st : {sx_[0], sx_[1], sx_[2], sg_})
+    for (hipStream_t st : {sx_[0], sx_[1], sx_[2], sg_, si_})
         if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : ev_integ_) (void)hipEventDestroy(e);
     for (hipEvent_t e : {ev_fork_, ev_joinx_[0], ev_joinx_[1], ev_joinx_[2], ev_g0_, ev_g1_})
         if (e) (void)hipEventDestroy(e);
 }
@@ -925,14 +926,43 @@ static int integ_chunk(int Bi) {     // steps per batched evaluation (~36 sample
 }
 
 void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, int B, int Nu, int T, const std::vector<int>& steps,
-                                  float* integ_all, hipStream_t s) {
+                                  float* integ_all, hipStream_t s, std::vector<std::pair<int, hipEvent_t>>* ready) {
     const int C = cfg.diff_channels, Bi = B + Nu, J = integ_chunk(Bi), NS = (int)steps.size();
     const size_t ct = (size_t)C * T, mark = ws().mark();
     const int Bv = J * Bi;
     const bool x3 = use_x3();
     static const bool env_two = []() { const char* v = getenv("DTTS_TWO_STREAMS"); return !(v && v[0] == '0'); }();
-    const bool two = env_two && opt_two_streams_;
-    if (two && !sx_[0]) make_side_stream(&sx_[0]);
+    // `ready` (the latency regime: diff_sample asks for it when the sampling loop is one launch sequence that cannot fill the chip):
+    // only the FIRST chunk of steps is evaluated on s; the later ones go to the low-priority stream si_ and run UNDER the loop's first
+    // steps, which wait for a chunk's event when they reach its first step.  Same launches on the same inputs: same values.  The
+    // scratch then stays carved until the caller rewinds (after the loop).
+    const bool piped = ready != nullptr && NS > J;
+    const bool two = (env_two && opt_two_streams_) || piped;
+    if (piped) {
+        if (!si_) {
+            // The chunks are chip-filling launches (36 samples): next to them every launch of the loop queues for CU slots, so the
+            // overlap returns 1 ms of the ~10 the chunks take (batch 1: 124.6 -> 123.7 ms, profiles/r05_integ_pipeline_ab.txt).
+            // Confining the chunks to DTTS_INTEG_CUS CUs (the mask's low bits) was measured and is OFF: 32 / 64 / 128 CUs gave 167 / 148 /
+            // 139 ms - a masked queue runs these launches far slower than its share of the chip.  Default: a low-priority stream.
+            static const int cus = []() { const char* v = getenv("DTTS_INTEG_CUS"); return v ? atoi(v) : 0; }();
+            if (cus > 0 && cus < 256) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+                DTTS_CHECK_HIP(hipExtStreamCreateWithCUMask(&si_, 8, mask));
+            } else {
+                int least = 0, greatest = 0;
+                DTTS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                DTTS_CHECK_HIP(hipStreamCreateWithPriority(&si_, hipStreamNonBlocking, least));
+            }
+        }
+        while ((int)ev_integ_.size() < cdiv(NS, J)) {
+            hipEvent_t e;
+            DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev_integ_.push_back(e);
+        }
+    }
+    hipStream_t side = piped ? si_ : sx_[0];
+    if (two && !piped && !sx_[0]) { make_side_stream(&sx_[0]); side = sx_[0]; }
     if (two && !ev_fork_) {
         DTTS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         for (auto& e : ev_joinx_) DTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -944,7 +974,7 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     struct Lane { hipStream_t st; float *bufA, *bufB, *bufC, *qkv, *ab; void* xs; };
     Lane lanes[2];
     for (int q = 0; q < (two ? 2 : 1); ++q) {
-        lanes[q].st = q ? sx_[0] : s;
+        lanes[q].st = q ? side : s;
         lanes[q].bufB = ws().f32((size_t)Bv * ct);
         lanes[q].bufC = ws().f32((size_t)Bv * ct);
         lanes[q].bufA = ws().f32((size_t)Bv * ct);
@@ -954,12 +984,12 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     }
     if (two) {
         DTTS_CHECK_HIP(hipEventRecord(ev_fork_, s));
-        DTTS_CHECK_HIP(hipStreamWaitEvent(sx_[0], ev_fork_, 0));
+        DTTS_CHECK_HIP(hipStreamWaitEvent(side, ev_fork_, 0));
     }
     std::vector<int> lv(Bv), sv(Bv);
     int ci = 0;
     for (int k0 = 0; k0 < NS; k0 += J, ++ci) {
-        const Lane& L = lanes[two ? (ci & 1) : 0];
+        const Lane& L = lanes[piped ? (ci ? 1 : 0) : (two ? (ci & 1) : 0)];
         Profiler::gate() = ((ci / 2) % Profiler::get().step_every) == 0;      // both lanes of a chunk pair, or neither
         const int jn = std::min(J, NS - k0), nb = jn * Bi;
         for (int j = 0; j < jn; ++j)
@@ -979,12 +1009,17 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
         dlayer(integ_[1], L.bufA, L.bufA);
         dlayer(integ_[2], L.bufA, outp);
         register_cols(dl, nullptr, 0, T, L.st);                        // enqueued: forget this chunk's table
+        if (piped && ci) {
+            DTTS_CHECK_HIP(hipEventRecord(ev_integ_[ci], si_));
+            ready->emplace_back(k0, ev_integ_[ci]);
+        }
     }
+    Profiler::gate() = true;
+    if (piped) return;                                                 // the caller's loop waits per chunk and rewinds
     if (two) {
         DTTS_CHECK_HIP(hipEventRecord(ev_joinx_[0], sx_[0]));
         DTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_joinx_[0], 0));
     }
-    Profiler::gate() = true;
     ws().rewind(mark);
 }
 
@@ -1066,19 +1101,28 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     }
     float* integ_all = nullptr;
     const int Bi = B + pl.Nu;
+    // option "integ_pipeline" (DTTS_INTEG_PIPELINE overrides; default: on up to batch 4, where a forward is ONE launch sequence in the
+    // latency regime): the integrator's later step chunks run under the first sampling steps instead of in front of the loop
+    static const int env_pipe = []() { const char* v = getenv("DTTS_INTEG_PIPELINE"); return v ? atoi(v) : -1; }();
+    const int pipe_opt = env_pipe >= 0 ? env_pipe : opt_integ_pipeline_;
+    const bool pipe = pipe_opt < 0 ? B <= 4 : pipe_opt != 0;
+    std::vector<std::pair<int, hipEvent_t>> ready;
     if (env_pre) {
         std::vector<int> steps(n_steps), li(Bi);
         for (int k = 0; k < n_steps; ++k) steps[k] = n_steps_ - 1 - k;
         for (int b = 0; b < B; ++b) li[b] = lens_host ? lens_host[b] : T;
         for (int u = 0; u < pl.Nu; ++u) li[B + u] = pl.ulen[u];
         integ_all = ws().f32((size_t)n_steps * Bi * C * T);
-        precompute_integrator(cbuf0, li.data(), B, pl.Nu, T, steps, integ_all, s);
+        precompute_integrator(cbuf0, li.data(), B, pl.Nu, T, steps, integ_all, s, pipe ? &ready : nullptr);
     }
     const size_t mark = ws().mark();
+    size_t next_ready = 0;
     for (int k = 0; k < n_steps; ++k) {
         const int i = n_steps_ - 1 - k;
         Profiler::gate() = (k % Profiler::get().step_every) == 0;
         ws().rewind(mark);                              // the forward's scratch is re-carved every step
+        if (next_ready < ready.size() && ready[next_ready].first == k)
+            DTTS_CHECK_HIP(hipStreamWaitEvent(s, ready[next_ready++].second, 0));
         diff_forward_pair(x, cbuf0, lens2, pl.lens_i, pl.umap, B, pl.Nu, T, i, out2, s,
                           integ_all ? integ_all + (size_t)k * Bi * C * T : nullptr);
         const bool last = (k == n_steps - 1);

@@ -253,6 +253,31 @@ def test_ragged_batch_launching_only_live_columns_is_bit_identical(rt, weights, 
     assert maxabs(outs[1][b, :, :lens[b]], alone[0]) < 1e-4
 
 
+@pytest.mark.parametrize("lens", [[333], [132, 77, 200]])
+def test_integrator_chunks_under_the_sampling_loop_are_bit_identical(rt, weights, lens):
+    """Option integ_pipeline (default: on up to batch 4): only the first chunk of the conditioning_timestep_integrator's step outputs
+    (vqvae/diff_model.py:295; it never sees x_t) is evaluated in front of the sampling loop, the later chunks run on a low-priority
+    stream under the first steps, which wait for a chunk's event at its first step.  Same launches on the same inputs: all 50 steps
+    (3 chunks at batch 1, 9 at a ragged batch of 3) must not change by one bit, also when the call is repeated (the chunks' scratch
+    is reused by the next call)."""
+    rs = np.random.RandomState(41)
+    B, T = len(lens), max(lens)
+    ce = dev(rs.randn(B, 768, T) * 0.5)
+    outs = {}
+    try:
+        for flag in (0, 1, 1):
+            rt.set_option("integ_pipeline", flag)
+            outs.setdefault(flag, []).append(host(rt.diff_sample(ce, 6, list(range(B)), lens=lens, n_steps=50, denorm=True)))
+    finally:
+        rt.set_option("integ_pipeline", -1)
+    dflt = host(rt.diff_sample(ce, 6, list(range(B)), lens=lens, n_steps=50, denorm=True))
+    for b, L in enumerate(lens):
+        ref = outs[0][0][b, :, :L]
+        assert np.isfinite(ref).all() and float(np.abs(ref).max()) > 0.1
+        for o in outs[1] + [dflt]:
+            assert np.array_equal(ref, o[b, :, :L]), b
+
+
 def test_errors_are_reported_not_crashes(rt):
     from detail_tts_amd.runtime import DttsError
     x = torch.zeros(1, 128, 8, device="cuda")
