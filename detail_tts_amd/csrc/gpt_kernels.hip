@@ -662,6 +662,7 @@ void launch_gather_last(const float* x, long long bs, int cs, const int* lens, i
 // HF GenerationMixin._sample logits processing + inverse-CDF multinomial of the Philox spec.
 constexpr int SAMP_THREADS = 1024;
 constexpr int SORT_MAX = 16384;
+static_assert(SAMP_THREADS == 4 * 256, "sampler: one thread per bin of the four radix histograms");
 
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned u = __float_as_uint(f);
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     float* skey = sv + Vpad;                            // [SORT_MAX]
     unsigned short* sidx = reinterpret_cast<unsigned short*>(skey + SORT_MAX);   // [SORT_MAX]
     __shared__ float red[SAMP_THREADS / 64];
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist4[4 * 256];                 // one histogram per radix pass, zeroed once: no barrier pair to recycle one
     __shared__ unsigned sh_u[4];
     __shared__ int sh_i[4];
 
@@ -729,8 +730,34 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
     } while (0)
     SSTAMP(0);
     GptCtl* ctl = p.ctl;
+    // Everything the kernel reads from memory that does not depend on the control block is requested FIRST: the token kernel's plain
+    // logits row (slices = 1, no bias: one load per score) and the seen flags go to registers while the control block's fields (a
+    // chain of dependent scalar loads) arrive; so do the fields the LAST phases need (the Philox stream, the finished flag, the next
+    // position embedding), which used to cost one memory round trip each behind a barrier.  Same values, same arithmetic.
+    constexpr int PF = 9;
+    const bool pf_on = p.slices == 1 && !p.bias && V <= PF * SAMP_THREADS;
+    float pf_x[PF];
+    unsigned char pf_seen[PF];
+    if (pf_on) {
+        const float* row = p.parts + (long long)b * p.Vs;
+        const unsigned char* seen0 = p.seen + (long long)b * V;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int v = tid + i * SAMP_THREADS;
+            pf_x[i] = v < V ? row[v] : 0.f;
+            pf_seen[i] = v < V ? seen0[v] : (unsigned char)0;
+        }
+    }
     const int step = ctl->step[b];
+    const float* const forced_u = ctl->forced_u;
+    const int u_stride = ctl->u_stride;
+    const unsigned long long seed_b = ctl->seed[b];
+    const int sample_id_b = ctl->sample_id[b];
+    const int fin_in = p.finished[b];
     if (step >= ctl->max_steps) return;                  // a replayed graph may run past the requested length: no-op
+    float pos_next = 0.f;                                 // mel_pos[step + 1][tid]: C <= SAMP_THREADS is the common case
+    const bool pos_pf = p.x_next && p.C <= SAMP_THREADS;
+    if (pos_pf && tid < p.C) pos_next = p.mel_pos[(long long)(step + 1) * p.C + tid];
     const int top_k = ctl->top_k;
     const float top_p = ctl->top_p;
     int token;
@@ -745,15 +772,41 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         const float rp = ctl->repetition_penalty, temp = ctl->temperature;
         const int eos_off = ctl->suppress_eos ? p.eos : -1;
         const bool typical = ctl->typical_mass > 0.f && ctl->typical_mass < 1.f;
+        // (the maximum of the processed scores rides along: top-k keeps it, so it is the softmax maximum of step 3 unless the typical
+        // warper - which may drop the most probable token - runs; a maximum does not depend on the order it is taken in)
+        float tmax = -INFINITY;
+        if (pf_on) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int v = tid + i * SAMP_THREADS;
+                if (v < V) {
+                    float x = 0.f;
+                    x += pf_x[i];
+                    if (v == eos_off) x = -INFINITY;
+                    if (pf_seen[i]) x = x < 0.f ? x * rp : x / rp;
+                    const float y = typical ? x : x / temp;
+                    sv[v] = y;
+                    tmax = fmaxf(tmax, y);
+                }
+            }
+        } else
 #pragma unroll 4
         for (int v = tid; v < V; v += SAMP_THREADS) {
             float x = p.bias ? p.bias[v] : 0.f;
             x += sum_parts(p.parts, p.slices, (long long)p.B * p.Vs, (long long)b * p.Vs + v);
             if (v == eos_off) x = -INFINITY;
             if (seen[v]) x = x < 0.f ? x * rp : x / rp;
-            sv[v] = typical ? x : x / temp;
+            const float y = typical ? x : x / temp;
+            sv[v] = y;
+            tmax = fmaxf(tmax, y);
         }
+        tmax = wmax(tmax);
+        if ((tid & 63) == 0) red[tid >> 6] = tmax;
+        hist4[tid] = 0;                                     // SAMP_THREADS == 4 * 256
+        if (tid == 0) sh_i[1] = 0;
         __syncthreads();
+        float mx_early = -INFINITY;
+        for (int i = 0; i < SAMP_THREADS / 64; ++i) mx_early = fmaxf(mx_early, red[i]);
         SSTAMP(1);
         // 1b. HF TypicalLogitsWarper (inference_speech_tortoise(typical_sampling=True), gpt/model.py:539; it sits between the repetition
         // penalty and the temperature): key = | -log p - H |, ascending sort of the whole vocabulary by it, keep the keys up to the
@@ -822,50 +875,64 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             unsigned prefix = 0, mask = 0;
             int krem = top_k;
             for (int pass = 3; pass >= 0; --pass) {
-                if (tid < 256) hist[tid] = 0;
-                __syncthreads();
+                unsigned* hist = hist4 + pass * 256;
                 const int sh = pass * 8;
+                // a thread's consecutive candidates in one bin are added at once (the top byte - sign and exponent - puts most of
+                // the vocabulary into two or three bins, and 64 lanes adding to one LDS address are served one after the other)
+                unsigned cur = 0, cnt = 0;
                 for (int v = tid; v < V; v += SAMP_THREADS) {
                     const unsigned k = f2ord(sv[v]);
-                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
+                    if ((k & mask) == prefix) {
+                        const unsigned bin = (k >> sh) & 255u;
+                        if (cnt && bin != cur) { atomicAdd(&hist[cur], cnt); cnt = 0; }
+                        cur = bin;
+                        ++cnt;
+                    }
                 }
+                if (cnt) atomicAdd(&hist[cur], cnt);
                 __syncthreads();
-                if (tid < 64) {
-                    // wave 0: lane l owns bins 255-4l .. 252-4l (descending); exclusive prefix of the counts above each lane's bins,
-                    // then the lane whose 4 bins cross `krem` walks them.  Exactly the serial top-down scan, in 6 shuffle steps.
-                    const int b0 = 255 - 4 * tid;
+                {
+                    // EVERY wave walks the histogram itself (no result to publish, no barrier pair): lane l owns bins 255-4l .. 252-4l
+                    // (descending); exclusive prefix of the counts above each lane's bins, then the lane whose 4 bins cross `krem`
+                    // walks them.  Exactly the serial top-down scan, in 6 shuffle steps.
+                    const int lane = tid & 63;
+                    const int b0 = 255 - 4 * lane;
                     const int c0 = (int)hist[b0], c1 = (int)hist[b0 - 1], c2 = (int)hist[b0 - 2], c3 = (int)hist[b0 - 3];
                     const int mine = c0 + c1 + c2 + c3;
                     int incl = mine;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) {
                         const int v = __shfl_up(incl, o);
-                        if (tid >= o) incl += v;
+                        if (lane >= o) incl += v;
                     }
                     const int excl = incl - mine;
                     const bool crosses = excl < krem && incl >= krem;
-                    // no lane crosses when the total is < krem: the serial scan then ends at bin 0 with acc = everything above it
+                    int bin_l = 0, rem_l = 0;
                     if (crosses) {
                         int acc = excl, bin = b0;
                         if (acc + c0 >= krem) bin = b0;
                         else if (acc + c0 + c1 >= krem) { acc += c0; bin = b0 - 1; }
                         else if (acc + c0 + c1 + c2 >= krem) { acc += c0 + c1; bin = b0 - 2; }
                         else { acc += c0 + c1 + c2; bin = b0 - 3; }
-                        if (bin == 0) acc = excl + (b0 == 3 ? c0 + c1 + c2 : (b0 == 2 ? c0 + c1 : (b0 == 1 ? c0 : 0)));
-                        sh_u[0] = (unsigned)bin;
-                        sh_i[0] = krem - acc;
+                        bin_l = bin;
+                        rem_l = krem - acc;
                     }
-                    const int total = __shfl(incl, 63);
-                    if (tid == 0 && total < krem) {
-                        sh_u[0] = 0u;
-                        sh_i[0] = krem - (total - (int)hist[0]);
+                    const unsigned long long who = __ballot(crosses);
+                    const int total = __shfl(incl, 63), h0 = __shfl(c3, 63);
+                    int bin, rem;
+                    if (who) {
+                        const int src = __ffsll((long long)who) - 1;
+                        bin = __shfl(bin_l, src);
+                        rem = __shfl(rem_l, src);
+                    } else {
+                        // no lane crosses when the total is < krem: the serial scan then ends at bin 0 with acc = everything above it
+                        bin = 0;
+                        rem = krem - (total - h0);
                     }
+                    prefix |= (unsigned)bin << sh;
+                    mask |= 255u << sh;
+                    krem = rem;
                 }
-                __syncthreads();
-                prefix |= sh_u[0] << sh;
-                mask |= 255u << sh;
-                krem = sh_i[0];
-                __syncthreads();
                 SSTAMP(5 - pass);
             }
             const float thr = ord2f(prefix);
@@ -875,14 +942,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             SSTAMP(6);
         }
         // 3. softmax statistics of the kept set
-        float mx = -INFINITY;
-        for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, sv[v]);
-        mx = block_reduce_max(mx, red);
+        float mx = mx_early;
+        if (typical) {
+            mx = -INFINITY;
+            for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, sv[v]);
+            mx = block_reduce_max(mx, red);
+        }
         SSTAMP(7);
         // 4. top-p (nucleus): ascending sort of the kept candidates, drop the tail whose cumulative prob <= 1 - top_p
         if (top_p < 1.0f) {
-            if (tid == 0) sh_i[1] = 0;
-            __syncthreads();
+            // (the slot counter sh_i[1] was cleared in front of the first barrier)
             for (int v = tid; v < V; v += SAMP_THREADS)
                 if (sv[v] > -INFINITY) {
                     const int slot = atomicAdd(&sh_i[1], 1);
@@ -893,13 +962,17 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             const int M = sh_i[1];
             int n2 = 64;
             while (n2 < M) n2 <<= 1;
-            for (int i = M + tid; i < n2; i += SAMP_THREADS) { skey[i] = INFINITY; sidx[i] = 0xffff; }
-            __syncthreads();
-            SSTAMP(8);
+            const float cut = 1.0f - top_p;
             if (n2 == 64) {
-                // top-k 50 leaves <= 64 candidates: one wave sorts them with no workgroup barriers (21 of them otherwise).  LDS
-                // operations of a wave complete in issue order; the wave barrier only pins the compiler's ordering.
+                // top-k 50 leaves <= 64 candidates: ONE WAVE pads, sorts, sums and cuts them with no workgroup barrier in between (21
+                // for the sort alone otherwise, 6 more for Z / the scan / the cut).  LDS operations of a wave complete in issue order;
+                // the wave barrier only pins the compiler's ordering.  The float operations are those of the general path below, in its
+                // order: Z = block_reduce_sum of one term per lane of wave 0 (the other waves add + 0.f), the scan = block_exclusive_scan
+                // with one element per thread (`base` = 0.f for wave 0).
                 if (tid < 64) {
+                    if (tid >= M) { skey[tid] = INFINITY; sidx[tid] = 0xffff; }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
                     for (int k = 2; k <= 64; k <<= 1)
                         for (int j = k >> 1; j > 0; j >>= 1) {
                             const int i = tid, ixj = i ^ j;
@@ -914,9 +987,29 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             __builtin_amdgcn_wave_barrier();
                         }
+                    float z = 0.f;
+                    if (tid < M) z += expf(skey[tid] - mx);
+                    z = 0.f + wsum(z);
+                    float loc = 0.f;
+                    if (tid < M) loc += expf(skey[tid] - mx) / z;
+                    float inc = loc;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const float t = __shfl_up(inc, o);
+                        if (tid >= o) inc += t;
+                    }
+                    float run = 0.f + inc - loc;
+                    if (tid < M) {
+                        run += expf(skey[tid] - mx) / z;
+                        if (run <= cut && tid != M - 1) sv[sidx[tid]] = -INFINITY;
+                    }
                 }
                 __syncthreads();
+                SSTAMP(11);
             } else {
+            for (int i = M + tid; i < n2; i += SAMP_THREADS) { skey[i] = INFINITY; sidx[i] = 0xffff; }
+            __syncthreads();
+            SSTAMP(8);
             for (int k = 2; k <= n2; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int i = tid; i < n2; i += SAMP_THREADS) {
@@ -932,7 +1025,6 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
                     }
                     __syncthreads();
                 }
-            }
             SSTAMP(9);
             // Z over the kept set, then inclusive cumulative prob in ascending order
             float z = 0.f;
@@ -945,13 +1037,13 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
             for (int i = i0; i < i0 + per && i < M; ++i) loc += expf(skey[i] - mx) / z;
             float tot;
             float run = block_exclusive_scan(loc, red, &tot);
-            const float cut = 1.0f - top_p;
             for (int i = i0; i < i0 + per && i < M; ++i) {
                 run += expf(skey[i] - mx) / z;
                 if (run <= cut && i != M - 1) sv[sidx[i]] = -INFINITY;
             }
             __syncthreads();
             SSTAMP(11);
+            }
         }
         // 5. inverse-CDF draw in vocabulary order
         const int per = (V + SAMP_THREADS - 1) / SAMP_THREADS;
@@ -962,10 +1054,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         float run = block_exclusive_scan(loc, red, &tot);
         SSTAMP(12);
         float u;
-        if (ctl->forced_u) u = ctl->forced_u[(long long)b * ctl->u_stride + step];
+        if (forced_u) u = forced_u[(long long)b * u_stride + step];
         else {
             float uu[4];
-            philox_uniform4(ctl->seed[b], (unsigned)ctl->sample_id[b], STAGE_GPT_SAMPLE, step, 0u, uu);
+            philox_uniform4(seed_b, (unsigned)sample_id_b, STAGE_GPT_SAMPLE, step, 0u, uu);
             u = uu[0];
         }
         const float target = u * tot;
@@ -984,7 +1076,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         token = sh_i[2] < V ? sh_i[2] : sh_i[3];
         SSTAMP(13);
     }
-    const bool fin = p.finished[b] != 0;
+    const bool fin = fin_in != 0;
     if (fin) token = p.eos;
     __syncthreads();
     if (tid == 0) {
@@ -994,7 +1086,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void sampler_kernel(const SamplerPara
         ctl->step[b] = step + 1;                 // only this workgroup reads or writes step[b] inside this launch
     }
     // next input embedding: mel_embedding[token] + mel_pos_embedding[step + 1]   (gpt/model.py:134-136 with position k)
-    if (p.x_next)
+    if (pos_pf) {
+        if (tid < p.C) p.x_next[(long long)b * p.C + tid] = p.mel_emb[(long long)token * p.C + tid] + pos_next;
+    } else if (p.x_next)
         for (int c = tid; c < p.C; c += SAMP_THREADS)
             p.x_next[(long long)b * p.C + c] = p.mel_emb[(long long)token * p.C + c] + p.mel_pos[(long long)(step + 1) * p.C + c];
     SSTAMP(14);
