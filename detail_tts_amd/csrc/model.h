@@ -215,7 +215,7 @@ public:
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
-        else if (key == "integ_pipeline") opt_integ_pipeline_ = value;      // -1: by batch size (on up to batch 4), 0 / 1
+        else if (key == "integ_pipeline") opt_integ_pipeline_ = value;      // 0 (default) / 1; -1: by batch size (on up to batch 4)
         else throw Error(-1, "unknown option '" + key + "'");
     }
     std::string last_error;
@@ -400,7 +400,7 @@ private:
     static constexpr int MAX_CFG_STREAMS = 4;
     hipStream_t sx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};   // extra streams of the diffusion forward
     hipEvent_t ev_fork_ = nullptr, ev_joinx_[MAX_CFG_STREAMS - 1] = {nullptr, nullptr, nullptr};
-    int opt_integ_pipeline_ = -1;         // option "integ_pipeline": the integrator's later step chunks under the first sampling steps
+    int opt_integ_pipeline_ = 0;          // option "integ_pipeline": the integrator's later step chunks under the first sampling steps (off: DESIGN.md par. 4.5)
     hipStream_t si_ = nullptr;            // their low-priority stream
     std::vector<hipEvent_t> ev_integ_;    // one per chunk
 

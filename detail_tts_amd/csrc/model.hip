@@ -950,9 +950,11 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
                 for (int b = 0; b < cus; ++b) mask[b >> 5] |= 1u << (b & 31);
                 DTTS_CHECK_HIP(hipExtStreamCreateWithCUMask(&si_, 8, mask));
             } else {
+                // DTTS_INTEG_PRIO=low: the lowest stream priority (measured: no different from the normal one)
+                static const bool low = []() { const char* v = getenv("DTTS_INTEG_PRIO"); return v && v[0] == 'l'; }();
                 int least = 0, greatest = 0;
                 DTTS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                DTTS_CHECK_HIP(hipStreamCreateWithPriority(&si_, hipStreamNonBlocking, least));
+                DTTS_CHECK_HIP(hipStreamCreateWithPriority(&si_, hipStreamNonBlocking, low ? least : 0));
             }
         }
         while ((int)ev_integ_.size() < cdiv(NS, J)) {
@@ -1101,8 +1103,11 @@ void Model::diff_sample(const float* code_emb, const int* lens_host, int B, int 
     }
     float* integ_all = nullptr;
     const int Bi = B + pl.Nu;
-    // option "integ_pipeline" (DTTS_INTEG_PIPELINE overrides; default: on up to batch 4, where a forward is ONE launch sequence in the
-    // latency regime): the integrator's later step chunks run under the first sampling steps instead of in front of the loop
+    // option "integ_pipeline" (DTTS_INTEG_PIPELINE overrides; 1 = on, -1 = on up to batch 4, where a forward is ONE launch sequence in
+    // the latency regime): the integrator's later step chunks run under the first sampling steps instead of in front of the loop.
+    // OFF by default: it returns 1 ms of a blocking batch-1 call, but in a process that holds more streams (after batch-8 requests) the
+    // extra stream shares a hardware queue with the next request's stage A and a pipelined single-utterance request takes 208 instead
+    // of 147 ms (profiles/r05_integ_pipeline_ab.txt)
     static const int env_pipe = []() { const char* v = getenv("DTTS_INTEG_PIPELINE"); return v ? atoi(v) : -1; }();
     const int pipe_opt = env_pipe >= 0 ? env_pipe : opt_integ_pipeline_;
     const bool pipe = pipe_opt < 0 ? B <= 4 : pipe_opt != 0;

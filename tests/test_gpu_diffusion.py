@@ -255,7 +255,7 @@ def test_ragged_batch_launching_only_live_columns_is_bit_identical(rt, weights, 
 
 @pytest.mark.parametrize("lens", [[333], [132, 77, 200]])
 def test_integrator_chunks_under_the_sampling_loop_are_bit_identical(rt, weights, lens):
-    """Option integ_pipeline (default: on up to batch 4): only the first chunk of the conditioning_timestep_integrator's step outputs
+    """Option integ_pipeline (off by default, DESIGN.md par. 4.5): only the first chunk of the conditioning_timestep_integrator's step outputs
     (vqvae/diff_model.py:295; it never sees x_t) is evaluated in front of the sampling loop, the later chunks run on a low-priority
     stream under the first steps, which wait for a chunk's event at its first step.  Same launches on the same inputs: all 50 steps
     (3 chunks at batch 1, 9 at a ragged batch of 3) must not change by one bit, also when the call is repeated (the chunks' scratch
@@ -269,12 +269,17 @@ def test_integrator_chunks_under_the_sampling_loop_are_bit_identical(rt, weights
             rt.set_option("integ_pipeline", flag)
             outs.setdefault(flag, []).append(host(rt.diff_sample(ce, 6, list(range(B)), lens=lens, n_steps=50, denorm=True)))
     finally:
-        rt.set_option("integ_pipeline", -1)
-    dflt = host(rt.diff_sample(ce, 6, list(range(B)), lens=lens, n_steps=50, denorm=True))
+        rt.set_option("integ_pipeline", 0)
+    rt.set_option("integ_pipeline", -1)                 # by batch size: on for these calls
+    try:
+        dflt = host(rt.diff_sample(ce, 6, list(range(B)), lens=lens, n_steps=50, denorm=True))
+    finally:
+        rt.set_option("integ_pipeline", 0)
+    dflt0 = host(rt.diff_sample(ce, 6, list(range(B)), lens=lens, n_steps=50, denorm=True))
     for b, L in enumerate(lens):
         ref = outs[0][0][b, :, :L]
         assert np.isfinite(ref).all() and float(np.abs(ref).max()) > 0.1
-        for o in outs[1] + [dflt]:
+        for o in outs[1] + [dflt, dflt0]:
             assert np.array_equal(ref, o[b, :, :L]), b
 
 
