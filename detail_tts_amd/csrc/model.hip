@@ -921,6 +921,8 @@ static size_t integ_ws_bytes(int Bv, int C, int T) {
     return sizeof(float) * (act + 2 * (3 * act + qkv_floats(Bv, C, T) + (size_t)2 * Bv * C)) + 2 * x3_bytes(Bv, C, T) + 32 * 256;
 }
 static int integ_chunk(int Bi) {     // steps per batched evaluation (~36 samples per launch; DTTS_INTEG_SAMPLES overrides)
+    // (batch 1, 12 / 20 / 36 / 52 / 100 samples per launch: diff_sample 122.8 - 126.2 / 123.1 / 123.5 - 124.2 / 123.4 / 123.6 ms - flat within the
+    // run-to-run spread, profiles/r05_integ_pipeline_ab.txt)
     static const int target = []() { const char* v = getenv("DTTS_INTEG_SAMPLES"); return v ? atoi(v) : 36; }();
     return std::max(1, target / Bi);
 }
