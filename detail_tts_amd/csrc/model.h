@@ -215,6 +215,7 @@ public:
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
+        else if (key == "ln_reg") set_ln_channels_reg(value != 0);          // process-wide: the register-resident channel LayerNorm (ops.h)
         else if (key == "integ_pipeline") opt_integ_pipeline_ = value;      // 0 (default) / 1; -1: by batch size (on up to batch 4)
         else throw Error(-1, "unknown option '" + key + "'");
     }

@@ -20,6 +20,7 @@ void launch_affine_apply(const float* x, long long x_bs, int x_cs, const float* 
 
 // LayerNorm over the channel axis of [B,C,T] (vqvae/modules/modules.py:36-48), y = LN(x + r) (r may be null);
 // columns t >= len are left untouched.
+void set_ln_channels_reg(bool on);     // 1 (default): norms of <= 1024 channels keep a thread's channels in registers (one load pass); bit-identical
 void launch_ln_channels(const float* x, const float* r, long long bs, int cs, const int* lens, int T, int B, int C,
                         const float* gamma, const float* beta, float eps, float* y, long long y_bs, int y_cs, hipStream_t s);
 

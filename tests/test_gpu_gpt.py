@@ -39,6 +39,28 @@ def test_teacher_forced_latents_golden(rt, golden):
     assert maxabs(lat, ref) < 2e-4, maxabs(lat, ref)
 
 
+def test_register_resident_channel_layernorm_is_bit_identical(rt, golden):
+    """Option ln_reg (default on): the channel LayerNorms of <= 1024 channels (GPT prefill / teacher-forced pass, MelStyleEncoder, enc_p)
+    load a thread's channels once into registers instead of walking the column three times.  Same values summed in the same order:
+    the teacher-forced latents (gpt/model.py:107-185, return_latent=True) of a ragged 2-row batch must not change by one bit."""
+    g = golden("gpt_forced")
+    n = g["codes"].shape[1]
+    refer = np.concatenate([g["refer"], g["refer"][:, :, ::-1]], 0).copy()
+    texts = [g["text"][0], g["text"][0][: max(3, len(g["text"][0]) // 2)]]
+    codes = [g["codes"][0], g["codes"][0][: max(2, n // 3)]]
+    rl = [g["refer"].shape[2], g["refer"].shape[2] - 37]
+    outs = {}
+    try:
+        for flag in (0, 1):
+            rt.set_option("ln_reg", flag)
+            outs[flag] = host(rt.gpt_latents(dev(refer), rl, texts, codes))
+    finally:
+        rt.set_option("ln_reg", 1)
+    assert np.isfinite(outs[1]).all() and float(np.abs(outs[1]).max()) > 0.1
+    assert np.array_equal(outs[0], outs[1])
+    assert maxabs(outs[1][:1, :, :n], g["latent"].transpose(0, 2, 1)) < 2e-4
+
+
 def test_decode_latents_equal_teacher_forced_golden(rt, golden):
     """KV-cache decode with forced tokens: the per-step hidden states are the reference's return_latent values."""
     g = golden("gpt_forced")
