@@ -275,6 +275,13 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *   "voc_chain_planes" (default 1): HiFiGAN ResBlock1 of the wide generator stages - every split-precision conv's epilogue writes
  *                 leaky_relu(y) as the NEXT conv's fp16 operand planes (convs1 without an fp32 output at all), one split pass per block
  *                 instead of six; 0 = a split pass in front of every conv.  The same planes bit for bit; env DTTS_VOC_CHAIN_PLANES=0;
+ *   "ln_reg"      (default 1; process-wide): the channel LayerNorms of <= 1024 channels (GPT prefill / teacher-forced pass,
+ *                 MelStyleEncoder, enc_p) hold a thread's channels in registers - one load pass instead of three; the same sums in the
+ *                 same order, bit-identical output; env DTTS_LN_REG=0;
+ *   "integ_pipeline" (default 0): 1 (-1: up to batch 4) = only the first chunk of the conditioning_timestep_integrator's step outputs is
+ *                 evaluated in front of the sampling loop, the later chunks on a stream of their own under the first sampling steps
+ *                 (bit-identical; returns 1 ms at batch 1 but can cost a pipelined request 60 ms in a process with many live
+ *                 streams: DESIGN.md par. 4.5); env DTTS_INTEG_PIPELINE;
  *   "x3_range_check" (default 0): 1 = a stage-C call checks that the inputs of its split-precision convs (ResBlock1, WaveNet in_layers:
  *                 unnormalised activations) stay inside the fp16 planes' range (|x| <= 4094); a violation fails the call instead of
  *                 saturating silently.  Reads a flag back at the end of the call (synchronises the stream); env DTTS_X3_RANGE_CHECK=1.
