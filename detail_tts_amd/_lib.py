@@ -28,7 +28,7 @@ class DttsConfig(C.Structure):
 
 
 class DttsGptOptions(C.Structure):
-    _fields_ = [("seed", C.c_ulonglong), ("sample_ids", c_int_p), ("max_generate_length", C.c_int), ("top_k", C.c_int),
+    _fields_ = [("struct_size", C.c_size_t), ("seed", C.c_ulonglong), ("sample_ids", c_int_p), ("max_generate_length", C.c_int), ("top_k", C.c_int),
                 ("top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float), ("suppress_eos", C.c_int),
                 ("forced_uniforms", C.c_void_p), ("forced_codes", c_int_p), ("row_seeds", c_u64_p), ("typical_mass", C.c_float)]
 
@@ -42,6 +42,7 @@ class DttsKernelStat(C.Structure):
 SIGNATURES = {
     "dtts_version": (C.c_char_p, []),
     "dtts_default_config": (None, [C.POINTER(DttsConfig)]),
+    "dtts_gpt_options_init": (None, [C.POINTER(DttsGptOptions)]),
     "dtts_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DttsConfig), C.c_int]),
     "dtts_destroy": (C.c_int, [C.c_void_p]),
     "dtts_last_error": (C.c_char_p, [C.c_void_p]),
@@ -81,6 +82,7 @@ SIGNATURES = {
                                       C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_vocoder_ticket": (C.c_longlong, [C.c_void_p]),
     "dtts_vocoder_check": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "dtts_vocoder_check_active": (C.c_int, [C.c_void_p]),
     "dtts_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_mel_style": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dtts_op_attention_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

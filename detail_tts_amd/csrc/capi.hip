@@ -108,6 +108,7 @@ int dtts_set_option(dtts_handle* h, const char* key, int value) {
 }
 
 long long dtts_vocoder_ticket(dtts_handle* h) { return h && h->m ? h->m->vocoder_ticket() : 0; }
+int dtts_vocoder_check_active(dtts_handle* h) { return h && h->m && h->m->vocoder_check_active() ? 1 : 0; }
 
 int dtts_vocoder_check(dtts_handle* h, long long ticket) {
     DTTS_API_BEGIN
@@ -174,11 +175,32 @@ int dtts_bind_weights(dtts_handle* h, const void* blob, size_t nbytes, const cha
     DTTS_API_END(h)
 }
 
+void dtts_gpt_options_init(dtts_gpt_options* o) {
+    if (!o) return;
+    *o = dtts_gpt_options{};
+    o->struct_size = sizeof(dtts_gpt_options);
+    o->max_generate_length = 600;
+    o->top_k = 50;
+    o->top_p = 0.8f;
+    o->temperature = 0.8f;
+    o->repetition_penalty = 2.0f;
+}
+
+static void check_gpt_options(const dtts_gpt_options* o) {
+    DTTS_REQUIRE(o, "options");
+    DTTS_REQUIRE(o->struct_size == sizeof(dtts_gpt_options),
+                 "dtts_gpt_options.struct_size does not match this library's layout: start from dtts_gpt_options_init() (built against another include/detail_hip.h?)");
+    DTTS_REQUIRE(o->sample_ids, "options: sample_ids");
+    DTTS_REQUIRE(o->typical_mass >= 0.f && o->typical_mass <= 1.f, "options: typical_mass outside [0, 1] (0 = off)");      // NaN fails both
+    DTTS_REQUIRE(o->temperature > 0.f && o->temperature < INFINITY && o->top_p >= 0.f && o->top_p <= 1.f && o->repetition_penalty > 0.f &&
+                     o->repetition_penalty < INFINITY, "options: temperature / top_p / repetition_penalty out of range");
+}
+
 int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
                       int Lt_max, int B, const dtts_gpt_options* opts, int* codes_out, int* ncodes_out, float* latents_cm,
                       int lat_stride, void* stream) {
     DTTS_API_BEGIN
-    DTTS_REQUIRE(opts && opts->sample_ids, "options");
+    check_gpt_options(opts);
     h->m->gpt_generate(refer, refer_lens, Tr, text, text_lens, Lt_max, B, *opts, codes_out, ncodes_out, latents_cm, lat_stride,
                        (hipStream_t)stream);
     DTTS_API_END(h)
@@ -187,7 +209,7 @@ int dtts_gpt_generate(dtts_handle* h, const float* refer, const int* refer_lens,
 int dtts_gpt_prefill(dtts_handle* h, const float* refer, const int* refer_lens, int Tr, const int* text, const int* text_lens,
                      int Lt_max, int B, const dtts_gpt_options* opts, float* latents_cm, int lat_stride, void* stream) {
     DTTS_API_BEGIN
-    DTTS_REQUIRE(opts && opts->sample_ids, "options");
+    check_gpt_options(opts);
     h->m->gpt_prefill(refer, refer_lens, Tr, text, text_lens, Lt_max, B, *opts, latents_cm, lat_stride, (hipStream_t)stream);
     DTTS_API_END(h)
 }

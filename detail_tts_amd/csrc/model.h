@@ -215,6 +215,8 @@ public:
         else if (key == "gn_fuse") opt_gn_fuse_ = value != 0;
         else if (key == "conv_cols") opt_conv_cols_ = value != 0;
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
+        else if (key == "voc_x3") opt_voc_x3_ = value != 0;                 // 0: stage C on the exact fp32 kernels only (the trunk keeps conv_x3's choice)
+        else if (key == "x3_fault") opt_x3_fault_ = value;                  // test hook: the n-th stage-C ticket from now on is raised as saturated
         else if (key == "ln_reg") set_ln_channels_reg(value != 0);          // process-wide: the register-resident channel LayerNorm (ops.h)
         else if (key == "integ_pipeline") opt_integ_pipeline_ = value;      // 0 (default) / 1; -1: by batch size (on up to batch 4)
         else throw Error(-1, "unknown option '" + key + "'");
@@ -365,6 +367,8 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
+    bool opt_voc_x3_ = true;         // stage C's split-precision kernels (ResBlock1 convs, WaveNet in_layers); 0 = exact fp32 (cannot saturate)
+    int opt_x3_fault_ = 0;           // test hook (option x3_fault)
     bool opt_voc_chain_ = true;      // ResBlock1 (wide generator stages): conv epilogues write the next conv's planes (resblock1_fwd)
     bool opt_conv_cols_ = true;      // ragged batches: trunk convs launch their live (sample, N tile) columns only (register_cols)
     bool opt_range_check_ = false;      // vocoder: detect activations beyond the split-precision planes' range (synchronises)
@@ -380,6 +384,7 @@ private:
     void x3_sat_check(hipStream_t s);   // option x3_range_check: synchronise and report this call's saturation
 public:
     long long vocoder_ticket() const { return x3_ticket_; }
+    bool vocoder_check_active() const { return x3_sat_dev_ != nullptr && vocoder_x3(); }
     // one ticket per TOP-LEVEL stage-C call: vocoder() opens the scope before the flow (whose WaveNet planes can saturate too) and the
     // generator calls inside it - one per window when streamed - report into the same slot
     int x3_sat_depth_ = 0;
@@ -438,7 +443,7 @@ private:
         unsigned long long last_use = 0;
         std::shared_ptr<std::atomic<int>> owner_alive;      // 1 while the owning host thread lives (its thread_local guard clears it)
     };
-    static constexpr size_t MAX_INT_RINGS = 16;      // rings of host threads that are GONE are recycled, not leaked
+    static constexpr size_t MAX_INT_RINGS = 16;      // soft cap: from here on rings of host threads that are GONE are recycled before a new one is made
     unsigned long long ring_clock_ = 0;
     std::map<std::thread::id, std::unique_ptr<IntRing>> int_rings_;
     std::mutex ints_mu_;        // guards the map only; a ring is touched by its own thread

@@ -347,7 +347,7 @@ void Model::rb_fused(const GenStageW& st, const float* x, float* y, int ch, cons
 // dtts_set_option "x3_range_check" 1 / DTTS_X3_RANGE_CHECK=1 additionally reads the flag at the END of the call, which synchronises
 // the stream; DTTS_X3_RANGE_CHECK=0 switches the check off.
 static const char* kSatMsg = "vocoder: an activation exceeds the range of the split-precision planes (|x| > 4094) - the ResBlock1 convs of this "
-                             "request saturated; rerun with dtts_set_option(\"conv_x3\", 0) or DTTS_VOC_X3=0 (exact fp32 kernels)";
+                             "request saturated; rerun with dtts_set_option(\"voc_x3\", 0) / DTTS_VOC_X3=0 (stage C alone) or \"conv_x3\", 0 (everything) on the exact fp32 kernels";
 
 int* Model::x3_sat_flag(hipStream_t s) {
     static const int env = []() { const char* v = getenv("DTTS_X3_RANGE_CHECK"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
@@ -370,6 +370,7 @@ int* Model::x3_sat_flag(hipStream_t s) {
                         "(dtts_vocoder_check); its waveform is wrong\n", x3_ticket_ - X3_SAT_SLOTS);
         *f = 0;
     }
+    if (opt_x3_fault_ > 0 && --opt_x3_fault_ == 0) *f = 1;        // test hook: this call "saturated"
     x3_sat_dev_ = x3_sat_ring_dev_ + slot;
     return x3_sat_dev_;
 }
@@ -390,7 +391,7 @@ void Model::x3_sat_check(hipStream_t s) {
 
 bool Model::vocoder_x3() const {
     static const bool env_on = []() { const char* v = getenv("DTTS_VOC_X3"); return !(v && v[0] == '0'); }();
-    return env_on && use_x3();
+    return env_on && opt_voc_x3_ && use_x3();
 }
 
 // unit entry point: dec.resblocks[stage * 3 + branch] on x [B, ch(stage), T]
@@ -812,12 +813,13 @@ void Model::vocoder(const float* mel, const int* lens_host, int B, int T, unsign
 // ------------------------------------------------------------------------------------------ VQ decode path
 __global__ void vq_gather_kernel(const float* table, const int* codes, int code_stride, const int* ncodes, const float* g, int C, int nmax,
                                  float* out) {
-    // out[b][c][t] = table[codes[b][t]][c] + g[b][c]      (quantizer.decode + g_vq, vqvae/model_24k.py:828, 841)
+    // out[b][c][t] = table[codes[b][t]][c] + g[b][c]      (quantizer.decode + g_vq, vqvae/model_24k.py:828, 841); code -1 = a frame of the
+    // zero latent the reference substitutes for an empty code sequence (:833-834)
     const int t = blockIdx.x, b = blockIdx.y;
     if (t >= ncodes[b]) return;
     const int code = codes[(long long)b * code_stride + t];
     for (int c = threadIdx.x; c < C; c += blockDim.x)
-        out[((long long)b * C + c) * nmax + t] = table[(long long)code * C + c] + g[(long long)b * C + c];
+        out[((long long)b * C + c) * nmax + t] = (code < 0 ? 0.f : table[(long long)code * C + c]) + g[(long long)b * C + c];
 }
 
 void Model::build_vq() {
@@ -941,7 +943,7 @@ void Model::vq_decode(const int* codes_host, const int* ncodes_host, int nmax, c
         n1[b] = ncodes_host ? ncodes_host[b] : nmax;
         DTTS_REQUIRE(n1[b] >= 1 && n1[b] <= nmax, "ncodes");
         for (int t = 0; t < n1[b]; ++t)
-            DTTS_REQUIRE(codes_host[(size_t)b * nmax + t] >= 0 && codes_host[(size_t)b * nmax + t] < 8192, "code outside the 8192-entry codebook");
+            DTTS_REQUIRE(codes_host[(size_t)b * nmax + t] >= -1 && codes_host[(size_t)b * nmax + t] < 8192, "code outside the 8192-entry codebook (-1 = a zero-latent frame)");
         n2[b] = 2 * n1[b];
         n4[b] = 4 * n1[b];
         rl[b] = refer_lens_host ? refer_lens_host[b] : Tr;

@@ -38,7 +38,7 @@ class UnifiedVoice:
         Off the `infer` path but part of the reference's surface: `do_sample=False` (HF greedy search: only the repetition penalty is a
         logits processor there, argmax), `num_return_sequences = n` (HF repeats every row n times - repeat_interleave - and samples the
         copies independently: `sample_ids` of length B * n name their noise streams, or of length B: copy r of row b draws from
-        sample_ids[b] + r), `input_tokens [rows, k]` (mel tokens in front of the generated ones; with num_return_sequences = n > 1 the
+        sample_ids[b] + r - the expanded ids must be distinct, else ValueError), `input_tokens [rows, k]` (mel tokens in front of the generated ones; with num_return_sequences = n > 1 the
         reference tiles them AND lets HF expand the batch again: n * n rows of the single prompt, reproduced), `typical_sampling`
         (HF TypicalLogitsWarper(mass=typical_mass), which HF applies between the repetition penalty and the temperature)."""
         nrs = int(num_return_sequences)
@@ -70,6 +70,11 @@ class UnifiedVoice:
             if len(ids) == B:
                 ids = [i + r for i in ids for r in range(nrs)]
         assert len(ids) == B * nrs, "sample_ids: one per returned sequence (or one per prompt)"
+        if len(set(ids)) != len(ids):
+            # HF samples all copies independently: two returned sequences on ONE Philox stream would be the same draw sequence
+            # (per-prompt ids [0, 1] with n = 2 expand to [0, 1, 1, 2]: ADVICE r05)
+            raise ValueError(f"sample_ids expand to {ids}: two returned sequences would share a noise stream - pass B * num_return_sequences "
+                             "distinct ids (or per-prompt ids at least num_return_sequences apart)")
         G = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         forced = None
         if it is not None:

@@ -162,6 +162,7 @@ class Runtime:
         si = _ints(sample_ids)
         rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
         o = _lib.DttsGptOptions()
+        self.lib.dtts_gpt_options_init(C.byref(o))
         row_seeds = None
         if isinstance(seed, (list, tuple, np.ndarray)):          # one Philox seed per row: rows of different requests in one session
             row_seeds = np.ascontiguousarray(np.asarray(seed, np.uint64))
@@ -199,6 +200,7 @@ class Runtime:
         si = _ints(sample_ids)
         rl = _ints(refer_lens if refer_lens is not None else [Tr] * B)
         o = _lib.DttsGptOptions()
+        self.lib.dtts_gpt_options_init(C.byref(o))
         row_seeds = None
         if isinstance(seed, (list, tuple, np.ndarray)):          # one Philox seed per row: rows of different requests in one session
             row_seeds = np.ascontiguousarray(np.asarray(seed, np.uint64))
@@ -324,6 +326,11 @@ class Runtime:
         """dtts_vocoder_check: raises when stage-C call `ticket` saturated its split-precision planes.  Call it AFTER waiting for that
         call (the waveform's stream / event), i.e. where the waveform is about to be read."""
         self._rc(self.lib.dtts_vocoder_check(self.h, int(ticket)))
+
+    def vocoder_check_active(self):
+        """False when the last stage-C call took no range-check flag (the check is switched off, or stage C ran on the exact fp32
+        kernels): dtts_vocoder_check has nothing to report then and nobody needs to wait for it"""
+        return bool(self.lib.dtts_vocoder_check_active(self.h))
 
     def generator(self, z, g, lens=None):
         _check(z, "z"); _check(g, "g")

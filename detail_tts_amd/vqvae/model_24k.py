@@ -113,6 +113,7 @@ class SynthesizerTrn:
         self.stream_trace = None      # set to [] to collect the per-request timeline of infer_stream()
         self.vocoder_done = None
         self.vocoder_ticket = 0
+        self.saturated_requests = 0   # requests of infer_stream whose stage C was re-run on the exact fp32 kernels
 
     def eval(self):
         return self
@@ -209,7 +210,7 @@ class SynthesizerTrn:
         else:
             wav = self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)
         self.vocoder_ticket = self.rt.vocoder_ticket()
-        if wait and check_range:
+        if wait and check_range and self.rt.vocoder_check_active():      # (check off - DTTS_X3_RANGE_CHECK=0, conv_x3 / voc_x3 = 0: nothing to wait for)
             torch.cuda.current_stream(self.device).synchronize()
             self.rt.vocoder_check(self.vocoder_ticket)
         mark("vocoder")
@@ -227,7 +228,7 @@ class SynthesizerTrn:
 
     # ------------------------------------------------------------------------------------------------------------
     def infer_stream(self, requests, noise_scale=NOISE_SCALE, *, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False,
-                     vocoder_chunk=0, pair_stage_a=False):
+                     vocoder_chunk=0, pair_stage_a=False, on_saturation="rerun_fp32"):
         """Batch server: `infer(..., batch=True)` over a sequence of request batches, software-pipelined over three HIP streams.
 
         requests: iterable of dicts with keys text [B,Lt], text_length [B], refer [B,128,Tr], refer_lengths [B] and optionally seed,
@@ -241,7 +242,13 @@ class SynthesizerTrn:
         third stream under stage B of request i+1.  Stage A is issued from a second host thread; the calling thread blocks only on a decode session's
         results (the code lengths size the diffusion) and on the waveform it is about to hand out, which is the PREVIOUS request's
         (one request of lag), so the diffusion stream never drains.  Device tensors handed over in a request must be complete (not pending on another stream):
-        stage A reads them on its own stream."""
+        stage A reads them on its own stream.
+
+        on_saturation: what happens to a request whose stage C saturated its split-precision planes (dtts_vocoder_check).  "rerun_fp32"
+        (default): THAT request's stage C is run again on the exact fp32 kernels (option voc_x3 = 0, which cannot saturate) and its
+        waveform is handed out as usual - the requests behind it, whose stages are already enqueued, are not lost (ADVICE r05);
+        "raise": the error leaves the generator (and ends the stream)."""
+        assert on_saturation in ("rerun_fp32", "raise")
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         if self._gpt_stream is None:
@@ -371,7 +378,31 @@ class SynthesizerTrn:
                     tr["ev_c1"].record(cur if serial_c else sc)
                     tr["host_b1"] = time.perf_counter()
             wav.record_stream(cur)
-            return wav, [1024 * v for v in n], self.vocoder_done, ticket
+            return wav, [1024 * v for v in n], self.vocoder_done, ticket, (mel, st["seed"], st["sids"], lens_t)
+
+        def hand_out(out):
+            """wait for this request's waveform; a saturated stage C is re-run on the exact fp32 kernels (this thread issues every stage-C
+            launch, so the option flips between two of them; stage A on the other thread never reads it)"""
+            out[2].synchronize()
+            try:
+                self.rt.vocoder_check(out[3])
+            except Exception:
+                if on_saturation == "raise":
+                    raise
+                mel, seed, sids, lens_t = out[4]
+                self.saturated_requests += 1
+                self.rt.set_option("voc_x3", 0)
+                try:
+                    with torch.cuda.stream(cur if serial_c else sc):
+                        wav = self.rt.vocoder(mel, seed, sids, lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
+                        redo = torch.cuda.Event()
+                        redo.record(cur if serial_c else sc)
+                finally:
+                    self.rt.set_option("voc_x3", 1)
+                wav.record_stream(cur)
+                redo.synchronize()
+                return wav, out[1]
+            return out[0], out[1]
 
         # Stage A is issued from its own host thread: a kernel-launch call blocks once its stream's hardware queue is full, so one
         # thread could not enqueue request i+1's decode (12 K launches) while it is still feeding request i's diffusion (10 K).  The
@@ -435,13 +466,9 @@ class SynthesizerTrn:
                     out = launch_bc(st)         # stage B / C of this request: enqueued, not waited for
                     launched = out
                     if pending is not None:
-                        pending[2].synchronize()
-                        self.rt.vocoder_check(pending[3])        # a saturated stage C fails THIS request (its waveform is complete now)
-                        yield pending[0], pending[1]
+                        yield hand_out(pending)                  # a saturated stage C concerns THIS request only (its waveform is complete now)
                     pending = out
-            pending[2].synchronize()
-            self.rt.vocoder_check(pending[3])
-            yield pending[0], pending[1]
+            yield hand_out(pending)
         finally:
             # closed early or failed: the decode session in flight must end before this handle's stage-A entry points are used again
             if fut is not None:
@@ -453,6 +480,8 @@ class SynthesizerTrn:
             # otherwise run its stage C on the same arena under it
             if launched is not None:
                 launched[2].synchronize()
+
+    EMPTY_CODE_FRAMES = 16
 
     def infer_gpt(self, text, text_length, refer, refer_lengths, noise_scale=NOISE_SCALE, *, batch=False, seed=None, sample_ids=None,
                   forced_codes=None, max_generate_length=MAX_GENERATE_LENGTH, top_k=50, suppress_eos=False):
@@ -478,8 +507,9 @@ class SynthesizerTrn:
             code_list = [codes[b, : int(ncodes[b]) - 1] for b in range(B)]          # codes[:, :-1]  (:828)
         else:
             code_list = [np.asarray(c) for c in forced_codes]
-        if min(len(c) for c in code_list) < 1:
-            raise ValueError("an utterance produced no mel codes (the reference substitutes zeros here, model_24k.py:833-834)")
+        # vqvae/model_24k.py:833-834: the stop token came first -> the reference decodes a ZERO latent of 16 frames (64 mel frames);
+        # code -1 is that zero vector in dtts_vq_decode
+        code_list = [c if len(c) else np.full(self.EMPTY_CODE_FRAMES, -1, np.int64) for c in code_list]
         mel = self.rt.vq_decode(code_list, refer, rl)
         lens_t = [4 * len(c) for c in code_list]
         return self.rt.vocoder(mel, seed, sample_ids, lens=lens_t, noise_scale=noise_scale)

@@ -94,6 +94,9 @@ int dtts_bind_weights(dtts_handle* h, const void* blob_dev, size_t nbytes, const
 /* Sampling options of HF generate() as the reference calls it (vqvae/model_24k.py:782-792): do_sample, top_p 0.8,
  * temperature 0.8, repetition_penalty 2.0, max_generate_length 600; top_k is HF's effective default 50. */
 typedef struct dtts_gpt_options {
+    size_t struct_size;             /* = sizeof(dtts_gpt_options) of the header the caller was built with: dtts_gpt_options_init sets it, and
+                                     * dtts_gpt_generate / dtts_gpt_prefill refuse any other value - a caller built against another layout of
+                                     * this struct fails loudly instead of passing garbage in the fields it does not know */
     unsigned long long seed;
     const int* sample_ids;          /* HOST [B]: Philox stream id of each utterance */
     int max_generate_length;        /* number of tokens generated at most (stop included) */
@@ -105,8 +108,13 @@ typedef struct dtts_gpt_options {
                                      * a forced prefix = inference_speech_tortoise's input_tokens, gpt/model.py:533-537), or NULL */
     const unsigned long long* row_seeds;   /* HOST [B] per-row Philox seed (rows of different requests in one session), or NULL: `seed` */
     float typical_mass;             /* inference_speech_tortoise(typical_sampling=True, typical_mass): HF TypicalLogitsWarper, applied between
-                                     * the repetition penalty and the temperature (gpt/model.py:539); <= 0 or >= 1: off */
+                                     * the repetition penalty and the temperature (gpt/model.py:539); 0 (or 1): off; values outside
+                                     * [0, 1] or not finite are rejected */
 } dtts_gpt_options;
+
+/* struct_size + the reference's sampling call (vqvae/model_24k.py:782-792: top_p 0.8, temperature 0.8, repetition_penalty 2.0,
+ * max_generate_length 600; HF's effective top_k 50), every pointer NULL, typical sampling off.  Call it first, then set sample_ids. */
+void dtts_gpt_options_init(dtts_gpt_options* o);
 
 /* UnifiedVoice.inference_speech_tortoise (gpt/model.py:514-545) + HF GenerationMixin._sample, with a real KV cache
  * (mel position k for the k-th code) and the sampler on the device.  refer [B,128,Tr] device, refer_lens HOST,
@@ -207,6 +215,9 @@ int dtts_vocoder_stream(dtts_handle* h, const float* mel, const int* lens, int B
  * reused.  The reference has no counterpart (it computes these convs in fp32: vqvae/modules/modules.py:315-328). */
 long long dtts_vocoder_ticket(dtts_handle* h);
 int dtts_vocoder_check(dtts_handle* h, long long ticket);
+/* 1 when the last stage-C call took a range-check flag (split-precision kernels in use, check not switched off); 0: dtts_vocoder_check has
+ * nothing to report for it, and a caller that would only wait in order to check need not wait */
+int dtts_vocoder_check_active(dtts_handle* h);
 
 /* Generator.forward (vqvae/model_24k.py:269-288): z [B,192,T], g [B,768] (NULL: `g is None`, no conditioning) -> wav [B,1,256*T] */
 int dtts_generator(dtts_handle* h, const float* z, const float* g, const int* lens, int B, int T, float* wav, void* stream);
@@ -217,7 +228,8 @@ int dtts_op_mel_style(dtts_handle* h, const char* which, const float* mel, const
 
 /* ---- VQ decode path of infer_gpt ---------------------------------------------------------------- */
 /* recon = vq_dec(quantizer.decode(codes) + vq_ref_enc(refer*mask, mask))  (vqvae/model_24k.py:828-845).
- * codes HOST int32 [B][nmax] (< 8192, stop token already dropped), ncodes HOST [B], refer DEVICE [B,128,Tr] -> mel_out DEVICE [B,128,4*nmax] */
+ * codes HOST int32 [B][nmax] (< 8192, stop token already dropped; -1 = a frame of the ZERO latent: the reference substitutes 16 of them
+ * for an empty code sequence, :833-834), ncodes HOST [B], refer DEVICE [B,128,Tr] -> mel_out DEVICE [B,128,4*nmax] */
 int dtts_vq_decode(dtts_handle* h, const int* codes, const int* ncodes, int nmax, const float* refer, const int* refer_lens, int Tr,
                    int B, float* mel_out, void* stream);
 

@@ -14,8 +14,14 @@ from . import vocoder as V
 F32 = np.float32
 
 
+EMPTY_FRAMES = 16       # vqvae/model_24k.py:833-834: an empty code sequence decodes to a ZERO latent of 16 frames
+
+
 def quantizer_decode(P, codes):
-    """codes [B,n] -> [B,768,n]: embed lookup (codebook_dim 8) -> project_out -> 'b n d -> b d n'."""
+    """codes [B,n] -> [B,768,n]: embed lookup (codebook_dim 8) -> project_out -> 'b n d -> b d n'.  n = 0 (the stop token came first):
+    the reference's substitute, zeros [B,768,16] (vqvae/model_24k.py:833-834)."""
+    if np.asarray(codes).shape[-1] == 0:
+        return np.zeros((np.asarray(codes).shape[0], P["quantizer.vq.layers.0.project_out.weight"].shape[0], EMPTY_FRAMES), F32)
     q = P["quantizer.vq.layers.0._codebook.embed"][np.asarray(codes, np.int64)]                 # [B,n,8]
     q = ops.linear(q, P["quantizer.vq.layers.0.project_out.weight"], P["quantizer.vq.layers.0.project_out.bias"])
     return np.ascontiguousarray(q.transpose(0, 2, 1), F32)

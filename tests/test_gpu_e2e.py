@@ -103,6 +103,26 @@ def test_infer_gpt_forced_codes_vs_reference_golden(model, golden):
     tol("infer_gpt_forced_wav_rms", rms(wav, g["wav"]), 1e-7)
 
 
+def test_infer_gpt_with_an_empty_code_sequence_vs_reference_golden(model, golden):
+    """vqvae/model_24k.py:833-834: the stop token first -> the reference decodes a zero latent of 16 frames; alone and as one row of a batch
+    next to a row with codes (that row equals its own run)."""
+    g, gv = golden("infer_gpt_empty"), golden("vq_path")
+    refer = torch.from_numpy(g["refer"])
+    text = torch.zeros((1, 4), dtype=torch.int32)
+    wav = model.infer_gpt(text, torch.tensor([4]), refer, torch.tensor([refer.shape[2]]), seed=int(g["seed"]), sample_ids=[int(g["sample_id"])],
+                          forced_codes=[np.zeros((0,), np.int64)]).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    tol("infer_gpt_empty_wav_rms", rms(wav, g["wav"]), 1e-7)
+    recon = model.rt.vq_decode([np.full(16, -1)], refer.cuda(), [refer.shape[2]]).cpu().numpy()
+    tol("infer_gpt_empty_recon_maxabs", float(np.abs(recon - g["recon"]).max()), 1e-4)
+    # the free-sampling route: a first draw of the stop token gives ncodes == 1 -> codes[:, :-1] is empty
+    both = model.infer_gpt(torch.zeros((2, 4), dtype=torch.int32), torch.tensor([4, 4]), torch.cat([refer, torch.from_numpy(gv["refer"])]),
+                           torch.tensor([refer.shape[2], gv["refer"].shape[2]]), batch=True, seed=int(g["seed"]),
+                           sample_ids=[int(g["sample_id"]), int(gv["sample_id"])], forced_codes=[np.zeros((0,), np.int64), gv["codes"][0]]).cpu().numpy()
+    tol("infer_gpt_empty_row_in_batch_rms", rms(both[0, :, : 16384], g["wav"][0]), 1e-7)
+    tol("infer_gpt_codes_row_next_to_empty_rms", rms(both[1, :, : gv["wav"].shape[2]], gv["wav"][0]), 1e-7)
+
+
 def test_infer_gpt_free_sampling_vs_oracle(model, weights):
     from oracle import gpt as G, vq
     rs = np.random.RandomState(34)

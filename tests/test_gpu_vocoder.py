@@ -418,3 +418,38 @@ def test_calls_from_many_short_lived_host_threads(rt):
         t.start()
         t.join()
     assert len(outs) == 24 and all(np.array_equal(o, ref) for o in outs)
+
+
+def test_calls_from_more_than_sixteen_long_lived_host_threads(rt):
+    """a pool of 20 LIVE worker threads that take turns on one handle (serialised: the "two at a time" contract holds) - the
+    17th live thread used to fail permanently; now it gets an upload ring of its own.  Same result from every thread, twice round."""
+    import threading
+    rs = np.random.RandomState(73)
+    mel = dev((rs.randn(2, 128, 40) * 2 - 5).astype(np.float32))
+    ref = host(rt.mel_style("ref_enc", mel, [40, 29]))
+    n = 20
+    turn = [threading.Semaphore(0) for _ in range(n)]
+    done = threading.Semaphore(0)
+    outs, errs = [], []
+
+    def work(i):
+        torch.cuda.set_device(0)
+        for _ in range(2):
+            turn[i].acquire()
+            try:
+                outs.append(host(rt.mel_style("ref_enc", mel, [40, 29])))
+            except Exception as e:          # noqa: BLE001
+                errs.append(repr(e))
+            done.release()
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    for _ in range(2):
+        for i in range(n):
+            turn[i].release()
+            done.acquire()
+    for t in ths:
+        t.join()
+    assert not errs, errs[:2]
+    assert len(outs) == 2 * n and all(np.array_equal(o, ref) for o in outs)

@@ -190,6 +190,21 @@ def test_vq_decode_path(weights, golden):
     assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-3
 
 
+def test_vq_decode_path_with_an_empty_code_sequence(weights, golden):
+    """infer_gpt when the stop token comes first (vqvae/model_24k.py:833-834): a zero latent of 16 frames -> 64 mel frames -> wav,
+    against the reference's own infer_gpt run (tests/golden/make_golden_r6.py)."""
+    from oracle import vq
+    g = golden("infer_gpt_empty")
+    T = g["refer"].shape[2]
+    mel = vq.vq_decode_mel(weights, np.zeros((1, 0), np.int64), g["refer"], [T])
+    assert mel.shape == g["recon"].shape == (1, 128, 64)
+    assert maxabs(mel, g["recon"]) < 1e-4
+    wav = vq.infer_gpt_from_codes(weights, np.zeros((0,), np.int64), g["refer"][0], int(g["seed"]), int(g["sample_id"]))
+    ref = g["wav"][0, 0]
+    assert wav.shape == ref.shape == (16384,)
+    assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-3
+
+
 def test_frontend_mel_against_reference_function(golden):
     """oracle.frontend.mel_spectrogram vs the reference's own mel_spectrogram_torch / spectrogram_torch (fixture `frontend`)."""
     from oracle import frontend as FE
