@@ -355,6 +355,9 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     power = power.stop()
+    if power:       # the step's ENERGY: at the board's power limit a kernel costs the step its joules, not its stand-alone duration
+        power["energy_J_per_step"] = round(power["mean_W"] * dt / args.steps, 1)
+        power["J_per_audio_s"] = round(power["mean_W"] * dt / (args.steps * B * n_codes * 1024 / 24000.0), 3)
     prof = model.rt.profile_report()
     model.rt.profile_enable(False)
     model.rt.profile_sampling(1)
@@ -403,6 +406,24 @@ def main():
                                              suppress_eos=True) for i in range(n)], 3)
         extra["unpipelined_ms_per_step"] = round(ms, 2)
         extra["unpipelined_audio_s_per_s"] = round((n_codes * 1024 / 24000.0) * B / (ms * 1e-3), 2)
+        # (a') the same blocking steps on the EXACT fp32 kernels (conv_x3 = 0: v_mfma_f32_32x32x2_f32 convs + fp32-MFMA attention in the
+        # trunk and the generator): what `dtype: "f32"` costs without the split-precision operands (two fp16 planes, 3 fp16 MFMA
+        # products per fp32 product) - the headline runs on those, and says so in roofline.arithmetic
+        model.rt.set_option("conv_x3", 0)
+        try:
+            model.infer(text, tl, refer, rl, batch=True, seed=4050, sample_ids=sample_ids, max_generate_length=n_codes + 1, suppress_eos=True)
+            ps = PowerSampler(local).start()
+            ms32, _ = timed(lambda n: [model.infer(text, tl, refer, rl, batch=True, seed=4051 + i, sample_ids=sample_ids,
+                                                   max_generate_length=n_codes + 1, suppress_eos=True) for i in range(n)], 3)
+            pw32 = ps.stop()
+        finally:
+            model.rt.set_option("conv_x3", 1)
+        extra["exact_fp32"] = {"ms_per_step": round(ms32, 2), "audio_s_per_s": round((n_codes * 1024 / 24000.0) * B / (ms32 * 1e-3), 2),
+                               "vs_split_precision_unpipelined": round(ms32 / ms, 3), "mean_W": pw32 and pw32["mean_W"],
+                               "mean_sclk_MHz": pw32 and pw32["mean_sclk_MHz"],
+                               "energy_J_per_step": pw32 and round(pw32["mean_W"] * ms32 * 1e-3, 1),
+                               "note": "3 blocking infer() calls with dtts_set_option(\"conv_x3\", 0): every conv / attention of the trunk and the generator "
+                                       "on the exact fp32 MFMA kernels (compare with unpipelined_ms_per_step)"}
         # (b) batch 1 (configs[1]): latency of one blocking infer(), and the pipelined period of a stream of single-utterance requests
         r1 = dict(text=text[:1], text_length=tl[:1], refer=refer[:1], refer_lengths=rl[:1], sample_ids=sample_ids[:1])
         model.infer(text[:1], tl[:1], refer[:1], rl[:1], batch=True, seed=1, sample_ids=sample_ids[:1], max_generate_length=n_codes + 1, suppress_eos=True)
@@ -431,6 +452,33 @@ def main():
         extra["ragged_batch"] = {"codes": rn, "prompt_frames": rrl, "text_ids": rtl, "ms_per_step": round(ms, 2),
                                  "audio_s_per_s": round(sum(rn) * 1024 / 24000.0 / (ms * 1e-3), 2), "distinct_lengths": len(set(rn)),
                                  "note": "pipelined like the headline; audio counted per utterance's own length; forced codes through the decode session"}
+        # (d) configs[4]: long-form 60 s utterances (n = 1406 codes -> T = 5624 frames), batch 4, the generator streamed in 256-frame
+        # windows on its own HIP stream: one blocking call, then 3 requests through the three-stream pipeline
+        if n_codes == N_CODES and B == 8 and os.environ.get("DTTS_BENCH_NO_LONGFORM") != "1":
+            LB, LN, LCH = 4, 1406, 256
+            lkw = dict(batch=True, sample_ids=sample_ids[:LB], max_generate_length=LN + 1, suppress_eos=True)
+            model.infer(text[:LB], tl[:LB], refer[:LB], rl[:LB], seed=4400, stream_vocoder=True, vocoder_chunk=LCH, **lkw)     # arena growth
+            torch.cuda.synchronize()
+            model.stage_ms = {}
+            ps = PowerSampler(local).start()
+            msl, lw = timed(lambda n: [model.infer(text[:LB], tl[:LB], refer[:LB], rl[:LB], seed=4401, stream_vocoder=True, vocoder_chunk=LCH, **lkw)], 1)
+            pwl = ps.stop()
+            lstage = {k: round(v, 1) for k, v in model.stage_ms.items()}
+            model.stage_ms = None
+            assert lw[0].shape[-1] == LN * 1024 and bool(torch.isfinite(lw[0]).all())
+            del lw
+            lreq = dict(text=text[:LB], text_length=tl[:LB], refer=refer[:LB], refer_lengths=rl[:LB], sample_ids=sample_ids[:LB])
+            msp, lo = timed(lambda n: list(model.infer_stream((dict(lreq, seed=4410 + i) for i in range(n)), max_generate_length=LN + 1,
+                                                              suppress_eos=True, vocoder_chunk=LCH)), 3)
+            assert all(l == [LN * 1024] * LB for _, l in lo)
+            del lo
+            laudio = LB * LN * 1024 / 24000.0
+            extra["longform"] = {"workload": "configs[4]: 60 s utterances (1406 codes, T = 5624 frames), batch 4, generator streamed in 256-frame windows "
+                                             "(dtts_vocoder_stream) on its own HIP stream", "batch": LB, "codes": LN, "vocoder_chunk_frames": LCH,
+                                 "blocking_s_per_call": round(msl * 1e-3, 3), "blocking_audio_s_per_s": round(laudio / (msl * 1e-3), 2),
+                                 "pipelined_s_per_request": round(msp * 1e-3, 3), "pipelined_audio_s_per_s": round(laudio / (msp * 1e-3), 2),
+                                 "stage_ms": lstage, "mean_W": pwl and pwl["mean_W"], "mean_sclk_MHz": pwl and pwl["mean_sclk_MHz"],
+                                 "note": "same weights, prompts and code path as the headline; the attention is O(T^2) at T = 5624 (36 x the headline's per frame)"}
     rank_ms = [dt / args.steps * 1e3]
     if multi:
         t = torch.zeros(world, device=dev, dtype=torch.float64)

@@ -140,6 +140,8 @@ struct GptTokenParams {
     int exclusive_cu;                // ask for a CU's whole LDS: one token workgroup per CU, no LDS-using workgroup next to it
     int prio;                        // s_setprio 3 for the kernel's waves (default 1)
     int poll_nap;                    // extra sleep rounds between two polls of an exchange word (default 0)
+    int ablate;                      // measurement only, results are garbage (DTTS_GPT_TOKEN_ABLATE): bit 0 = no weight loads (hops and CU hold as
+                                     // they are, no weight bytes), bit 1 = no waiting at the exchanges (weight bytes as they are, no hold), bit 2 = exit at once
     int min_rows;                    // smallest instantiation a session may take: 1 (default), 4 or 8 (e.g. 8: sessions of <= 4 rows run the 8-row kernel)
 };
 bool gpt_token_supported(int C, int H, int F, int NL, int V);

@@ -310,8 +310,13 @@ __device__ __forceinline__ const T* pin_v(const T* p) {
 }
 
 template <int KT>
-__device__ __forceinline__ void wload(float4 (&wr)[KT / 2], const float4* base, int tid) {
+__device__ __forceinline__ void wload(float4 (&wr)[KT / 2], const float4* base, int tid, bool skip = false) {
     base = pin_v(base);
+    if (skip) {                                    // DTTS_GPT_TOKEN_ABLATE bit 0 (measurement: the token's hops and hold without its weight bytes)
+#pragma unroll
+        for (int i = 0; i < KT / 2; ++i) wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < KT / 2; ++i) wr[i] = ldg4(base + (i * 256 + tid));
 }
@@ -395,8 +400,9 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
     const int tid_k = threadIdx.x, w = blockIdx.x;
-    PollState ps{p.err, false, p.poll_nap};
-    if (*p.err) return;                                   // a timed-out session stays dead (no 0.3 s of spinning per token)
+    PollState ps{p.err, (p.ablate & 2) != 0, p.poll_nap};      // (ablate bit 1: every poll takes whatever it finds)
+    const bool no_w = (p.ablate & 1) != 0;
+    if (*p.err || (p.ablate & 4)) return;                                   // a timed-out session stays dead (no 0.3 s of spinning per token)
     const unsigned epoch = *p.epoch;
     const GptCtl* ctl = p.ctl;
     const int B = p.B;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
     const int ah = w >> 3;
 
     float4 wq[Q_KT / 2];
-    wload<Q_KT>(wq, p.L[0].wq + (size_t)w * (Q_KT / 2) * 256, tid_k);
+    wload<Q_KT>(wq, p.L[0].wq + (size_t)w * (Q_KT / 2) * 256, tid_k, no_w);
     if (tid_k < 2 * NR) {                                 // layer 0's input (the sampler's plain rows) enters the same exchange as every other layer's
         const int b = tid_k >> 1, h = tid_k & 1;
         const float* x = p.x_in + b * TC + NP * w + 3 * h;
@@ -642,9 +648,9 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         STAMP(3);
         // prefetch for P2b / P3: the c_proj and c_fc slices
         float4 wp[P_KT / 2];
-        wload<P_KT>(wp, L.wp + (size_t)w * (P_KT / 2) * 256, tid);
+        wload<P_KT>(wp, L.wp + (size_t)w * (P_KT / 2) * 256, tid, no_w);
         float4 wf[F_KT / 2];
-        wload<F_KT>(wf, L.wf + (size_t)w * (F_KT / 2) * 256, tid);
+        wload<F_KT>(wf, L.wf + (size_t)w * (F_KT / 2) * 256, tid, no_w);
         // ------------------------------------------------------------------------------------------------ P2b: c_proj + residual
         q_poll8(xc, [&](int b) { return AB + b * XQ + tid; }, tag, v, ps);
         STAMP(4);
@@ -674,10 +680,15 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
         {
             typedef float f3 __attribute__((ext_vector_type(3)));
             const float* src = pin_v(L.w2 + (size_t)(NF * w) * TC) + 3 * tid;
+            if (no_w) {
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const f3 t = *GLOBAL_PTR(f3, src + j * TC);
-                w2[j][0] = t.x; w2[j][1] = t.y; w2[j][2] = t.z;
+                for (int j = 0; j < NF; ++j) w2[j][0] = w2[j][1] = w2[j][2] = 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const f3 t = *GLOBAL_PTR(f3, src + j * TC);
+                    w2[j][0] = t.x; w2[j][1] = t.y; w2[j][2] = t.z;
+                }
             }
         }
 #pragma unroll
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
                 q_store(xc, RB + (owner * TG + w) * RS_Q + (j - owner * RS_Q), r[0], r[1], r[2], tag);
             }
             // prefetch for the next layer's P1 (unconditional: a conditional reload keeps the old slice live across the whole layer)
-            wload<Q_KT>(wq, p.L[l + 1 < p.NL ? l + 1 : l].wq + (size_t)w * (Q_KT / 2) * 256, tid);
+            wload<Q_KT>(wq, p.L[l + 1 < p.NL ? l + 1 : l].wq + (size_t)w * (Q_KT / 2) * 256, tid, no_w);
         }
         STAMP(7);
         // ------------------------------------------------------------------------------------------------ P5: owner sum -> next X
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
     {
         const int tid = tid_k, l = p.NL;
         float4 wh[H_KT / 2];
-        wload<H_KT>(wh, p.wh + (size_t)(w * 3) * (H_KT / 2) * 256, tid);
+        wload<H_KT>(wh, p.wh + (size_t)(w * 3) * (H_KT / 2) * 256, tid, no_w);
         float v[NR][3];
         q_poll8(xc, [&](int b) { return XB + b * XQ + tid; }, (epoch << 4) | (unsigned)p.NL, v, ps);
         STAMP(0);
@@ -811,7 +822,7 @@ __global__ __launch_bounds__(256) void gpt_token_kernel(const GptTokenParams p) 
             constexpr int OH = (NR * NH + 255) / 256;
             float rh[OH];
             col_gemv<NR, H_PN, H_KL, H_KT>(wh, sm, tid, rh);
-            if (pass < 2) wload<H_KT>(wh, p.wh + (size_t)(w * 3 + pass + 1) * (H_KT / 2) * 256, tid);
+            if (pass < 2) wload<H_KT>(wh, p.wh + (size_t)(w * 3 + pass + 1) * (H_KT / 2) * 256, tid, no_w);
 #pragma unroll
             for (int j = 0; j < OH; ++j) {
                 const int o = tid + 256 * j;

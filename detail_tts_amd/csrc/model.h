@@ -367,6 +367,7 @@ private:
                                           // same launches issued eagerly on ROCm 7.2 / MI355X: DESIGN.md section 4)
 
     bool opt_two_streams_ = true;
+    int prof_rot_ = 0;               // precompute_integrator calls so far: rotates the chunk pairs the profiler brackets
     bool opt_voc_x3_ = true;         // stage C's split-precision kernels (ResBlock1 convs, WaveNet in_layers); 0 = exact fp32 (cannot saturate)
     int opt_x3_fault_ = 0;           // test hook (option x3_fault)
     bool opt_voc_chain_ = true;      // ResBlock1 (wide generator stages): conv epilogues write the next conv's planes (resblock1_fwd)

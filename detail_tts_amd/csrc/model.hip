@@ -995,9 +995,13 @@ void Model::precompute_integrator(const float* cbuf0, const int* lens_i_host, in
     }
     std::vector<int> lv(Bv), sv(Bv);
     int ci = 0;
+    // profile sampling: both lanes of a chunk pair, or neither - and WHICH pairs rotates from call to call, so that over step_every calls
+    // every pair is bracketed exactly once: the bracketed share of this pre-pass is 1 / step_every like the loop's (a fixed choice of
+    // pairs 0 and 5 of 7 bracketed 32 % of it, and bench.py's busy share - union x step_every - counted the pre-pass 1.6 x: VERDICT r05)
+    const int prof_rot = prof_rot_++;
     for (int k0 = 0; k0 < NS; k0 += J, ++ci) {
         const Lane& L = lanes[piped ? (ci ? 1 : 0) : (two ? (ci & 1) : 0)];
-        Profiler::gate() = ((ci / 2) % Profiler::get().step_every) == 0;      // both lanes of a chunk pair, or neither
+        Profiler::gate() = ((ci / 2 + prof_rot) % Profiler::get().step_every) == 0;
         const int jn = std::min(J, NS - k0), nb = jn * Bi;
         for (int j = 0; j < jn; ++j)
             for (int b = 0; b < Bi; ++b) {

@@ -396,8 +396,10 @@ void Model::gpt_step_launches(hipStream_t s) {
         p.exclusive_cu = env_excl >= 0 ? env_excl : (opt_tok_exclusive_ ? 1 : 0);
         static const int env_prio = []() { const char* v = getenv("DTTS_GPT_TOKEN_PRIO"); return v ? atoi(v) : 1; }();
         static const int env_nap = []() { const char* v = getenv("DTTS_GPT_TOKEN_NAP"); return v ? atoi(v) : 0; }();
+        static const int env_ablate = []() { const char* v = getenv("DTTS_GPT_TOKEN_ABLATE"); return v ? atoi(v) : 0; }();
         p.prio = env_prio;
         p.poll_nap = env_nap;
+        p.ablate = env_ablate;
         static const int env_min_rows = []() { const char* v = getenv("DTTS_GPT_TOKEN_MIN_ROWS"); return v ? atoi(v) : 0; }();
         p.min_rows = env_min_rows ? env_min_rows : opt_tok_min_rows_;
         if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)

@@ -306,6 +306,74 @@ def test_infer_stream_pipeline_equals_infer(model, suppress_eos):
     assert list(model.infer_stream(iter([]))) == []
 
 
+def test_infer_stream_reruns_a_saturated_request_on_fp32_and_keeps_draining(model):
+    """a stage C that saturated its split-precision planes used to raise out of the generator and lose every later request.  Now
+    THAT request's stage C runs again on the exact fp32 kernels (option voc_x3 = 0) and the stream goes on: requests 0 and 2 equal their
+    blocking infer() bit for bit, request 1 (fault hook x3_fault: its ticket is raised as saturated) equals the blocking call made with
+    voc_x3 = 0; on_saturation="raise" keeps the old behaviour."""
+    from detail_tts_amd.runtime import DttsError
+    rs = np.random.RandomState(19)
+    reqs = []
+    for i, (B, Tr, Lt) in enumerate([(2, 200, 10), (2, 180, 9), (1, 220, 12)]):
+        refer = torch.from_numpy((rs.randn(B, 128, Tr) * 2 - 5).astype(np.float32))
+        text = torch.from_numpy(np.concatenate([rs.randint(3, 255, (B, Lt)), np.zeros((B, 1), np.int64)], 1).astype(np.int32))
+        reqs.append(dict(text=text, text_length=torch.full((B,), Lt + 1), refer=refer, refer_lengths=torch.full((B,), Tr), seed=700 + i,
+                         sample_ids=[10 * i + b for b in range(B)]))
+    G = 14
+
+    def blocking(r):
+        return model.infer(r["text"], r["text_length"], r["refer"], r["refer_lengths"], batch=True, seed=r["seed"], sample_ids=r["sample_ids"],
+                           max_generate_length=G, suppress_eos=True)
+    ref = [blocking(r) for r in reqs]
+    model.rt.set_option("voc_x3", 0)
+    try:
+        ref1_fp32 = blocking(reqs[1])
+        assert not model.rt.vocoder_check_active()
+    finally:
+        model.rt.set_option("voc_x3", 1)
+    before = model.saturated_requests
+    model.rt.set_option("x3_fault", 2)                   # the second stage-C call from now on
+    outs = list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=True))
+    assert len(outs) == 3 and model.saturated_requests == before + 1
+    assert torch.equal(outs[0][0], ref[0]) and torch.equal(outs[2][0], ref[2])
+    assert torch.equal(outs[1][0], ref1_fp32)
+    tol("stage_c_fp32_vs_split_precision_rms", float((outs[1][0] - ref[1]).pow(2).mean().sqrt()), 1e-7)
+    model.rt.set_option("x3_fault", 1)
+    with pytest.raises(DttsError, match="voc_x3"):
+        list(model.infer_stream(iter(reqs), max_generate_length=G, suppress_eos=True, on_saturation="raise"))
+    assert torch.equal(blocking(reqs[0]), ref[0])        # the handle is usable afterwards
+
+
+def test_gpt_options_struct_is_versioned_and_range_checked(model):
+    """dtts_gpt_options carries its size (a caller built against another layout fails loudly) and out-of-range sampling
+    parameters - typical_mass in particular, which any stray value in (0, 1) would switch ON - are rejected."""
+    import ctypes as C
+    from detail_tts_amd import _lib
+    from detail_tts_amd.runtime import DttsError
+    rt = model.rt
+    o = _lib.DttsGptOptions()
+    rt.lib.dtts_gpt_options_init(C.byref(o))
+    assert o.struct_size == C.sizeof(_lib.DttsGptOptions) and o.top_k == 50 and abs(o.top_p - 0.8) < 1e-7 and o.typical_mass == 0.0
+    assert abs(o.temperature - 0.8) < 1e-7 and o.repetition_penalty == 2.0 and o.max_generate_length == 600 and not o.forced_codes
+    rs = np.random.RandomState(3)
+    refer = torch.from_numpy((rs.randn(1, 128, 40) * 2 - 5).astype(np.float32)).cuda()
+    text = [np.array([5, 9, 0], np.int32)]
+    rt.gpt_generate(refer, [40], text, 1, [0], max_generate_length=3)                   # the normal call works
+    for bad in (dict(typical_mass=1.5), dict(typical_mass=float("nan")), dict(typical_mass=-0.2), dict(temperature=0.0), dict(top_p=1.5)):
+        with pytest.raises(DttsError, match="options"):
+            rt.gpt_generate(refer, [40], text, 1, [0], max_generate_length=3, **bad)
+    # a struct that did not come from dtts_gpt_options_init (size 0): refused
+    ids = np.zeros(1, np.int32)
+    o2 = _lib.DttsGptOptions()
+    o2.sample_ids, o2.max_generate_length, o2.temperature, o2.top_p, o2.repetition_penalty = ids.ctypes.data_as(_lib.c_int_p), 3, 0.8, 0.8, 2.0
+    tx = np.array([[5, 9, 0]], np.int32)
+    tl = np.array([3], np.int32)
+    codes, nc = np.zeros((1, 3), np.int32), np.zeros(1, np.int32)
+    rc = rt.lib.dtts_gpt_generate(rt.h, C.c_void_p(refer.data_ptr()), None, 40, tx.ctypes.data_as(_lib.c_int_p), tl.ctypes.data_as(_lib.c_int_p), 3, 1,
+                                  C.byref(o2), codes.ctypes.data_as(_lib.c_int_p), nc.ctypes.data_as(_lib.c_int_p), None, 3, rt._stream())
+    assert rc != 0 and b"struct_size" in rt.lib.dtts_last_error(rt.h)
+
+
 def test_infer_stream_closed_early_leaves_the_handle_usable(model):
     """Abandoning the generator after the first result waits for the decode session in flight; a plain infer() afterwards is unaffected."""
     rs = np.random.RandomState(10)
