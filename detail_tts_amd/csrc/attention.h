@@ -28,6 +28,11 @@ struct AttnParams {
     int x3_tp = 0;
     // x3 only: q / k / v come as AttnPlanes images (qkv is ignored) written by the qkv conv
     const void* planes = nullptr;
+    // attention_x3b only (set by its launcher): the keys of a (sample, head, query block) split over `ksplit` workgroups, whose waves
+    // leave their unnormalised (O, l, m) in kpart; the last wave to arrive (kcount) merges them in split order
+    int ksplit = 1;
+    float* kpart = nullptr;
+    int* kcount = nullptr;
 };
 
 // Operand images of the split-precision attention (head dim 48), written by the qkv conv's epilogue (conv_x3.hip) and consumed by
@@ -50,6 +55,8 @@ void launch_flash_attention(const AttnParams& p, hipStream_t stream);
 void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3 (fp32 q, k, v)
 void launch_flash_attention_x3w(const AttnParams& p, hipStream_t stream);  // ... when the operands are AttnPlanes images (round 2-4 kernel: DTTS_ATTN_KERNEL=w)
 void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream);  // ... the block-skewed kernel (default)
+void set_attn_ksplit(int n);      // key ranges per (sample, head, query block) of attention_x3b launches of <= 2 samples: 1 = off, 2 (default) .. 4; process-wide
+int attn_ksplit();
 
 // VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)
 //   relk[b,h,t,r] = scale * sum_c q[c,t] * Ek[r][c]

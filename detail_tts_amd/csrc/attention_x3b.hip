@@ -24,6 +24,7 @@
 // Vector instructions per launch 1.92e7 -> 1.51e7 (rocprofv3 SQ_INSTS_VALU, B = 8, T = 936), 102.6 -> 94.5 us alone
 // (profiles/r05_attn_ablate_pipelined.txt); under the bench the chip runs at its 1400 W power limit (profiles/r05_power_bench.txt:
 // 1340 - 1360 W, 1.97 GHz) and the step time does not move (DESIGN.md par. 4).
+#include <atomic>
 #include <type_traits>
 
 #include "attention.h"
@@ -284,7 +285,7 @@ __device__ __forceinline__ void mfma_result_fence(f16v& a, f16v& b) {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b));
 }
 
-template <int MINB, int ABL>
+template <int MINB, int ABL, bool KSPLIT = false>
 __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnParams p) {
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int NW = 4, QPB = NW * QPW;
@@ -294,7 +295,11 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane & 31, hh = lane >> 5;
     const int nqb = (p.T + QPB - 1) / QPB;
-    const int Lid = xcd_remap(blockIdx.x, gridDim.x);
+    // KSPLIT: the keys of a (head, sample, query block) are cut into p.ksplit ranges of whole 64-key tiles, one workgroup each (adjacent
+    // ids: one XCD, one K / V image); launches of <= 2 samples only (batch 1: a wave's 30-block serial chain is what a launch takes)
+    const int S = KSPLIT ? p.ksplit : 1;
+    const int Lall = xcd_remap(blockIdx.x, gridDim.x);
+    const int Lid = KSPLIT ? Lall / S : Lall, zsp = KSPLIT ? Lall - Lid * S : 0;
     const int qb = Lid % nqb, hb = Lid / nqb;
     // ids in (head, sample, query block) order: an XCD's contiguous share of the grid is two heads of EVERY sample.  In (sample, head, ...)
     // order an XCD held ONE sample's 16 heads, so a ragged batch took as long as its longest row (attention work ~ len^2) while the
@@ -318,7 +323,11 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     const float bias_lo = p.bias_tab[h * (2 * BIAS_CLIP + 1)] * LOG2E, bias_hi = p.bias_tab[h * (2 * BIAS_CLIP + 1) + 2 * BIAS_CLIP] * LOG2E;
 
     const int tq0 = q0 + wave * QPW, t = tq0 + q;
-    const int ntiles = (len + KT - 1) / KT, nblk = 2 * ntiles;
+    const int ntiles_all = (len + KT - 1) / KT;
+    // this workgroup's tiles [jt0, jt0 + ntiles) of the sample's ntiles_all; everything below counts tiles and blocks from jt0 (`boff` =
+    // the absolute index of local block 0 enters where a key's POSITION matters: bias classes, bias table, length mask)
+    const int jt0 = KSPLIT ? zsp * ntiles_all / S : 0;
+    const int ntiles = KSPLIT ? (zsp + 1) * ntiles_all / S - jt0 : ntiles_all, nblk = 2 * ntiles, boff = 2 * jt0;
     const bool wave_active = tq0 < len;
 
     // LDS-DMA of what iteration j1 needs (issued one iteration ahead): K tile j1 and V tile j1 - 1 = blocks 2 j1 - 2, 2 j1 - 1 (the PV
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     // [plane][j][hh][channel].  Every piece is unconditionally live: a tile index outside the sequence is clamped (the piece lands in
     // a stage / slot nobody reads before it is overwritten).
     const unsigned lane16 = lane * 16;
-    const unsigned char* lane_img = kvimg + lane16;
+    const unsigned char* lane_img = kvimg + lane16 + (size_t)jt0 * AttnPlanes::TILE_BYTES;
     auto dma_group = [&](int j1) __attribute__((always_inline)) {
         const int kt = j1 < ntiles ? j1 : ntiles - 1, vt = j1 < 1 ? 0 : j1 - 1;
         const unsigned char* ksrc = lane_img + (size_t)kt * AttnPlanes::TILE_BYTES + wave * 1024;
@@ -362,9 +371,12 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     st.alpha = 1.f;
     st.need = 0;
 
+    const bool empty = KSPLIT && ntiles == 0;          // fewer tiles than splits: this range has no keys (workgroup-uniform)
+    if (!empty) {
     dma_group(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }
 
     // per-lane LDS byte offsets: K chunk (plane 0, c8 = hh, key q); V chunks (plane 0, j 0, hh, channel vch) of a ring slot: channel
     // ct 32 + q; lanes q >= 16 of the second channel tile (accumulator rows 48..63) read the ones area, whatever the slot: row 48 = sum of P
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
         const unsigned kb_addr = k_lane + ((bq >> 1) & 1) * KBYTES + (bq & 1) * (32 * 16);
         const unsigned voff = (bv & 3) * VSLOT;
         const unsigned va0 = v_lane0 + voff, va1 = v_lane1 + (voff & slot_mask1);
-        const int s0b = bs * 32;
+        const int s0b = (bs + boff) * 32;
         const bool far_hi = s0b - (tq0 + QPW - 1) >= BIAS_CLIP, far_lo = (s0b + 31) - tq0 <= -BIAS_CLIP;
         const int lim = len - s0b - 4 * hh;                                  // key of register r is valid iff roff(r) < lim
         const float bfar = far_hi ? bias_hi : bias_lo;
@@ -395,6 +407,8 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
 
     // Waves whose 32 queries all lie beyond the length only stage their share of the tiles (same barriers); the active ones run the
     // steps.  Two separate loops: a per-iteration `if (active)` is a join with the accumulators live on both sides.
+    if (!wave_active && empty) return;
+    if (!empty) {
     dma_group(1);
     if (!wave_active) {
         for (int j = 1; j <= ((ABL & 2) ? 1 : ntiles); ++j) {
@@ -424,9 +438,10 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     };
     {
         // blocks b with 32 b + 31 - tq0 <= -64 are far below, with 32 b - (tq0 + 31) >= 64 far above; blocks >= bmask reach beyond len
-        const int b_lo_end = (tq0 - BIAS_CLIP - 31 >= 0) ? (tq0 - BIAS_CLIP - 31) / 32 + 1 : 0;      // first block that is not far below
-        const int b_hi_beg = (tq0 + QPW - 1 + BIAS_CLIP + 31) / 32;                                  // first block that is far above
-        const int bmask = len / 32;                                                                  // first block with a key >= len
+        auto rel = [&](int v) { return v > boff ? v - boff : 0; };                                   // absolute -> local block index
+        const int b_lo_end = rel((tq0 - BIAS_CLIP - 31 >= 0) ? (tq0 - BIAS_CLIP - 31) / 32 + 1 : 0);      // first block that is not far below
+        const int b_hi_beg = rel((tq0 + QPW - 1 + BIAS_CLIP + 31) / 32);                                  // first block that is far above
+        const int bmask = rel(len / 32);                                                                  // first block with a key >= len
         auto clampj = [&](int v) { return v < 1 ? 1 : (v > ntiles ? ntiles : v); };
         // iteration j is FAR-below iff 2 j < b_lo_end, FAR-above iff 2 j - 1 >= b_hi_beg; masked iff 2 j >= bmask
         const int jA = clampj(b_lo_end / 2 + ((b_lo_end & 1) ? 1 : 0));            // first j with 2 j >= b_lo_end  (= ceil(b_lo_end / 2))
@@ -445,8 +460,43 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
     // V(ntiles - 1) arrived with the last group: the last softmax with the PV product before it, then the PV product of the last block
     step(nblk - 1, P1{}, T0{}, T1{}, T1{}, T1{});
     step(nblk, P0{}, T0{}, T1{}, T0{}, T1{});
+    }      // !empty
 
     mfma_result_fence(st.oacc[0], st.oacc[1]);
+    if (KSPLIT && S > 1) {
+        // This wave's (O 24 values, l, m) per lane -> its slab (lane-contiguous runs: 26 x 256 floats per workgroup); the LAST wave of
+        // the S to arrive merges them in split order, its own included, from memory - the result never depends on who arrives last:
+        // O = sum_z O_z 2^(m_z - M), l likewise, M = max_z m_z (m is the lazy running maximum the P of that range were taken against,
+        // log2 domain; an empty range left m = -inf, O = l = 0).  Agent-scope (sc1) accesses as in conv_x3's split-K: coherent across the
+        // XCDs without a release / acquire fence pair's bulk L2 write-back.  Per WAVE: no workgroup barrier, inactive waves never arrive.
+        float* slab = p.kpart + ((size_t)Lid * S) * X3_SLAB_FLOATS;
+        float* mine = slab + (size_t)zsp * X3_SLAB_FLOATS + tid;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + r * 256, st.oacc[0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) __hip_atomic_store(mine + (16 + r) * 256, st.oacc[1][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 25 * 256, st.m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have reached the coherent level
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(p.kcount + Lid * NW + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != S - 1) return;
+        if (lane == 0) __hip_atomic_store(p.kcount + Lid * NW + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+        float M = -INFINITY;
+        for (int zz = 0; zz < S; ++zz)
+            M = fmaxf(M, __hip_atomic_load(slab + (size_t)zz * X3_SLAB_FLOATS + tid + 25 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.oacc[0][r] = st.oacc[1][r] = 0.f;
+        for (int zz = 0; zz < S; ++zz) {
+            const float* src = slab + (size_t)zz * X3_SLAB_FLOATS + tid;
+            const float mz = __hip_atomic_load(src + 25 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float sc = mz == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mz - M);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.oacc[0][r] = fmaf(sc, __hip_atomic_load(src + r * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), st.oacc[0][r]);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) st.oacc[1][r] = fmaf(sc, __hip_atomic_load(src + (16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), st.oacc[1][r]);
+        }
+    }
     if (t >= len) return;
     const float inv = 1.f / st.oacc[1][8];              // acc = (1024 P)(16 V); row 48 = (1024 P)(16): the denominator at V's scale
     // lane (q, hh) holds channels ct 32 + 8 rg + 4 hh + (0..3) of query t: half hh of the 8-channel chunk ct 4 + rg
@@ -477,18 +527,54 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
 }
 }  // namespace
 
+// option "attn_ksplit" / DTTS_ATTN_KSPLIT (process-wide, like ln_reg): 1 = off, 2 (default) .. 4
+static std::atomic<int> g_attn_ksplit{-1};
+void set_attn_ksplit(int n) { g_attn_ksplit.store(n < 1 ? 1 : (n > 4 ? 4 : n), std::memory_order_relaxed); }
+int attn_ksplit() {
+    int v = g_attn_ksplit.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("DTTS_ATTN_KSPLIT");
+        set_attn_ksplit(e ? atoi(e) : 2);
+        v = g_attn_ksplit.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // operands = AttnPlanes images (p.planes)
 void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream) {
     DTTS_REQUIRE(p.D == 48 && p.bias_tab && !p.causal && !p.band && !p.ml_out && p.planes, "attention_x3b covers head dim 48 with the T5 bias on operand images");
     constexpr int NW = 4;
     // workgroups per CU: 2 (218 registers; 1024 workgroups of the headline launch = two full rounds of 512) or, DTTS_ATTN_OCC=3, 3 (spills)
     static const int occ = []() { const char* v = getenv("DTTS_ATTN_OCC"); return v ? atoi(v) : 2; }();
-    const dim3 grid(cdiv(p.T, NW * QPW) * p.H * p.B);
+    const int base = cdiv(p.T, NW * QPW) * p.H * p.B;
     static const int abl = []() { const char* v = getenv("DTTS_ATTN_ABLATE"); return v ? atoi(v) : 0; }();
+    // Key split (round 6): launches of <= 2 samples (the batch-1 CFG pair, single-sample unit calls) cannot fill the chip with
+    // (head, sample, 128-query) workgroups - 256 at T = 936 - and take what ONE wave's serial walk over all 30 key blocks takes.  There
+    // the keys are cut into S ranges, one workgroup each, merged by the last wave to arrive.  Larger launches (the headline's 8-sample
+    // chunks) keep one workgroup per query block: bit-identical to round 5.  DTTS_ATTN_KSPLIT = S (default 2; 1 = off), only while
+    // S x workgroups fit one round of the chip at two workgroups per CU.
+    const int ks_env = attn_ksplit();
+    static const int ks_maxb = []() { const char* v = getenv("DTTS_ATTN_KSPLIT_MAXB"); return v ? atoi(v) : 2; }();
+    int S = 1;
+    if (!abl && p.B <= ks_maxb && ks_env > 1 && AttnPlanes::nt64(p.T) >= 2 * ks_env) {
+        S = ks_env;
+        while (S > 1 && ((size_t)base * S > X3_MAX_SLABS || (size_t)base * NW > X3_SPLIT_COUNTERS)) --S;
+    }
+    const dim3 grid(base * S);
     auto go = [&](auto kern) {
         lds_optin(reinterpret_cast<const void*>(kern), LDS_BYTES);
         hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS_BYTES, stream, p);
     };
+    if (S > 1) {
+        AttnParams q = p;
+        q.ksplit = S;
+        x3_split_workspace(stream, (size_t)base * S, &q.kpart, &q.kcount);
+        auto kern = flash_attn_x3b_kernel<2, 0, true>;
+        lds_optin(reinterpret_cast<const void*>(kern), LDS_BYTES);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS_BYTES, stream, q);
+        DTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     if (abl) {          // measurement builds (garbage results): which ingredient of the loop costs what (DESIGN.md par. 4)
         switch (abl) {
             case 1: go(flash_attn_x3b_kernel<2, 1>); break;

@@ -41,6 +41,12 @@ void launch_gn_split_planes(const float* x, long long x_bs, int x_cs, const int*
 // as a 1x1 conv without residual (EPI 4: the WaveNet in_layers over launch_split_planes_taps planes)
 void launch_conv_x3(const ConvParams& p, hipStream_t s);
 
+// Split scratch of a launch stream (conv_x3's split-K slabs; the trunk attention's key-split partials use the same slot: launches on one
+// stream are ordered): `part` = nslabs slabs of X3_SLAB_FLOATS floats, `count` = X3_SPLIT_COUNTERS arrival counters that are zero
+// between launches (the reducing workgroup / wave resets its counter).
+constexpr size_t X3_SLAB_FLOATS = 96 * 256, X3_MAX_SLABS = 1024, X3_SPLIT_COUNTERS = 4096;
+void x3_split_workspace(hipStream_t s, size_t nslabs, float** part, int** count);
+
 // ---- fused GroupNorm (p.gn_out3): the norm + activation + split that FOLLOWS a trunk conv runs in that conv's epilogue.  A tile holds
 // 128 rows x 192 columns of one sample; a GroupNorm group is 24 channels x all T columns, so a tile needs the statistics of the <= 7
 // groups its rows touch over ALL N tiles (and, for the groups that straddle its row range, of the neighbouring M tile).  Every wave

@@ -1197,7 +1197,7 @@ struct KSplitWs {
 };
 KSplitWs ksplit_workspace(hipStream_t s, size_t nslabs) {
     constexpr int SLOTS = 8;
-    constexpr size_t MAX_SLABS = 1024, MAX_TILES = 512;
+    constexpr size_t MAX_SLABS = X3_MAX_SLABS, MAX_TILES = X3_SPLIT_COUNTERS;
     static std::mutex mu;
     static hipStream_t owner[SLOTS];
     static int owner_dev[SLOTS];
@@ -1233,6 +1233,12 @@ KSplitWs ksplit_workspace(hipStream_t s, size_t nslabs) {
     return {part[k], count[k]};
 }
 }  // namespace
+
+void x3_split_workspace(hipStream_t s, size_t nslabs, float** part, int** count) {
+    const KSplitWs w = ksplit_workspace(s, nslabs);
+    *part = w.part;
+    *count = w.count;
+}
 
 size_t conv_x3_gn_xch_bytes(int B, int Cout, int T) { return (size_t)B * (Cout / 8) * cdiv(T, BN) * 2 * 16; }
 

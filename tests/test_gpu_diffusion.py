@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from conftest import tol
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -129,6 +131,40 @@ def test_attention_block_with_growing_scores_rescales_mid_sequence(rt, weights):
     for b, L in enumerate(lens):
         ref = D.attention_block(weights, p, x[b:b + 1, :, :L], 16)[0]
         assert maxabs(y[b, :, :L], ref) < 2e-4 * max(1.0, float(np.abs(ref).max())), (b, maxabs(y[b, :, :L], ref), float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("S", [2, 3, 4])
+def test_attention_key_split_of_small_launches_vs_unsplit_and_oracle(rt, weights, S):
+    """Round 6: launches of <= 2 samples cut the keys of every (sample, head, 128-query block) into S ranges of
+    whole 64-key tiles, one workgroup each; the last wave to arrive merges the (O, l, m) partials in split order.  Against the unsplit
+    kernel (fp32 summation-order noise only) and against the dense oracle: a ragged pair whose short row has FEWER tiles than splits
+    (empty ranges), lengths on / off tile edges, growing scores (the lazy maximum differs between ranges), repeated (the arrival
+    counters are back at zero after every launch; the merge never depends on who arrives last: bit-identical)."""
+    from oracle import diffusion as D
+    rs = np.random.RandomState(50 + S)
+    T, lens = 700, [700, 40]
+    ramp = (0.3 + 2.7 * np.arange(T) / T).astype(np.float32)
+    x = (rs.randn(2, 768, T) * ramp[None, None, :]).astype(np.float32)
+    p = "diffusion.layers.5.attn"
+    try:
+        rt.set_option("attn_ksplit", 1)
+        y1 = host(rt.op_attention_block(p, dev(x), lens))
+        rt.set_option("attn_ksplit", S)
+        ys = host(rt.op_attention_block(p, dev(x), lens))
+        again = [host(rt.op_attention_block(p, dev(x), lens)) for _ in range(3)]
+        one = host(rt.op_attention_block(p, dev(x[:1, :, :576]), [512]))
+        rt.set_option("attn_ksplit", 1)
+        one1 = host(rt.op_attention_block(p, dev(x[:1, :, :576]), [512]))
+    finally:
+        rt.set_option("attn_ksplit", 2)
+    assert all(np.array_equal(a, ys) for a in again)
+    for b, L in enumerate(lens):
+        ref = D.attention_block(weights, p, x[b:b + 1, :, :L], 16)[0]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert maxabs(ys[b, :, :L], ref) < 2e-4 * scale, (b, maxabs(ys[b, :, :L], ref))
+        tol(f"attn_ksplit{S}_vs_unsplit_row{b}", maxabs(ys[b, :, :L], y1[b, :, :L]) / scale, 2e-5)
+    assert float(np.abs(ys - y1).max()) > 0.0          # the split path did run
+    tol(f"attn_ksplit{S}_single_sample_vs_unsplit", maxabs(one[0, :, :512], one1[0, :, :512]) / max(1.0, float(np.abs(one1).max())), 2e-5)
 
 
 def test_attention_block_1536(rt, weights):
