@@ -340,7 +340,9 @@ private:
     GptTokenParams tokp_;                 // its launch parameters (weight side filled at bind time, session side at prefill)
     bool tok_ok_ = false;                 // the model has the shape the token kernel is written for
     bool opt_gpt_token_ = true;           // option "gpt_token_kernel"
-    bool opt_tok_exclusive_ = true;       // option "gpt_token_exclusive_cu": the token kernel asks for whole CUs
+    bool opt_tok_exclusive_ = false;      // option "gpt_token_exclusive_cu": 1 = the token kernel asks for whole CUs (a CU's whole LDS).  Default 0 since round 6:
+                                          // 2 x 500 headline requests through infer_stream, one run per setting, every waveform bit-identical to its
+                                          // blocking infer() (profiles/r06_soak.txt), and sharing is 0.4 - 0.55 % faster
     int opt_tok_min_rows_ = 1;            // option "gpt_token_min_rows": 1-row sessions take the 1-row token kernel, <= 4 rows the 4-row one (4 / 8: the smallest instantiation allowed)
     bool tok_failed_ = false;             // an exchange timed out once: this handle stays on the chain (until the option is set again)
     int opt_tok_fault_ = 0;               // option "gpt_token_fault"

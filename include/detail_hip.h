@@ -267,9 +267,15 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 Bound only when the device can hold its 128 workgroups at once (>= 128 CUs, opt-in LDS); if an exchange of a
  *                 running session ever times out, dtts_gpt_finish replays that session on the chain (same codes as the chain) and the
  *                 handle stays on the chain until this option is set to 1 again;
- *   "gpt_token_exclusive_cu" (default 1): the token kernel asks for a CU's whole LDS, so no LDS-using workgroup shares its CUs;
- *                 0 = it shares CUs with whatever else runs.  A scheduling policy, not a correctness requirement (both settings are
- *                 stress-tested bit-identical under stage B / C loads); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
+ *   "gpt_token_exclusive_cu" (default 0 since round 6): 1 = the token kernel asks for a CU's whole LDS, so no LDS-using workgroup
+ *                 shares its CUs; 0 = it shares CUs with whatever else runs (0.4 - 0.55 % faster under the request pipeline).  A
+ *                 scheduling policy, not a correctness requirement: both settings are stress-tested bit-identical under stage B / C
+ *                 loads and soaked over 500 pipelined headline requests each (profiles/r06_soak.txt); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
+ *   "attn_ksplit" (default 2; process-wide): trunk-attention launches of <= 2 samples (the batch-1 CFG pair) cut the keys of every
+ *                 (sample, head, 128-query block) into that many ranges, one workgroup each, merged by the last wave to arrive in split
+ *                 order (deterministic; fp32 summation-order noise against 1 = off); larger launches are unaffected; env DTTS_ATTN_KSPLIT;
+ *   "voc_x3"      (default 1): 0 = stage C alone on the exact fp32 kernels (cannot saturate; what infer_stream re-runs a saturated
+ *                 request with); "x3_fault" n (test hook): the n-th stage-C ticket from now on is raised as saturated;
  *   "gpt_token_min_rows" (default 1): the smallest instantiation of the token kernel a session may take: 1-row sessions run the
  *                 1-row kernel, sessions of <= 4 rows the 4-row one (round 5: the batch-1 latency case; per row bit-identical to the
  *                 8-row one); 4 / 8 = the smallest allowed is the 4- / 8-row kernel; env DTTS_GPT_TOKEN_MIN_ROWS;

@@ -478,7 +478,7 @@ def test_token_kernel_under_concurrent_load(model, load, exclusive, rows):
         assert not failed, failed
         assert rounds[0] >= 2, "the load did not run next to the sessions"
     finally:
-        rt.set_option("gpt_token_exclusive_cu", 1)
+        rt.set_option("gpt_token_exclusive_cu", 0)        # the default since round 6 (profiles/r06_soak.txt)
 
 
 def test_token_kernel_timeout_is_replayed_on_the_chain(model):

@@ -85,7 +85,7 @@ def main():
         total_bad += len(bad)
         print(f"exclusive_cu={setting}: {REQUESTS} requests in {dt:.1f} s ({dt / REQUESTS * 1e3:.1f} ms per request), {len(bad)} mismatching waveforms {bad[:16]}; "
               f"saturated requests re-run on fp32: {m.saturated_requests}; board power {pw}", flush=True)
-    m.rt.set_option("gpt_token_exclusive_cu", 1)
+    m.rt.set_option("gpt_token_exclusive_cu", 0)
     print("SOAK CLEAN" if total_bad == 0 else f"SOAK FOUND {total_bad} MISMATCHES")
     return 1 if total_bad else 0
 
