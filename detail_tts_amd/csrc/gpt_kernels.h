@@ -112,10 +112,13 @@ constexpr int GPT_TOKEN_WGS = 128;
 constexpr int GPT_TOKEN_MAX_LAYERS = 12;
 constexpr int GPT_TOKEN_VS = 66 * GPT_TOKEN_WGS;                     // logits row stride (mel_head columns padded to 66 per workgroup)
 constexpr int GPT_TOKEN_ROWS = 16;                                   // rows of a session the token kernel covers (four instantiations: 1, 4, 8 and 16)
+constexpr int GPT_TOKEN_W2_WORDS = 18;                               // float4 per thread and virtual workgroup of the packed mlp c_proj (24 rows x 3 columns)
+constexpr int GPT_TOKEN_N_WINDOW = 24;                               // gpt_token_n.hip: weight words (float4) a thread keeps in flight
 constexpr int GPT_TOKEN_XCH_WORDS = 2 * (16 * 256 * 6 + 128 * 128 * 32);     // exchange arena of a 16-row session in 8-byte units (addressed in 16-byte words)
 struct GptTokenLayer {
     const float4 *wq, *wp, *wf;      // c_attn / attention c_proj / c_fc repacked in register order (launch_gpt_token_pack 0 / 1 / 2)
     const float* w2;                 // mlp c_proj, K-major [3072][768] as bound
+    const float4* w2p;               // ... and repacked in thread order for the 64 / 32-workgroup kernels (launch_gpt_token_pack 4)
     const float *bq, *bp, *bf, *b2, *g1, *be1, *g2, *be2;
 };
 struct GptTokenParams {
@@ -142,6 +145,7 @@ struct GptTokenParams {
     int poll_nap;                    // extra sleep rounds between two polls of an exchange word (default 0)
     int ablate;                      // measurement only, results are garbage (DTTS_GPT_TOKEN_ABLATE): bit 0 = no weight loads (hops and CU hold as
                                      // they are, no weight bytes), bit 1 = no waiting at the exchanges (weight bytes as they are, no hold), bit 2 = exit at once
+    int wgs;                         // 128 (gpt_token.hip) or 64 / 32 (gpt_token_n.hip: sessions of 5 .. 8 rows; the same bits on fewer CUs for longer)
     int min_rows;                    // smallest instantiation a session may take: 1 (default), 4 or 8 (e.g. 8: sessions of <= 4 rows run the 8-row kernel)
 };
 bool gpt_token_supported(int C, int H, int F, int NL, int V);
@@ -149,5 +153,7 @@ bool gpt_token_prepare();            // device check + kernel attributes at bind
 size_t gpt_token_pack_floats(int which);
 void launch_gpt_token_pack(int which, const float* W, int N, int CoutP, float* out, hipStream_t s);
 void launch_gpt_token(const GptTokenParams& p, hipStream_t s);
+bool gpt_token_n_prepare();          // gpt_token_n.hip: kernel attributes of the 64 / 32-workgroup instantiations
+void launch_gpt_token_n(const GptTokenParams& p, hipStream_t s);      // called by launch_gpt_token when p.wgs < 128
 
 }  // namespace dtts

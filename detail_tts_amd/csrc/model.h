@@ -209,6 +209,7 @@ public:
         else if (key == "gpt_token_kernel") { opt_gpt_token_ = value != 0; if (value != 0) tok_failed_ = false; gpt_drop_graphs(); }
         else if (key == "gpt_token_exclusive_cu") { opt_tok_exclusive_ = value != 0; gpt_drop_graphs(); }
         else if (key == "gpt_token_min_rows") { DTTS_REQUIRE(value == 1 || value == 4 || value == 8, "gpt_token_min_rows: 1, 4 or 8"); opt_tok_min_rows_ = value; gpt_drop_graphs(); }
+        else if (key == "gpt_token_wgs") { DTTS_REQUIRE(value == 128 || value == 64 || value == 32, "gpt_token_wgs: 128, 64 or 32"); opt_tok_wgs_ = value; gpt_drop_graphs(); }
         else if (key == "gpt_token_fault") opt_tok_fault_ = value;       // test hook: the n-th token launch from now on times out
         else if (key == "gpt_token_fault_eos") opt_tok_fault_eos_ = value;   // ... and leaves every row flagged finished (a spurious stop token)
         else if (key == "cfg_streams") opt_cfg_streams_ = value < 0 ? 0 : value;
@@ -344,6 +345,7 @@ private:
                                           // 2 x 500 headline requests through infer_stream, one run per setting, every waveform bit-identical to its
                                           // blocking infer() (profiles/r06_soak.txt), and sharing is 0.4 - 0.55 % faster
     int opt_tok_min_rows_ = 1;            // option "gpt_token_min_rows": 1-row sessions take the 1-row token kernel, <= 4 rows the 4-row one (4 / 8: the smallest instantiation allowed)
+    int opt_tok_wgs_ = 128;               // option "gpt_token_wgs": workgroups of the token kernel for sessions of 5 .. 8 rows (64 / 32: gpt_token_n.hip, the same bits)
     bool tok_failed_ = false;             // an exchange timed out once: this handle stays on the chain (until the option is set again)
     int opt_tok_fault_ = 0;               // option "gpt_token_fault"
     int opt_tok_fault_eos_ = 0;           // option "gpt_token_fault_eos"

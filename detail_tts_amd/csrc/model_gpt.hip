@@ -65,7 +65,7 @@ void Model::build_gpt(hipStream_t s) {
     tok_ok_ = tok_ok_ && gpt_token_prepare();            // 128 co-resident workgroups + the opt-in LDS size on THIS device
     tok_failed_ = false;
     if (tok_ok_) {
-        const size_t per_layer = gpt_token_pack_floats(0) + gpt_token_pack_floats(1) + gpt_token_pack_floats(2);
+        const size_t per_layer = gpt_token_pack_floats(0) + gpt_token_pack_floats(1) + gpt_token_pack_floats(2) + gpt_token_pack_floats(4);
         gpt_tokw_.ensure(sizeof(float) * (per_layer * gpt_layers_.size() + gpt_token_pack_floats(3) + GPT_TOKEN_VS) + 65536 +
                          sizeof(GptTokenLayer) * GPT_TOKEN_MAX_LAYERS);
         gpt_tokw_.reset();
@@ -85,6 +85,9 @@ void Model::build_gpt(hipStream_t s) {
             t.wp = reinterpret_cast<const float4*>(pj);
             t.wf = reinterpret_cast<const float4*>(f);
             t.w2 = w.fc2.w;
+            float* f2 = gpt_tokw_.f32(gpt_token_pack_floats(4));
+            launch_gpt_token_pack(4, w.fc2.w, w.fc2.Cout, w.fc2.CoutP, f2, s);
+            t.w2p = reinterpret_cast<const float4*>(f2);
             t.bq = w.attn.b; t.bp = w.proj.b; t.bf = w.fc.b; t.b2 = w.fc2.b;
             t.g1 = w.ln1_g; t.be1 = w.ln1_b; t.g2 = w.ln2_g; t.be2 = w.ln2_b;
         }
@@ -402,6 +405,8 @@ void Model::gpt_step_launches(hipStream_t s) {
         p.ablate = env_ablate;
         static const int env_min_rows = []() { const char* v = getenv("DTTS_GPT_TOKEN_MIN_ROWS"); return v ? atoi(v) : 0; }();
         p.min_rows = env_min_rows ? env_min_rows : opt_tok_min_rows_;
+        static const int env_wgs = []() { const char* v = getenv("DTTS_GPT_TOKEN_WGS"); return v ? atoi(v) : 0; }();
+        p.wgs = env_wgs ? env_wgs : opt_tok_wgs_;
         if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)
             const int one = 1;
             DTTS_CHECK_HIP(hipMemcpyAsync(gs_.tok_err, &one, sizeof(int), hipMemcpyHostToDevice, s));

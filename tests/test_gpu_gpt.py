@@ -287,6 +287,46 @@ def test_one_and_four_row_token_kernels_equal_the_eight_row_token_kernel_bit_for
     assert torch.equal(l1, l1_8)
 
 
+@pytest.mark.parametrize("wgs", [64, 32])
+def test_narrow_token_kernels_equal_the_128_workgroup_kernel_bit_for_bit(rt, wgs):
+    """Round 6: sessions of 5 .. 8 rows on 64 / 32 workgroups (gpt_token_n.hip, option gpt_token_wgs): every workgroup runs 2 / 4 of
+    the 128 virtual workgroups of gpt_token.hip - shared polls / LayerNorms / tiles, fused column GEMVs, streamed weights - with the
+    same thread -> (column, k) mapping and the same order of every sum, so codes AND latents are bit-identical to the 128-workgroup
+    kernel: ragged 8-row and 5-row sessions (free sampling, stop token allowed / suppressed), a teacher-forced 6-row session past
+    384 / 512 keys, and the chain as the third opinion on the codes."""
+    rs = np.random.RandomState(97)
+    for B, G in ((8, 48), (5, 30)):
+        refer = (rs.randn(B, 128, 120) * 2 - 5).astype(np.float32)
+        rl = [120 - 6 * b for b in range(B)]
+        texts = [np.concatenate([rs.randint(3, 255, 5 + (b % 5) * 3), [0]]).astype(np.int32) for b in range(B)]
+        args = (dev(refer), rl, texts, 50 + B, list(range(60, 60 + B)))
+        ref = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+        ref_l = ref[2].clone()
+        e_ref = rt.gpt_generate(*args, max_generate_length=14)
+        rt.set_option("gpt_token_wgs", wgs)
+        try:
+            for _ in range(2):                   # twice: the exchange arena keeps the first session's words, the launch counter keeps counting
+                out = rt.gpt_generate(*args, max_generate_length=G, suppress_eos=True)
+                assert np.array_equal(ref[0], out[0]) and np.array_equal(ref[1], out[1]), (B, wgs)
+                assert torch.equal(ref_l, out[2]), (B, wgs)
+            e = rt.gpt_generate(*args, max_generate_length=14)
+        finally:
+            rt.set_option("gpt_token_wgs", 128)
+        assert np.array_equal(e_ref[0], e[0]) and np.array_equal(e_ref[1], e[1]), (B, wgs)
+    B, G = 6, 160
+    refer = (rs.randn(B, 128, 150) * 2 - 5).astype(np.float32)
+    texts = [np.concatenate([rs.randint(3, 255, 400 - 30 * b), [0]]).astype(np.int32) for b in range(B)]
+    forced = [rs.randint(0, 8192, G).astype(np.int32) for _ in range(B)]
+    args = (dev(refer), None, texts, 9, list(range(3, 3 + B)))
+    l128 = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2].clone()
+    rt.set_option("gpt_token_wgs", wgs)
+    try:
+        ln = rt.gpt_generate(*args, max_generate_length=G + 1, forced_codes=forced)[2].clone()
+    finally:
+        rt.set_option("gpt_token_wgs", 128)
+    assert torch.equal(l128, ln)
+
+
 def test_token_kernel_long_session_equals_the_chain(rt):
     """Sessions whose key count passes 512 (the register-resident K rounds) and 384 (the V rounds) of the persistent token kernel: a
     400-token prompt + 200 teacher-forced tokens, latents against the launch-per-GEMV chain at every position; and free sampling at
