@@ -30,7 +30,7 @@ class DttsConfig(C.Structure):
 class DttsGptOptions(C.Structure):
     _fields_ = [("struct_size", C.c_size_t), ("seed", C.c_ulonglong), ("sample_ids", c_int_p), ("max_generate_length", C.c_int), ("top_k", C.c_int),
                 ("top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float), ("suppress_eos", C.c_int),
-                ("forced_uniforms", C.c_void_p), ("forced_codes", c_int_p), ("row_seeds", c_u64_p), ("typical_mass", C.c_float)]
+                ("forced_uniforms", C.c_void_p), ("forced_codes", c_int_p), ("row_seeds", c_u64_p), ("typical_mass", C.c_float), ("token_wgs", C.c_int)]
 
 
 class DttsKernelStat(C.Structure):

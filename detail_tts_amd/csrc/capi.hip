@@ -192,6 +192,7 @@ static void check_gpt_options(const dtts_gpt_options* o) {
                  "dtts_gpt_options.struct_size does not match this library's layout: start from dtts_gpt_options_init() (built against another include/detail_hip.h?)");
     DTTS_REQUIRE(o->sample_ids, "options: sample_ids");
     DTTS_REQUIRE(o->typical_mass >= 0.f && o->typical_mass <= 1.f, "options: typical_mass outside [0, 1] (0 = off)");      // NaN fails both
+    DTTS_REQUIRE(o->token_wgs == 0 || o->token_wgs == 128 || o->token_wgs == 64 || o->token_wgs == 32, "options: token_wgs is 0 (the handle's option), 128, 64 or 32");
     DTTS_REQUIRE(o->temperature > 0.f && o->temperature < INFINITY && o->top_p >= 0.f && o->top_p <= 1.f && o->repetition_penalty > 0.f &&
                      o->repetition_penalty < INFINITY, "options: temperature / top_p / repetition_penalty out of range");
 }

@@ -41,7 +41,7 @@ template <int NV>
 struct NG {
     static constexpr int TGN = TG / NV;
     static constexpr int SQ = 0, SP = SQ + NV * Q2, SF = SP + NV * P2, SW = SF + NV * F2, LEN = SW + NV * W2;      // stream positions of a layer
-    static constexpr int D = NV == 2 ? 16 : GPT_TOKEN_N_WINDOW;   // weight words in flight per thread
+    static constexpr int D = NV == 2 ? 28 : GPT_TOKEN_N_WINDOW;   // weight words in flight per thread (NV = 2: 14 rounds = ~1.5 us of FMAs ahead, the HBM latency under load)
     static constexpr int HLEN = 3 * NV * H2;                      // mel_head: 3 passes
     static_assert(D <= NV * Q2 && D <= NV * H2, "the window reaches into the next layer's c_attn only");
 };
@@ -78,6 +78,13 @@ __device__ __forceinline__ void pin8(float (&a)[8][2], int c) {
 __device__ __forceinline__ void pin8x3(float (&a)[8][3], int c) {
     asm volatile("" : "+v"(a[0][c]), "+v"(a[1][c]), "+v"(a[2][c]), "+v"(a[3][c]), "+v"(a[4][c]), "+v"(a[5][c]), "+v"(a[6][c]), "+v"(a[7][c]));
 }
+// the thread index behind an opaque zero: what a phase derives from it (LDS addresses, k lanes, exchange offsets) is recomputed there
+// instead of being computed at the top of the layer and kept in registers - or in scratch - across all the other phases
+__device__ __forceinline__ int fresh(int tid) {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return tid + z;
+}
 template <class T>
 __device__ __forceinline__ const T* at_z(const T* p, long long z) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + z); }
 
@@ -107,8 +114,9 @@ __device__ __forceinline__ float4 sload(int pos, const GptTokenLayer& L, const f
 // workgroup j; per virtual workgroup the FMAs, their order, the k-lane partials and their sum are col_gemv's -> the same bits.
 // `issue(pos, n)` loads the words D positions behind pos .. pos + n - 1.
 template <int NV, int PN, int KL, int KT, int POS, int SN, class Issue>
-__device__ __forceinline__ void col_gemv_n(float4 (&s)[SN], Issue&& issue, SmemN<NV>& sm, int tid, float (&out)[NV]) {
+__device__ __forceinline__ void col_gemv_n(float4 (&s)[SN], Issue&& issue, SmemN<NV>& sm, int tid_in, float (&out)[NV]) {
     constexpr int NC = 2 * PN;
+    const int tid = fresh(tid_in);
     static_assert(NR * NC <= 256 && KL * NR * NC <= 4096 && KT % 2 == 0 && POS + NV * (KT / 2) <= SN, "col_gemv_n");
     const int q = tid % PN, kl = tid / PN;
     float acc[NV][NR][2];
@@ -297,10 +305,12 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
         // attention items (head vv / 8, row vv % 8), vv = NV w + it.  Thread (kq = tid / 4, cgp = tid % 4) holds channels [12 cgp, 12 cgp + 12) of
         // the cached keys 4 (kq + 64 u) .. + 3 in registers; item 0's are requested here, before its q can have arrived, item it + 1's
         // when item it's PV sums are done
-        float4 kreg[2][12];
+        float4 kreg[12];
         // (uniform base + a 32-bit lane offset recomputed behind an opaque zero: `global_load v, v_off, s[base]`, and no per-load 64-bit
         // address that the compiler could hoist out of the item loop and keep in registers)
-        auto load_k = [&](int it) __attribute__((always_inline)) {
+        // One round u of 256 keys at a time (48 registers): round 0 is prefetched, round 1 - keys 256 .. 511, which only a session's last
+        // tokens have - is loaded when round 0's scores are done.
+        auto load_k = [&](int it, int u) __attribute__((always_inline)) {
             const int vv = NV * w + it, ah = vv >> 3, ab = vv & 7;
             const bool arow = ab < B;
             const int ncach = arow ? ctl->lp[ab] + ctl->step[ab] - 1 : 0;
@@ -308,20 +318,16 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
             int oz = 0;
             asm volatile("" : "+v"(oz));
             const int to = tid + oz, kq = to >> 2, cgp = to & 3;
+            const int s0 = 4 * (kq + 64 * u);
+            if (arow && s0 < ncach) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int s0 = 4 * (kq + 64 * u);
-                if (arow && s0 < ncach) {
+                for (int c = 0; c < 12; ++c) kreg[c] = ldg4(kb + (unsigned)(((12 * cgp + c) * p.cap + s0) * 4));
+            } else {
 #pragma unroll
-                    for (int c = 0; c < 12; ++c) kreg[u][c] = ldg4(kb + (unsigned)(((12 * cgp + c) * p.cap + s0) * 4));
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) kreg[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int c = 0; c < 12; ++c) kreg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        // its V rows: thread (slot = tid / 4, cg = tid % 4) owns 12 channels of the keys slot + 64 u; requested when the item's scores are
-        // done (keys and V rows are never in registers at the same time: 96 + 72 of a lane's 168)
+        // its V rows: thread (slot = tid / 4, cg = tid % 4) owns 12 channels of the keys slot + 64 u; requested with the keys
         float4 vr[6][3];
         auto load_v = [&](int it) __attribute__((always_inline)) {
             const int vv = NV * w + it, ah = vv >> 3, ab = vv & 7;
@@ -344,7 +350,8 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
                 }
             }
         };
-        load_k(0);
+        load_k(0, 0);
+        load_v(0);
         if (tid < NV * (NR * NQ / 3)) {                        // 6 triples per row and virtual workgroup
             const int j = tid / (NR * NQ / 3), t = tid % (NR * NQ / 3), b = t / (NQ / 3), t3 = t - b * (NQ / 3);
             const float* o = sm.oq[j] + b * NQ + 3 * t3;
@@ -389,15 +396,14 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
                     const float4 qq = *reinterpret_cast<const float4*>(&sm.qkv[0][12 * cgp + 4 * c4]);
                     qv[4 * c4] = qq.x; qv[4 * c4 + 1] = qq.y; qv[4 * c4 + 2] = qq.z; qv[4 * c4 + 3] = qq.w;
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                auto score_round = [&](int u) __attribute__((always_inline)) {
                     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int c = 0; c < 12; ++c) {
-                        a.x += qv[c] * kreg[u][c].x;
-                        a.y += qv[c] * kreg[u][c].y;
-                        a.z += qv[c] * kreg[u][c].z;
-                        a.w += qv[c] * kreg[u][c].w;
+                        a.x += qv[c] * kreg[c].x;
+                        a.y += qv[c] * kreg[c].y;
+                        a.z += qv[c] * kreg[c].z;
+                        a.w += qv[c] * kreg[c].w;
                     }
                     a.x += __shfl_xor(a.x, 1); a.y += __shfl_xor(a.y, 1); a.z += __shfl_xor(a.z, 1); a.w += __shfl_xor(a.w, 1);
                     a.x += __shfl_xor(a.x, 2); a.y += __shfl_xor(a.y, 2); a.z += __shfl_xor(a.z, 2); a.w += __shfl_xor(a.w, 2);
@@ -411,6 +417,11 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
                                 mx = fmaxf(mx, av[e]);
                             }
                     }
+                };
+                score_round(0);
+                if (ncach > 256) {                             // (workgroup-uniform)
+                    load_k(it, 1);
+                    score_round(1);
                 }
                 for (int sk = 512 + tid; sk < ncach; sk += 256) {
                     float d = 0.f;
@@ -429,7 +440,6 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
             }
             const int slot = tid >> 2, cg = tid & 3;
             const float* vp = cb + (size_t)TC * p.cap + ah * TD;
-            load_v(it);                                        // (the key registers are free now; the rows arrive under the softmax)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
             if (lane == 0) sm.mred[wave] = mx;
@@ -477,7 +487,10 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) *reinterpret_cast<float4*>(pv + e * 4) = make_float4(acc[e * 4], acc[e * 4 + 1], acc[e * 4 + 2], acc[e * 4 + 3]);
             }
-            if (it + 1 < NV) load_k(it + 1);                   // (the V registers are free now; the next item's keys arrive under this item's tail)
+            if (it + 1 < NV) {                                 // (the registers are free now; the next item's keys and V rows arrive under this item's tail)
+                load_k(it + 1, 0);
+                load_v(it + 1);
+            }
             __syncthreads();
             if (tid < TD) {
                 float o = 0.f;
@@ -699,15 +712,13 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
     if (w == 0 && tid_k == 0) *p.epoch = epoch + 1;
 }
 
-// 64 workgroups: at most 168 registers per lane (three waves per SIMD's worth), so that a token workgroup takes the place of ONE of a
-// CU's three conv / attention workgroups instead of two; gpt_token_n64u_kernel is the same code without the cap (A/B: DTTS_GPT_TOKEN_N_UNCAPPED=1)
 template <int NV>
-__global__ __launch_bounds__(256) void gpt_token_n_kernel(const GptTokenParams p);
-template <>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gpt_token_n_kernel<2>(const GptTokenParams p) { gpt_token_n_body<2>(p); }
-template <>
-__global__ __launch_bounds__(256) void gpt_token_n_kernel<4>(const GptTokenParams p) { gpt_token_n_body<4>(p); }
-__global__ __launch_bounds__(256) void gpt_token_n64u_kernel(const GptTokenParams p) { gpt_token_n_body<2>(p); }
+__global__ __launch_bounds__(256) void gpt_token_n_kernel(const GptTokenParams p) { gpt_token_n_body<NV>(p); }
+// (Measured and dropped: the 64-workgroup kernel capped at 168 registers per lane - amdgpu_waves_per_eu(3, 3), so that a token workgroup
+// would take the place of ONE of a CU's three 168-register conv workgroups instead of two.  With the keys one round at a time and the
+// window emptied across the attention items the allocator still parked ~50 long-lived values and two window words per layer in scratch;
+// scratch reloads retire in order BEHIND the window's loads: 143 ms per 234 tokens alone instead of 105, 461.5 ms per pipelined step
+// instead of 452.7.  profiles/r06_token_wgs.txt)
 
 template <int NV>
 bool prepare_one() {
@@ -727,15 +738,7 @@ bool prepare_one() {
 
 }  // namespace
 
-bool gpt_token_n_prepare() {
-    try {
-        lds_optin(reinterpret_cast<const void*>(gpt_token_n64u_kernel), LDS_EXCLUSIVE);
-    } catch (const Error&) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return prepare_one<2>() && prepare_one<4>();
-}
+bool gpt_token_n_prepare() { return prepare_one<2>() && prepare_one<4>(); }
 
 // p.wgs = 64 / 32: the token on that many workgroups (sessions of up to 8 rows; bit-identical to launch_gpt_token's 128)
 void launch_gpt_token_n(const GptTokenParams& p, hipStream_t s) {
@@ -744,9 +747,7 @@ void launch_gpt_token_n(const GptTokenParams& p, hipStream_t s) {
     DTTS_REQUIRE(p.cap <= 6144, "persistent decode token: KV capacity over the LDS score buffer");
     const int nv = GPT_TOKEN_WGS / p.wgs;
     const int lds = p.exclusive_cu ? LDS_EXCLUSIVE : (int)(nv == 2 ? sizeof(SmemN<2>) : sizeof(SmemN<4>));
-    static const bool uncapped = []() { const char* v = getenv("DTTS_GPT_TOKEN_N_UNCAPPED"); return v && v[0] == '1'; }();
-    if (nv == 2 && uncapped) hipLaunchKernelGGL(gpt_token_n64u_kernel, dim3(p.wgs), dim3(256), lds, s, p);
-    else if (nv == 2) hipLaunchKernelGGL(gpt_token_n_kernel<2>, dim3(p.wgs), dim3(256), lds, s, p);
+    if (nv == 2) hipLaunchKernelGGL(gpt_token_n_kernel<2>, dim3(p.wgs), dim3(256), lds, s, p);
     else hipLaunchKernelGGL(gpt_token_n_kernel<4>, dim3(p.wgs), dim3(256), lds, s, p);
     DTTS_CHECK_HIP(hipGetLastError());
 }

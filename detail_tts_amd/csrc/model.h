@@ -85,6 +85,7 @@ struct GptSession {
     float* logits = nullptr;
     int* tok_err = nullptr;
     unsigned* tok_epoch = nullptr;
+    int tok_wgs = 128;                 // workgroups of the token kernel for this session (dtts_gpt_options.token_wgs, else option gpt_token_wgs)
 };
 
 struct ResBlock1W {

@@ -314,6 +314,7 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     c.temperature = o.temperature;
     c.top_p = o.top_p;
     c.typical_mass = o.typical_mass;
+    gs_.tok_wgs = o.token_wgs ? o.token_wgs : opt_tok_wgs_;      // latched: a later set_option does not change a running session's kernel
     c.top_k = o.top_k;
     c.suppress_eos = o.suppress_eos;
     c.max_steps = G;
@@ -406,7 +407,7 @@ void Model::gpt_step_launches(hipStream_t s) {
         static const int env_min_rows = []() { const char* v = getenv("DTTS_GPT_TOKEN_MIN_ROWS"); return v ? atoi(v) : 0; }();
         p.min_rows = env_min_rows ? env_min_rows : opt_tok_min_rows_;
         static const int env_wgs = []() { const char* v = getenv("DTTS_GPT_TOKEN_WGS"); return v ? atoi(v) : 0; }();
-        p.wgs = env_wgs ? env_wgs : opt_tok_wgs_;
+        p.wgs = env_wgs ? env_wgs : gs_.tok_wgs;
         if (opt_tok_fault_ > 0 && --opt_tok_fault_ == 0) {      // test hook: what a timed-out exchange leaves behind (flag up, token dead)
             const int one = 1;
             DTTS_CHECK_HIP(hipMemcpyAsync(gs_.tok_err, &one, sizeof(int), hipMemcpyHostToDevice, s));

@@ -153,7 +153,7 @@ class Runtime:
         return out, lens
 
     def gpt_generate(self, refer, refer_lens, texts, seed, sample_ids, max_generate_length=600, top_k=50, top_p=0.8,
-                     temperature=0.8, repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None, forced_fill=8193, typical_mass=0.0):
+                     temperature=0.8, repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None, forced_fill=8193, typical_mass=0.0, token_wgs=0):
         """-> (codes int32 [B,G] incl. stop, ncodes [B], latents_cm float32 cuda [B,768,G])"""
         _check(refer, "refer"); _check(forced_uniforms, "forced_uniforms")
         B, _, Tr = refer.shape
@@ -173,6 +173,7 @@ class Runtime:
         o.top_p, o.temperature, o.repetition_penalty = float(top_p if top_p is not None else 1.0), float(temperature), float(repetition_penalty)
         o.suppress_eos = 1 if suppress_eos else 0
         o.typical_mass = float(typical_mass or 0.0)
+        o.token_wgs = int(token_wgs or 0)       # 0: the handle's gpt_token_wgs option; 64 / 32: this session decodes on fewer workgroups (same bits)
         o.forced_uniforms = forced_uniforms.data_ptr() if forced_uniforms is not None else None
         fc = None
         if forced_codes is not None:
@@ -191,7 +192,7 @@ class Runtime:
 
     # decode session (include/detail_hip.h: dtts_gpt_prefill / _decode_step / _decode / _all_finished / _finish), <= 16 rows
     def gpt_prefill(self, refer, refer_lens, texts, seed, sample_ids, max_generate_length=600, top_k=50, top_p=0.8, temperature=0.8,
-                    repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None, forced_fill=8193, typical_mass=0.0):
+                    repetition_penalty=2.0, suppress_eos=False, forced_uniforms=None, forced_codes=None, forced_fill=8193, typical_mass=0.0, token_wgs=0):
         """conditioning encoder + prefill + first token; returns the latents tensor [B,768,G] the steps fill column by column"""
         _check(refer, "refer"); _check(forced_uniforms, "forced_uniforms")
         B, _, Tr = refer.shape
@@ -211,6 +212,7 @@ class Runtime:
         o.top_p, o.temperature, o.repetition_penalty = float(top_p if top_p is not None else 1.0), float(temperature), float(repetition_penalty)
         o.suppress_eos = 1 if suppress_eos else 0
         o.typical_mass = float(typical_mass or 0.0)
+        o.token_wgs = int(token_wgs or 0)       # 0: the handle's gpt_token_wgs option; 64 / 32: this session decodes on fewer workgroups (same bits)
         o.forced_uniforms = forced_uniforms.data_ptr() if forced_uniforms is not None else None
         if forced_codes is not None:
             fc = np.full((B, G), int(forced_fill), np.int32)      # steps past a row's list: the stop token, or -1 = sample there (a forced PREFIX)

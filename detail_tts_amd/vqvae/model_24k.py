@@ -263,6 +263,10 @@ class SynthesizerTrn:
         trace = self.stream_trace          # a list: per-request host times and stream events (tools/pipeline_trace.py)
         kw = dict(max_generate_length=max_generate_length, top_k=top_k, top_p=TOP_P, temperature=TEMPERATURE,
                   repetition_penalty=REPETITION_PENALTY, suppress_eos=suppress_eos)
+        # Stage A here decodes NEXT TO the previous request's diffusion: its sessions of 5 .. 8 rows take the 64-workgroup token kernel
+        # (gpt_token_n.hip: the same codes and latents bit for bit, 105 instead of 80 ms alone, but half the CUs for 1.3 x as long:
+        # -5 .. -7 ms per pipelined request, profiles/r06_token_wgs.txt); a blocking infer() keeps the 128-workgroup kernel.
+        kw_a = dict(kw, token_wgs=int(os.environ.get("DTTS_STREAM_TOKEN_WGS", "64")))
 
         def parse(req):
             text = torch.as_tensor(req["text"])
@@ -311,7 +315,7 @@ class SynthesizerTrn:
                         assert all(st["forced"] is not None for st in sts), "forced_codes: all requests of a shared session or none"
                         forced = [c for st in sts for c in st["forced"]]
                     self.rt.gpt_prefill(refer, [v for st in sts for v in st["rl"]], [t for st in sts for t in st["texts"]], seeds,
-                                        [v for st in sts for v in st["sids"]], forced_codes=forced, **kw)
+                                        [v for st in sts for v in st["sids"]], forced_codes=forced, **kw_a)
                     if suppress_eos:                           # fixed length: the whole decode is enqueued without a host round trip
                         self.rt.gpt_decode(max_generate_length)
                 else:                                          # more than one decode session: group after group, on this thread / stream

@@ -110,6 +110,10 @@ typedef struct dtts_gpt_options {
     float typical_mass;             /* inference_speech_tortoise(typical_sampling=True, typical_mass): HF TypicalLogitsWarper, applied between
                                      * the repetition penalty and the temperature (gpt/model.py:539); 0 (or 1): off; values outside
                                      * [0, 1] or not finite are rejected */
+    int token_wgs;                  /* workgroups of the persistent decode-token kernel for THIS session of 5 .. 8 rows: 128, 64 or 32 (the same
+                                     * codes and latents bit for bit; fewer workgroups decode longer on fewer CUs - what a session that runs
+                                     * NEXT TO another request's diffusion should ask for: SynthesizerTrn.infer_stream passes 64); 0 = the
+                                     * handle's "gpt_token_wgs" option (default 128: the fastest decode when nothing else runs) */
 } dtts_gpt_options;
 
 /* struct_size + the reference's sampling call (vqvae/model_24k.py:782-792: top_p 0.8, temperature 0.8, repetition_penalty 2.0,
@@ -276,6 +280,11 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 order (deterministic; fp32 summation-order noise against 1 = off); larger launches are unaffected; env DTTS_ATTN_KSPLIT;
  *   "voc_x3"      (default 1): 0 = stage C alone on the exact fp32 kernels (cannot saturate; what infer_stream re-runs a saturated
  *                 request with); "x3_fault" n (test hook): the n-th stage-C ticket from now on is raised as saturated;
+ *   "gpt_token_wgs" (default 128): workgroups of the token kernel for sessions of 5 .. 8 rows whose dtts_gpt_options.token_wgs is 0:
+ *                 64 / 32 = csrc/gpt_token_n.hip, every workgroup runs 2 / 4 of the 128 virtual workgroups (shared polls, LayerNorms and
+ *                 tiles, fused column GEMVs, weights streamed through a register window): codes and latents bit-identical, 105 / 205 ms per
+ *                 234 tokens alone instead of 80, but half / a quarter of the CUs - next to a diffusion 64 is 5 - 7 ms per request
+ *                 faster than 128 and 32 slower (profiles/r06_token_wgs.txt); env DTTS_GPT_TOKEN_WGS overrides both;
  *   "gpt_token_min_rows" (default 1): the smallest instantiation of the token kernel a session may take: 1-row sessions run the
  *                 1-row kernel, sessions of <= 4 rows the 4-row one (round 5: the batch-1 latency case; per row bit-identical to the
  *                 8-row one); 4 / 8 = the smallest allowed is the 4- / 8-row kernel; env DTTS_GPT_TOKEN_MIN_ROWS;

@@ -431,10 +431,13 @@ def _load_zero_lds(rt):
     return go
 
 
-@pytest.mark.parametrize("rows", [8, 3, 1])          # the 8-row (headline), 4-row and 1-row instantiations of the token kernel
-@pytest.mark.parametrize("exclusive", [1, 0])
-@pytest.mark.parametrize("load", ["diffusion", "vocoder", "zero_lds"])
-def test_token_kernel_under_concurrent_load(model, load, exclusive, rows):
+_LOAD_MATRIX = [(load, exclusive, rows, 128) for load in ("diffusion", "vocoder", "zero_lds") for exclusive in (1, 0) for rows in (8, 3, 1)]
+# round 6: the 64- / 32-workgroup instantiations (gpt_token_n.hip; what infer_stream's stage A runs), sharing CUs with the load
+_LOAD_MATRIX += [(load, 0, 8, wgs) for load in ("diffusion", "vocoder", "zero_lds") for wgs in (64, 32)]
+
+
+@pytest.mark.parametrize("load,exclusive,rows,wgs", _LOAD_MATRIX)      # rows: the 8-row (headline), 4-row and 1-row instantiations of the token kernel
+def test_token_kernel_under_concurrent_load(model, load, exclusive, rows, wgs):
     """Stage A's persistent token kernel runs under the previous request's stages B and C in SynthesizerTrn.infer_stream.  200 decode
     sessions repeated while another host thread keeps that load running on its own stream must give the same codes and latents bit
     for bit - with the token workgroups on CUs of their own (exclusive = 1) AND sharing CUs with the load (exclusive = 0: the round-3
@@ -445,7 +448,8 @@ def test_token_kernel_under_concurrent_load(model, load, exclusive, rows):
     gen = _token_session(rt, B=rows)
     rt.set_option("gpt_token_exclusive_cu", exclusive)
     try:
-        c0, l0 = gen()
+        c0, l0 = gen()                                   # (alone, on the 128-workgroup kernel: what every kernel has to reproduce)
+        rt.set_option("gpt_token_wgs", wgs)
         stop = threading.Event()
         failed = []
         rounds = [0]
@@ -471,13 +475,14 @@ def test_token_kernel_under_concurrent_load(model, load, exclusive, rows):
             for _ in range(200):
                 c1, l1 = gen()
                 bad += not (np.array_equal(c0, c1) and torch.equal(l0, l1))
-            assert bad == 0, f"{bad} of 200 {rows}-row sessions differ under the {load} load (exclusive_cu={exclusive})"
+            assert bad == 0, f"{bad} of 200 {rows}-row sessions differ under the {load} load (exclusive_cu={exclusive}, {wgs} workgroups)"
         finally:
             stop.set()
             th.join()
         assert not failed, failed
         assert rounds[0] >= 2, "the load did not run next to the sessions"
     finally:
+        rt.set_option("gpt_token_wgs", 128)
         rt.set_option("gpt_token_exclusive_cu", 0)        # the default since round 6 (profiles/r06_soak.txt)
 
 
