@@ -55,7 +55,8 @@ void launch_flash_attention(const AttnParams& p, hipStream_t stream);
 void launch_flash_attention_x3(const AttnParams& p, hipStream_t stream);   // called by launch_flash_attention when p.x3 (fp32 q, k, v)
 void launch_flash_attention_x3w(const AttnParams& p, hipStream_t stream);  // ... when the operands are AttnPlanes images (round 2-4 kernel: DTTS_ATTN_KERNEL=w)
 void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream);  // ... the block-skewed kernel (default)
-void set_attn_ksplit(int n);      // key ranges per (sample, head, query block) of attention_x3b launches of <= 2 samples: 1 = off, 2 (default) .. 4; process-wide
+void set_attn_ksplit(int n);      // key ranges per (sample, head, query block) of attention_x3b launches of <= 2 samples that do not fill the CUs: 1 = off, 2 .. 4 (default: up to 4); process-wide
+void set_attn_ksplit_cus(int n);  // ... split only while workgroups x S <= n (default 256)
 int attn_ksplit();
 
 // VITS relative-position helpers (vqvae/modules/attentions.py:198-239), W = window (4)

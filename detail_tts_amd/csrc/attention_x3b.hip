@@ -527,14 +527,27 @@ __global__ __launch_bounds__(256, MINB) void flash_attn_x3b_kernel(const AttnPar
 }
 }  // namespace
 
-// option "attn_ksplit" / DTTS_ATTN_KSPLIT (process-wide, like ln_reg): 1 = off, 2 (default) .. 4
+// option "attn_ksplit" / DTTS_ATTN_KSPLIT (process-wide, like ln_reg): the largest split tried, 1 = off, 2 .. 4 (default 4);
+// option "attn_ksplit_cus" / DTTS_ATTN_KSPLIT_CUS: a launch is split only while its workgroups x S stay within this count (default 256 =
+// the CUs; tests raise it to run the split path at any shape)
+static std::atomic<int> g_attn_ksplit_cus{-1};
+void set_attn_ksplit_cus(int n) { g_attn_ksplit_cus.store(n < 1 ? 1 : n, std::memory_order_relaxed); }
+static int attn_ksplit_cus() {
+    int v = g_attn_ksplit_cus.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("DTTS_ATTN_KSPLIT_CUS");
+        set_attn_ksplit_cus(e ? atoi(e) : 256);
+        v = g_attn_ksplit_cus.load(std::memory_order_relaxed);
+    }
+    return v;
+}
 static std::atomic<int> g_attn_ksplit{-1};
 void set_attn_ksplit(int n) { g_attn_ksplit.store(n < 1 ? 1 : (n > 4 ? 4 : n), std::memory_order_relaxed); }
 int attn_ksplit() {
     int v = g_attn_ksplit.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("DTTS_ATTN_KSPLIT");
-        set_attn_ksplit(e ? atoi(e) : 2);
+        set_attn_ksplit(e ? atoi(e) : 4);
         v = g_attn_ksplit.load(std::memory_order_relaxed);
     }
     return v;
@@ -548,17 +561,18 @@ void launch_flash_attention_x3b(const AttnParams& p, hipStream_t stream) {
     static const int occ = []() { const char* v = getenv("DTTS_ATTN_OCC"); return v ? atoi(v) : 2; }();
     const int base = cdiv(p.T, NW * QPW) * p.H * p.B;
     static const int abl = []() { const char* v = getenv("DTTS_ATTN_ABLATE"); return v ? atoi(v) : 0; }();
-    // Key split (round 6): launches of <= 2 samples (the batch-1 CFG pair, single-sample unit calls) cannot fill the chip with
-    // (head, sample, 128-query) workgroups - 256 at T = 936 - and take what ONE wave's serial walk over all 30 key blocks takes.  There
-    // the keys are cut into S ranges, one workgroup each, merged by the last wave to arrive.  Larger launches (the headline's 8-sample
-    // chunks) keep one workgroup per query block: bit-identical to round 5.  DTTS_ATTN_KSPLIT = S (default 2; 1 = off), only while
-    // S x workgroups fit one round of the chip at two workgroups per CU.
+    // Key split (round 6): a launch of <= 2 samples (the batch-1 CFG pair, single-sample unit calls) whose (head, sample, 128-query)
+    // workgroups do not even fill the CUs cuts the keys into S ranges, one workgroup each, merged by the last wave to arrive - but only
+    // while base x S workgroups still find a CU each: at T = 936 the pair's 256 workgroups already occupy every CU and a split buys
+    // nothing (measured: batch-1 diffusion 122.8 ms without, 123.4 / 125.9 / 126.8 ms with S = 2 / 3 / 4, profiles/r06_batch1.txt), so
+    // the headline shapes run exactly round 5's launch.  DTTS_ATTN_KSPLIT = the largest S tried (default 4; 1 = off).
     const int ks_env = attn_ksplit();
     static const int ks_maxb = []() { const char* v = getenv("DTTS_ATTN_KSPLIT_MAXB"); return v ? atoi(v) : 2; }();
+    const int ks_cus = attn_ksplit_cus();
     int S = 1;
-    if (!abl && p.B <= ks_maxb && ks_env > 1 && AttnPlanes::nt64(p.T) >= 2 * ks_env) {
+    if (!abl && p.B <= ks_maxb && ks_env > 1) {
         S = ks_env;
-        while (S > 1 && ((size_t)base * S > X3_MAX_SLABS || (size_t)base * NW > X3_SPLIT_COUNTERS)) --S;
+        while (S > 1 && ((long long)base * S > ks_cus || AttnPlanes::nt64(p.T) < 2 * S || (size_t)base * S > X3_MAX_SLABS || (size_t)base * NW > X3_SPLIT_COUNTERS)) --S;
     }
     const dim3 grid(base * S);
     auto go = [&](auto kern) {

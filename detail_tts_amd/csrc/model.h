@@ -219,6 +219,7 @@ public:
         else if (key == "voc_chain_planes") opt_voc_chain_ = value != 0;
         else if (key == "voc_x3") opt_voc_x3_ = value != 0;                 // 0: stage C on the exact fp32 kernels only (the trunk keeps conv_x3's choice)
         else if (key == "x3_fault") opt_x3_fault_ = value;                  // test hook: the n-th stage-C ticket from now on is raised as saturated
+        else if (key == "attn_ksplit_cus") set_attn_ksplit_cus(value);
         else if (key == "attn_ksplit") set_attn_ksplit(value);             // process-wide: key split of the trunk attention's small launches (attention.h)
         else if (key == "ln_reg") set_ln_channels_reg(value != 0);          // process-wide: the register-resident channel LayerNorm (ops.h)
         else if (key == "integ_pipeline") opt_integ_pipeline_ = value;      // 0 (default) / 1; -1: by batch size (on up to batch 4)

@@ -275,9 +275,12 @@ int dtts_spectrogram(dtts_handle* h, const float* wav, const int* lens, int B, i
  *                 shares its CUs; 0 = it shares CUs with whatever else runs (0.4 - 0.55 % faster under the request pipeline).  A
  *                 scheduling policy, not a correctness requirement: both settings are stress-tested bit-identical under stage B / C
  *                 loads and soaked over 500 pipelined headline requests each (profiles/r06_soak.txt); env DTTS_GPT_TOKEN_EXCLUSIVE_CU;
- *   "attn_ksplit" (default 2; process-wide): trunk-attention launches of <= 2 samples (the batch-1 CFG pair) cut the keys of every
- *                 (sample, head, 128-query block) into that many ranges, one workgroup each, merged by the last wave to arrive in split
- *                 order (deterministic; fp32 summation-order noise against 1 = off); larger launches are unaffected; env DTTS_ATTN_KSPLIT;
+ *   "attn_ksplit" (default 4; process-wide): trunk-attention launches of <= 2 samples (the batch-1 CFG pair) whose (sample, head,
+ *                 128-query block) workgroups do not fill the CUs cut the keys of each into up to that many ranges, one workgroup each,
+ *                 merged by the last wave to arrive in split order (deterministic; fp32 summation-order noise against 1 = off) - only
+ *                 while workgroups x ranges <= "attn_ksplit_cus" (default 256): at T = 936 the pair's 256 workgroups already hold every
+ *                 CU and the split costs 0.6 - 4 ms of a 123 ms diffusion (profiles/r06_batch1.txt), so the headline shapes are not
+ *                 split; larger launches are never split; env DTTS_ATTN_KSPLIT / DTTS_ATTN_KSPLIT_CUS;
  *   "voc_x3"      (default 1): 0 = stage C alone on the exact fp32 kernels (cannot saturate; what infer_stream re-runs a saturated
  *                 request with); "x3_fault" n (test hook): the n-th stage-C ticket from now on is raised as saturated;
  *   "gpt_token_wgs" (default 128): workgroups of the token kernel for sessions of 5 .. 8 rows whose dtts_gpt_options.token_wgs is 0:

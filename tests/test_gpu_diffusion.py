@@ -147,6 +147,7 @@ def test_attention_key_split_of_small_launches_vs_unsplit_and_oracle(rt, weights
     x = (rs.randn(2, 768, T) * ramp[None, None, :]).astype(np.float32)
     p = "diffusion.layers.5.attn"
     try:
+        rt.set_option("attn_ksplit_cus", 1 << 20)          # (by default a launch is split only while its workgroups x S find a CU each)
         rt.set_option("attn_ksplit", 1)
         y1 = host(rt.op_attention_block(p, dev(x), lens))
         rt.set_option("attn_ksplit", S)
@@ -156,7 +157,8 @@ def test_attention_key_split_of_small_launches_vs_unsplit_and_oracle(rt, weights
         rt.set_option("attn_ksplit", 1)
         one1 = host(rt.op_attention_block(p, dev(x[:1, :, :576]), [512]))
     finally:
-        rt.set_option("attn_ksplit", 2)
+        rt.set_option("attn_ksplit", 4)
+        rt.set_option("attn_ksplit_cus", 256)
     assert all(np.array_equal(a, ys) for a in again)
     for b, L in enumerate(lens):
         ref = D.attention_block(weights, p, x[b:b + 1, :, :L], 16)[0]
