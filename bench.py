@@ -28,7 +28,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 matrix peak (no sparsity)
 XS_PRODUCTS = 3.0               # fp16 MFMA products per fp32 product on the split-precision path (csrc/conv_x3.h)
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E 8 TB/s (6.3 TB/s achievable)
-PMC_TRAFFIC = "r05_pmc_layer_traffic.json"      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the trunk kernels (this round)
+PMC_TRAFFIC = "r06_pmc_layer_traffic.json"      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the trunk kernels (this round)
 
 
 def cpu_baseline(W, seed=1234):

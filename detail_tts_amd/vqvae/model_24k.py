@@ -267,6 +267,8 @@ class SynthesizerTrn:
         # (gpt_token_n.hip: the same codes and latents bit for bit, 105 instead of 80 ms alone, but half the CUs for 1.3 x as long:
         # -5 .. -7 ms per pipelined request, profiles/r06_token_wgs.txt); a blocking infer() keeps the 128-workgroup kernel.
         kw_a = dict(kw, token_wgs=int(os.environ.get("DTTS_STREAM_TOKEN_WGS", "64")))
+        # ... except the FIRST group of a stream: nothing runs next to it, so it takes the fastest decode (128 workgroups, 80 ms)
+        a_state = {"first": True}
 
         def parse(req):
             text = torch.as_tensor(req["text"])
@@ -315,7 +317,8 @@ class SynthesizerTrn:
                         assert all(st["forced"] is not None for st in sts), "forced_codes: all requests of a shared session or none"
                         forced = [c for st in sts for c in st["forced"]]
                     self.rt.gpt_prefill(refer, [v for st in sts for v in st["rl"]], [t for st in sts for t in st["texts"]], seeds,
-                                        [v for st in sts for v in st["sids"]], forced_codes=forced, **kw_a)
+                                        [v for st in sts for v in st["sids"]], forced_codes=forced, **(kw if a_state["first"] else kw_a))
+                    a_state["first"] = False
                     if suppress_eos:                           # fixed length: the whole decode is enqueued without a host round trip
                         self.rt.gpt_decode(max_generate_length)
                 else:                                          # more than one decode session: group after group, on this thread / stream
