@@ -486,11 +486,21 @@ def test_token_kernel_under_concurrent_load(model, load, exclusive, rows, wgs):
         rt.set_option("gpt_token_exclusive_cu", 0)        # the default since round 6 (profiles/r06_soak.txt)
 
 
-def test_token_kernel_timeout_is_replayed_on_the_chain(model):
-    """An exchange poll that gives up (the kernel's 128 workgroups not co-resident) must not lose the session: dtts_gpt_finish replays it
+@pytest.mark.parametrize("rows,wgs", [(2, 128), (8, 64), (6, 32)])      # the 4-row kernel; round 6: the 64- / 32-workgroup kernels
+def test_token_kernel_timeout_is_replayed_on_the_chain(model, rows, wgs):
+    """An exchange poll that gives up (the kernel's workgroups not co-resident) must not lose the session: dtts_gpt_finish replays it
     on the launch-per-GEMV chain and the handle stays on the chain.  The test hook raises the error flag before the 7th token launch."""
     rt = model.rt
-    gen = _token_session(rt, seed=11, B=2, G=20)
+    gen = _token_session(rt, seed=11, B=rows, G=20)
+    rt.set_option("gpt_token_wgs", wgs)
+    try:
+        _timeout_replay_body(rt, gen)
+    finally:
+        rt.set_option("gpt_token_wgs", 128)
+        rt.set_option("gpt_token_kernel", 1)
+
+
+def _timeout_replay_body(rt, gen):
     rt.set_option("gpt_token_kernel", 0)
     c_chain, l_chain = gen()
     rt.set_option("gpt_token_kernel", 1)
