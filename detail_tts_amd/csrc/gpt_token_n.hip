@@ -15,10 +15,16 @@
 //     float4 per thread - every consumed word issues the load of the word D positions further down the layer's stream
 //     (c_attn | c_proj | c_fc | mlp c_proj, then the next layer's c_attn), so a workgroup keeps D x 4 KB in flight while it computes and
 //     nothing but D registers x 4 is ever held.  One CU streams 50 - 70 GB/s (tools/ubench/stream_rate.hip): a layer's 28 MB / TGN per
-//     workgroup is 7 / 15 us (NV = 2 / 4), the same order as its FMA issue time.
+//     workgroup is 7 / 15 us (NV = 2 / 4), the same order as its FMA issue time;
+//   * the window is EMPTY across the attention items (c_attn's rounds request nothing beyond their own words; c_proj's and the head of
+//     c_fc's are requested under the AT hop), where the registers hold an item's cached keys (one 256-key round at a time) and V rows
+//     instead, prefetched while the previous item finishes.
+// Measured (one MI355X, profiles/r06_token_wgs.txt): 80 / 105 / 205 ms per 234 tokens alone on 128 / 64 / 32 workgroups; next to a
+// diffusion 64 workgroups make the pipelined step 1.4 % faster than 128 (half the CUs for 1.3 x as long), 32 make it slower: what
+// SynthesizerTrn.infer_stream asks for is 64 (dtts_gpt_options.token_wgs).
 // Every virtual workgroup computes exactly what it computes in gpt_token.hip - same thread -> (column, k) mapping, same order of every
 // sum, same exchange words at the same addresses - so logits, latents and sampled codes are BIT-IDENTICAL to the 128-workgroup kernel
-// (tests/test_gpu_e2e.py::test_narrow_token_kernels_equal_the_128_workgroup_kernel_bit_for_bit); a session may even change kernels
+// (tests/test_gpu_gpt.py::test_narrow_token_kernels_equal_the_128_workgroup_kernel_bit_for_bit); a session may even change kernels
 // between tokens.  The packed weights are the same arrays (virtual workgroups NV w .. NV w + NV - 1 are consecutive slices); only the
 // mlp c_proj gets a packed copy of its own (launch_gpt_token_pack 4), because its 12-byte row loads do not fit the float4 stream.
 #include <cstdio>

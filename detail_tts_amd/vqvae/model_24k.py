@@ -356,6 +356,8 @@ class SynthesizerTrn:
                         st["tr"]["host_a2"] = time.perf_counter()
             return sts
 
+        skip_c_state = {}
+
         def launch_bc(st):
             cur.wait_event(st["a_done"])
             refer, lat, n = st["refer"], st["lat"], st["n"]
@@ -376,8 +378,15 @@ class SynthesizerTrn:
             with torch.cuda.stream(cur if serial_c else sc):
                 if not serial_c:
                     sc.wait_event(ready)
-                wav = self.rt.vocoder(mel, st["seed"], st["sids"], lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
-                ticket = self.vocoder_ticket = self.rt.vocoder_ticket()
+                # DTTS_EXPERIMENT_SKIP_C=1 (measurement only, results are NOT valid synthesis): every request after the first hands out the
+                # first request's waveform instead of running stage C - what stage C costs the step (profiles/r06_stage_c_floor.txt)
+                skip_c = os.environ.get("DTTS_EXPERIMENT_SKIP_C") == "1" and skip_c_state.get("wav") is not None and skip_c_state["n"] == n
+                if skip_c:
+                    wav, ticket = skip_c_state["wav"], skip_c_state["ticket"]
+                else:
+                    wav = self.rt.vocoder(mel, st["seed"], st["sids"], lens=lens_t, noise_scale=noise_scale, stream_chunk=int(vocoder_chunk or 0))
+                    ticket = self.vocoder_ticket = self.rt.vocoder_ticket()
+                    skip_c_state.update(wav=wav, ticket=ticket, n=list(n))
                 mel.record_stream(cur if serial_c else sc)
                 self.vocoder_done = torch.cuda.Event()
                 self.vocoder_done.record(cur if serial_c else sc)
