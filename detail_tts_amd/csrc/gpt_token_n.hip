@@ -356,13 +356,13 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
                 }
             }
         };
-        load_k(0, 0);
-        load_v(0);
         if (tid < NV * (NR * NQ / 3)) {                        // 6 triples per row and virtual workgroup
             const int j = tid / (NR * NQ / 3), t = tid % (NR * NQ / 3), b = t / (NQ / 3), t3 = t - b * (NQ / 3);
             const float* o = sm.oq[j] + b * NQ + 3 * t3;
             q_store(xc, QB + b * (3 * XQ) + (NQ / 3) * (NV * w + j) + t3, o[0], o[1], o[2], tag);
         }
+        load_k(0, 0);                                          // (behind the stores: every other workgroup's items wait for those words, and the
+        load_v(0);                                             //  42 row loads would sit in front of them in the memory pipeline for ~1 us)
         NSTAMP(1);
         // ------------------------------------------------------------------------------------------------ P2: NV attention items
 #pragma unroll 1                                               // (rolled: the layer's code has to stay inside the 64 KB instruction cache)
