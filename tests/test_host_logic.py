@@ -166,6 +166,24 @@ def test_c_abi_exports_every_declared_symbol():
     assert (cfg.diff_channels, cfg.diff_steps, cfg.gpt_mel_codes, cfg.upsample_rates[0]) == (768, 50, 8194, 8)
 
 
+def test_gpt_options_struct_of_the_ctypes_mirror_matches_the_library():
+    """dtts_gpt_options carries its own size: the library refuses a struct of another layout.  dtts_gpt_options_init is
+    host-only, so the CPU suite can check that the ctypes mirror (detail_tts_amd/_lib.py) has exactly the layout the shipped library was
+    built with - including round 6's token_wgs - and the reference's sampling defaults (vqvae/model_24k.py:782-792)."""
+    import ctypes as C
+    from detail_tts_amd import _lib
+    lib = _lib.load()
+    o = _lib.DttsGptOptions()
+    lib.dtts_gpt_options_init(C.byref(o))
+    assert o.struct_size == C.sizeof(_lib.DttsGptOptions)
+    assert (o.max_generate_length, o.top_k, o.token_wgs) == (600, 50, 0)
+    assert abs(o.top_p - 0.8) < 1e-6 and abs(o.temperature - 0.8) < 1e-6 and abs(o.repetition_penalty - 2.0) < 1e-6 and o.typical_mass == 0.0
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "detail_hip.h")).read()
+    body = hdr[hdr.index("typedef struct dtts_gpt_options {"):hdr.index("} dtts_gpt_options;")]
+    for name, _ in _lib.DttsGptOptions._fields_:
+        assert name in body, name
+
+
 def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
     from detail_tts_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
