@@ -148,6 +148,8 @@ __device__ __forceinline__ void col_gemv_n(float4 (&s)[SN], Issue&& issue, SmemN
         issue(POS + i * NV, NV);
         float xn[NR], yn[NR];
         if (i + 1 < KT / 2) tile_rows(i + 1, xn, yn);
+        // (per accumulator the order is col_gemv's - the x term, then the y term -; across accumulators all x terms come first, so that the
+        // two FMAs of one accumulator are 16 NV instructions apart instead of back to back)
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const float4 wv = s[POS + i * NV + j];
@@ -155,6 +157,18 @@ __device__ __forceinline__ void col_gemv_n(float4 (&s)[SN], Issue&& issue, SmemN
             for (int b = 0; b < NR; ++b) {
                 acc[j][b][0] += x[b] * wv.x;
                 acc[j][b][1] += x[b] * wv.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            pin8(acc[j], 0);
+            pin8(acc[j], 1);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 wv = s[POS + i * NV + j];
+#pragma unroll
+            for (int b = 0; b < NR; ++b) {
                 acc[j][b][0] += y[b] * wv.z;
                 acc[j][b][1] += y[b] * wv.w;
             }
@@ -365,7 +379,7 @@ __device__ __forceinline__ void gpt_token_n_body(const GptTokenParams& p) {
         load_v(0);                                             //  42 row loads would sit in front of them in the memory pipeline for ~1 us)
         NSTAMP(1);
         // ------------------------------------------------------------------------------------------------ P2: NV attention items
-#pragma unroll 1                                               // (rolled: the layer's code has to stay inside the 64 KB instruction cache)
+#pragma unroll 1                                               // (rolled: unrolled, the key / V registers of consecutive items overlap and the kernel needs 366 instead of 257 registers)
         for (int it = 0; it < NV; ++it) {
             const int vv = NV * w + it, ah = vv >> 3, ab = vv & 7;
             const bool arow = ab < B;
