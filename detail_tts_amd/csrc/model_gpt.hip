@@ -314,7 +314,11 @@ void Model::gpt_prefill(const float* refer, const int* refer_lens_host, int Tr, 
     c.temperature = o.temperature;
     c.top_p = o.top_p;
     c.typical_mass = o.typical_mass;
-    gs_.tok_wgs = o.token_wgs ? o.token_wgs : opt_tok_wgs_;      // latched: a later set_option does not change a running session's kernel
+    {
+        const int wgs = o.token_wgs ? o.token_wgs : opt_tok_wgs_;      // latched: a later set_option does not change a running session's kernel
+        if (wgs != gs_.tok_wgs) gpt_drop_graphs();                      // (captured decode graphs hold the previous session's kernel choice)
+        gs_.tok_wgs = wgs;
+    }
     c.top_k = o.top_k;
     c.suppress_eos = o.suppress_eos;
     c.max_steps = G;
