@@ -489,19 +489,20 @@ def test_free_sampling_234_tokens_vs_reference_hf_loop(golden, EI, weights):
     g = golden("gpt_generate_fullsize")
     rt = Runtime(weights, folded=True, parts=("gpt",))
     ref = g["codes"][0]
-    for B in (1, 8):                       # alone, and as row 3 of an 8-row decode session (the bench's session shape)
-        rs = np.random.RandomState(17)
+    for B, wgs in ((1, 0), (8, 0), (8, 64), (8, 32)):      # alone; as row 3 of an 8-row decode session (the bench's session shape) on the 128-workgroup
+        rs = np.random.RandomState(17)                      # token kernel and - round 6 - on the 64- / 32-workgroup ones (dtts_gpt_options.token_wgs)
         refer = (rs.randn(B, 128, T) * 2 - 5).astype(np.float32)
         texts = [np.concatenate([rs.randint(3, 255, 60), [0]]).astype(np.int32) for _ in range(B)]
         sids = [200 + b for b in range(B)]
         row = 0 if B == 1 else 3
         refer[row], texts[row], sids[row] = EI["refer"][0], EI["text"][0], int(g["sample_id"])
-        codes, ncodes, _ = rt.gpt_generate(dev(refer), [T] * B, texts, int(g["seed"]), sids, max_generate_length=N_CODES + 1, suppress_eos=True)
+        codes, ncodes, _ = rt.gpt_generate(dev(refer), [T] * B, texts, int(g["seed"]), sids, max_generate_length=N_CODES + 1, suppress_eos=True,
+                                           token_wgs=wgs)
         got = np.asarray(codes[row][: ref.size])
         if not np.array_equal(got, ref):
             k = int(np.nonzero(got != ref)[0][0])
             margin = float(g["f64_margins"][k])
-            assert margin < 1e-6, f"B={B}: first divergent step {k}: got {got[k]}, reference {ref[k]}, CDF margin {margin:.3e} (not a tie)"
+            assert margin < 1e-6, f"B={B} wgs={wgs}: first divergent step {k}: got {got[k]}, reference {ref[k]}, CDF margin {margin:.3e} (not a tie)"
             print(f"\n[free sampling, B={B}] tie at step {k} (CDF margin {margin:.3e}); identical before it")
         else:
             print(f"\n[free sampling, B={B}] all {ref.size} tokens identical to the reference's HF loop (min CDF margin {float(g['f64_margins'].min()):.2e})")
